@@ -1,0 +1,32 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_case_names():
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "case_*.npz")))
+
+
+def load_golden(name):
+    g = dict(np.load(os.path.join(GOLDEN_DIR, f"case_{name}.npz"), allow_pickle=False))
+    g["meta"] = json.loads(str(g["meta"]))
+    return g
+
+
+@pytest.fixture(params=golden_case_names())
+def golden(request):
+    return load_golden(request.param)

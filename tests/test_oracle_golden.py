@@ -1,0 +1,110 @@
+"""Pin the oracle (oracle/) against outputs of the reference itself (tests/golden/*.npz).
+
+The golden files were produced by tests/golden/make_golden.py importing the reference's
+model.py; nothing here reads /root/reference.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import dense_ref, metrics_ref, sparse_ref
+
+
+def _sd(g):
+    return {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+
+
+def _Z_nkd(g):
+    Z = dense_ref.project(torch.from_numpy(g["x"]), _sd(g))          # [K,N,d]
+    return np.ascontiguousarray(Z.permute(1, 0, 2).numpy())          # [N,K,d]
+
+
+def test_dense_forward_matches_reference(golden):
+    g, m = golden, golden["meta"]
+    x, adj = torch.from_numpy(g["x"]), torch.from_numpy(g["adj"])
+    emb, P = dense_ref.forward(x, adj, _sd(g), m["beta"], m["t"])
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(P.numpy(), g["link_pred"], rtol=1e-6, atol=1e-6)
+    Z = dense_ref.project(x, _sd(g))
+    H, e, att, p, s = dense_ref.route_aggregate(Z, adj, m["beta"], m["t"])
+    np.testing.assert_allclose(e.numpy(), g["alpha0"], rtol=1e-6)
+    np.testing.assert_allclose(att.numpy(), g["att"], rtol=1e-6, atol=1e-7)
+    on_edge = g["adj"] == 1
+    assert (p.numpy()[on_edge] == g["p"][on_edge]).all()
+    np.testing.assert_allclose(s.numpy(), g["s"], rtol=1e-6)
+
+
+def test_dense_loss_and_grads_match_reference(golden):
+    g, m = golden, golden["meta"]
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(g).items()}
+    x, adj = torch.from_numpy(g["x"]), torch.from_numpy(g["adj"])
+    _emb, P = dense_ref.forward(x, adj, sd, m["beta"], m["t"])
+    loss = dense_ref.bce_pair_loss(P, torch.from_numpy(g["ori_adj"]), torch.from_numpy(g["pos_mask"]),
+                                   torch.from_numpy(g["neg_mask"]), m["m"])
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    for k, v in sd.items():
+        ref = g["grad__" + k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(v.grad.numpy() - ref).max() <= 1e-4 * scale, k
+
+
+def test_sparse_forward_matches_reference(golden):
+    g, m = golden, golden["meta"]
+    Z = _Z_nkd(g)
+    N, K, d = Z.shape
+    rowptr, col, rev = sparse_ref.csr_from_dense(g["adj"])
+    H, p, a, s_raw = sparse_ref.forward(Z, rowptr, col, m["beta"], m["t"])
+    src = sparse_ref.edge_rows(rowptr)
+    assert (p == g["p"][src, col]).all()
+    np.testing.assert_allclose(a, g["a"][src, col], rtol=2e-6)
+    s = np.where(s_raw == 0, 1, s_raw)
+    np.testing.assert_allclose(s, g["s"], rtol=2e-6)
+    emb = H.reshape(N, K * d)                       # [N,K,d] row-major == cat(h_k, dim=1)
+    np.testing.assert_allclose(emb, g["emb"], rtol=1e-5, atol=2e-6)
+    # every ordered pair, incl. non-edges and the diagonal
+    uu, vv = np.divmod(np.arange(N * N), N)
+    prob = sparse_ref.score_pairs(Z, H, uu, vv, m["t"]).reshape(N, N)
+    np.testing.assert_allclose(prob, g["link_pred"], rtol=1e-5, atol=2e-6)
+    # rev really is the transpose permutation
+    assert (src[rev] == col).all() and (col[rev] == src).all()
+
+
+def test_sparse_backward_matches_reference_grads(golden):
+    """Analytic edge-list backward (Appendix A.3) -> dZ, pushed through the MLP by autograd,
+    must reproduce the reference's parameter gradients."""
+    g, m = golden, golden["meta"]
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(g).items()}
+    x = torch.from_numpy(g["x"])
+    Zt = dense_ref.project(x, sd).permute(1, 0, 2).contiguous()      # [N,K,d]
+    Z = Zt.detach().numpy()
+    N = Z.shape[0]
+    rowptr, col, rev = sparse_ref.csr_from_dense(g["adj"])
+    H, p, a, s_raw = sparse_ref.forward(Z, rowptr, col, m["beta"], m["t"])
+    pu, pv = np.nonzero(g["pos_mask"])
+    nu, nv = np.nonzero(g["neg_mask"])
+    pp = sparse_ref.score_pairs(Z, H, pu, pv, m["t"])
+    pn = sparse_ref.score_pairs(Z, H, nu, nv, m["t"])
+    lab_p, lab_n = g["ori_adj"][pu, pv], g["ori_adj"][nu, nv]
+    loss = metrics_ref.pair_bce(pp, lab_p, pn, lab_n, m["m"])
+    assert abs(loss - float(g["loss"])) <= 2e-5 * max(1.0, abs(float(g["loss"])))
+    gp = metrics_ref.bce_grad(pp, lab_p, 1.0)
+    gn = metrics_ref.bce_grad(pn, lab_n, 1.0 / m["m"])
+    au, av = np.r_[pu, nu], np.r_[pv, nv]
+    dZ_s, dH = sparse_ref.score_pairs_bwd(Z, H, au, av, m["t"], np.r_[gp, gn])
+    dZ = dZ_s + sparse_ref.route_aggregate_bwd(Z, rowptr, col, rev, p, a, s_raw, m["beta"], m["t"], dH)
+    Zt.backward(torch.from_numpy(dZ))
+    for k, v in sd.items():
+        ref = g["grad__" + k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(v.grad.numpy() - ref).max() <= 2e-4 * scale, k
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN_DIR, "auc_*.npz"))))
+def test_auc_matches_sklearn_vectors(path):
+    g = np.load(path)
+    assert abs(metrics_ref.auc_tie_avg(g["y"], g["score"]) - float(g["auc"])) < 1e-12
