@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""edges/sec (aggregate+score) at K=8, d=64 — the metric of BASELINE.json — on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload squirrel|chameleon|...]
+
+One "step" = one forward pass of the hot path over the whole training graph with inputs
+resident in HBM: route (model.py:56-72) + aggregate (model.py:73-75) over the E_sym directed
+non-zeros of the training adjacency, + the pair scorer (model.py:109-113) over the P scored
+training pairs.  value = (E_sym + P) * steps / time  (SURVEY.md §8d headline rate).  The
+projection GEMM and the one-time CSR construction are outside the timed region, as §8d says.
+
+N > 1 is launched by torch.distributed.run, one rank per GPU (see disenlink_amd/dist.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(K, d, n_nodes, n_edges, n_pairs, w=4):
+    """SURVEY.md §8(d), no cache credit: per edge route K*d*w+4+1+4, aggregate d*w+4+1+4+4;
+    per node 2*K*d*w (z_i in both passes) + K*d*w (h_i) + 2*K*4 (s) + 8 (rowptr); per pair 4*K*d*w+8+4."""
+    route = n_edges * (K * d * w + 9) + n_nodes * (K * d * w + K * 4 + 4)
+    aggregate = n_edges * (d * w + 13) + n_nodes * (2 * K * d * w + K * 4 + 4)
+    score = n_pairs * (4 * K * d * w + 12)
+    return dict(route=route, aggregate=aggregate, score=score)
+
+
+def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0):
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.graph import Graph, PairList
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    sg = synthetic_graph(name, seed=seed, scale=scale)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=m, seed=seed)
+    graph = Graph.from_edge_rows(torch.from_numpy(split.train_src).to(device),
+                                 torch.from_numpy(split.train_dst).to(device), sg.n_nodes)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    pairs = PairList.build(torch.from_numpy(pu).to(device), torch.from_numpy(pv).to(device), sg.n_nodes)
+    torch.manual_seed(seed)
+    model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.5, t=1).to(device)
+    x = torch.from_numpy(sg.features()).to(device)
+    with torch.no_grad():
+        Z = model.project(x).contiguous()
+    return sg, split, graph, pairs, model, x, Z
+
+
+def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=30.0):
+    """The oracle's dense restatement (same op sequence as model.py:56-76,109-113) timed on the host
+    cores: one warm-up, then the median of up to 3 passes within the budget."""
+    from oracle import dense_ref
+    N = Z_cpu.shape[0]
+    adj = torch.zeros(N, N)
+    src = torch.repeat_interleave(torch.arange(N), (graph_cpu.rowptr[1:] - graph_cpu.rowptr[:-1]).long())
+    adj[src, graph_cpu.col.long()] = 1
+    Zk = Z_cpu.permute(1, 0, 2).contiguous()
+    times = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.perf_counter()
+            H, e, _att, _p, _s = dense_ref.route_aggregate(Zk, adj, beta, t)
+            P = dense_ref.score_allpairs(H, e)
+            dt = time.perf_counter() - t0
+            del H, e, _att, P
+            if it > 0:
+                times.append(dt)
+            if time.perf_counter() - t_all > budget_s and times:
+                break
+    med = float(np.median(times))
+    return dict(value=n_units / med, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"whole workload, dense [K,N,N] forward (route+aggregate+all-pairs score) of oracle/dense_ref.py, "
+                       f"median of {len(times)} after 1 warm-up, {med:.2f} s per pass",
+                seconds_per_pass=med)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="squirrel")
+    ap.add_argument("--K", type=int, default=8)
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--nhidden", type=int, default=512)
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-generic", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from disenlink_amd import _lib, ops
+    lib = _lib.load()
+    if args.force_generic:
+        lib.dl_set_force_generic(1)
+
+    K, d = args.K, args.d
+    beta, t = 0.5, 1.0
+    if world > 1:
+        from disenlink_amd import dist as dl_dist
+        result = dl_dist.bench_sharded(args, rank, world, device)
+        if rank == 0:
+            print(json.dumps(result))
+        return
+
+    sg, split, graph, pairs, model, x, Z = build_workload(args.workload, device, K, d, args.nhidden, scale=args.scale)
+    E, P, N = graph.n_edges, pairs.n_pairs, graph.n_nodes
+
+    def step():
+        p, a, s = ops.route_fwd(graph, Z, t)
+        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        return p, a, s, H, prob
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+
+    # per-kernel durations with HIP events on the launch stream (torch's current stream), same loop
+    names = ("route", "aggregate", "score")
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    for i in range(args.steps):
+        ev[i][0].record()
+        p, a, s = ops.route_fwd(graph, Z, t)
+        ev[i][1].record()
+        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+        ev[i][2].record()
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        ev[i][3].record()
+    torch.cuda.synchronize()
+    ktime = {n: float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(args.steps)])) * 1e-3
+             for j, n in enumerate(names)}
+    abytes = algorithmic_bytes(K, d, N, E, P)
+    kernels = {n: dict(avg_us=ktime[n] * 1e6, algorithmic_bytes=abytes[n],
+                       achieved_GBs=abytes[n] / ktime[n] / 1e9, frac=abytes[n] / ktime[n] / 1e9 / HBM_PEAK_GBS)
+               for n in names}
+    dom = max(names, key=lambda n: ktime[n])
+    scatter_t = ktime["route"] + ktime["aggregate"]
+    scatter_b = abytes["route"] + abytes["aggregate"]
+
+    units = E + P
+    result = {
+        "metric": "edges/sec (aggregate+score) at K=8 d=64",
+        "value": units * args.steps / wall,
+        "unit": "edges/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-synthetic(seed 0): N={N}, edge rows={sg.src.size}, 85/5/10 split, "
+                               f"E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, beta={beta}, t={t}; "
+                               "forward route+aggregate+score_pairs",
+                   "K": K, "d": d, "n_nodes": N, "E_sym": E, "P": P, "fast_path": bool(lib.dl_has_fast_path(K, d))
+                   and not args.force_generic},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None},
+        "edge_scatter": {"kernels": "route+aggregate", "avg_us": scatter_t * 1e6, "algorithmic_bytes": scatter_b,
+                         "achieved_GBs": scatter_b / scatter_t / 1e9, "frac": scatter_b / scatter_t / 1e9 / HBM_PEAK_GBS,
+                         "edges_per_s": E / scatter_t},
+        "kernels": kernels,
+    }
+    if not args.no_cpu_baseline:
+        gcpu = graph.to("cpu")
+        result["cpu_baseline"] = cpu_baseline(Z.cpu(), gcpu, units, beta, t)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""ctypes binding of libdisenlink_hip.so (include/disenlink_hip.h).
+
+There is no CPU or eager fallback: if the library is missing, or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libdisenlink_hip.so")
+
+
+class DlGraph(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("rev", C.c_void_p),
+        ("seg_len", C.c_int32), ("n_seg", C.c_int32),
+        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("row_seg0", C.c_void_p),
+        ("n_multi", C.c_int32), ("multi_row", C.c_void_p),
+    ]
+
+
+class DlPairIncidence(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_pairs", C.c_int32),
+        ("inc_ptr", C.c_void_p), ("inc_other", C.c_void_p), ("inc_pair", C.c_void_p),
+    ]
+
+
+_P = C.c_void_p          # device pointers travel as integers
+EXPORTS = {
+    # name: (restype, argtypes) -- one entry per symbol declared in include/disenlink_hip.h
+    "dl_version": (C.c_char_p, []),
+    "dl_last_error": (C.c_char_p, []),
+    "dl_has_fast_path": (C.c_int, [C.c_int, C.c_int]),
+    "dl_set_force_generic": (C.c_int, [C.c_int]),
+    "dl_workspace_bytes": (C.c_size_t, [C.POINTER(DlGraph), C.c_int, C.c_int]),
+    "dl_route_fwd": (C.c_int, [C.POINTER(DlGraph), _P, C.c_int, C.c_int, C.c_float,
+                               _P, _P, _P, _P, C.c_size_t, _P]),
+    "dl_aggregate_fwd": (C.c_int, [C.POINTER(DlGraph), _P, C.c_int, C.c_int, C.c_float,
+                                   _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "dl_score_pairs_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     _P, _P, C.c_int, _P, _P]),
+    "dl_score_pairs_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.POINTER(DlPairIncidence), _P, _P, _P, _P, _P]),
+    "dl_route_aggregate_bwd": (C.c_int, [C.POINTER(DlGraph), _P, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+}
+
+_lib = None
+
+
+class DisenlinkHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library once.  Raises if it was not built (python -m disenlink_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DisenlinkHipError(
+            f"{LIB_PATH} not found: the HIP library is required (there is no CPU fallback). "
+            "Build it with `python -m disenlink_amd.build` or __graft_entry__.build().")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dl_last_error().decode(errors="replace")
+        raise DisenlinkHipError(f"{what} failed (code {rc}): {msg}")

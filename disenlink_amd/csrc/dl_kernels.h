@@ -1,0 +1,22 @@
+// Internal launch functions behind the C ABI (dl_api.hip dispatches between them).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "disenlink_hip.h"
+
+namespace dl {
+
+// generic: any K <= 64, any d (dl_generic.hip)
+int generic_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
+                      hipStream_t st);
+int generic_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+                          const float* a, const float* s, float* H, hipStream_t st);
+int generic_score_pairs_fwd(const float* Z, const float* H, int K, int d, float t, const int32_t* pu,
+                            const int32_t* pv, int P, float* prob, hipStream_t st);
+int generic_score_pairs_bwd(const float* Z, const float* H, int N, int K, int d, float t,
+                            const dl_pair_incidence* inc, const float* prob, const float* g_prob, float* dZ,
+                            float* dH, hipStream_t st);
+int generic_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
+                                const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
+                                int accumulate, float* dw, float* da, hipStream_t st);
+
+}  // namespace dl

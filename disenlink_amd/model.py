@@ -1,0 +1,105 @@
+"""Drop-in ``Disentangle`` module: same constructor, ``forward(x, adj)`` signature and
+``state_dict`` keys as the reference's ``model.Disentangle`` (model.py:91-114), with the
+routing / aggregation / scoring path running on libdisenlink_hip.so.
+
+    from disenlink_amd.model import Disentangle          # instead of: from model import Disentangle
+    model = Disentangle(nfeat, nhidden, nembed, nfactor=K, beta=b, t=t).to(device)
+    emb, a_pred = model(x, adj_sym)                       # main_disentangled.py:194
+
+For graphs where ``[N,N]`` cannot exist, ``forward_pairs(x, graph, pairs)`` scores a pair
+list instead; the reference has no counterpart for it.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import Graph, PairList
+
+
+class Factor(nn.Module):
+    """One Linear(F -> d); used when nhid == 1 (model.py:7-15, :94-95)."""
+
+    def __init__(self, nfeat, nhid):
+        super().__init__()
+        self.mlp = nn.Linear(nfeat, nhid)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class Factor2(nn.Module):
+    """Linear(F -> nmid) -> ReLU -> Linear(nmid -> d) (model.py:16-27, :96-97)."""
+
+    def __init__(self, nfeat, nmid, nhid):
+        super().__init__()
+        self.mlp1 = nn.Linear(nfeat, nmid)
+        self.mlp2 = nn.Linear(nmid, nhid)
+
+    def forward(self, x):
+        return self.mlp2(F.relu(self.mlp1(x)))
+
+
+class Disentangle(nn.Module):
+    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1):
+        super().__init__()
+        # creation order == the reference's (model.py:93-99), so a seeded init draws the same stream
+        if nhid == 1:
+            factors = [Factor(nfeat, nebed) for _ in range(nfactor)]
+        else:
+            factors = [Factor2(nfeat, nhid, nebed) for _ in range(nfactor)]
+        for i, f in enumerate(factors):
+            self.add_module("factor_{}".format(i), f)
+        self.single_layer = nhid == 1
+        self.temperature = t
+        self.nfactor = nfactor
+        self.nebed = nebed
+        self.beta = beta
+        self._graph_cache = None
+
+    @property
+    def factors(self):
+        return [getattr(self, "factor_{}".format(i)) for i in range(self.nfactor)]
+
+    # ------------------------------------------------------------------ projection (model.py:106)
+    def project(self, x: torch.Tensor) -> torch.Tensor:
+        """Z [N,K,d] = K independent MLPs of x, as one wide GEMM + one K-batched GEMM."""
+        fs = self.factors
+        K, d = self.nfactor, self.nebed
+        if self.single_layer:
+            W = torch.cat([f.mlp.weight for f in fs], dim=0)             # [K*d, F]
+            b = torch.cat([f.mlp.bias for f in fs], dim=0)
+            return F.linear(x, W, b).view(-1, K, d)
+        W1 = torch.cat([f.mlp1.weight for f in fs], dim=0)               # [K*nhid, F]
+        b1 = torch.cat([f.mlp1.bias for f in fs], dim=0)
+        hid = F.relu(F.linear(x, W1, b1)).view(x.shape[0], K, -1)        # [N,K,nhid]
+        W2 = torch.stack([f.mlp2.weight for f in fs], dim=0)             # [K,d,nhid]
+        b2 = torch.stack([f.mlp2.bias for f in fs], dim=0)               # [K,d]
+        Z = torch.einsum("nkh,kdh->nkd", hid, W2) + b2
+        return Z.contiguous()
+
+    # ------------------------------------------------------------------ graph cache
+    def _graph_for(self, adj: torch.Tensor) -> Graph:
+        key = (adj.data_ptr(), tuple(adj.shape), adj._version, adj.device)
+        if self._graph_cache is None or self._graph_cache[0] != key:
+            self._graph_cache = (key, Graph.from_dense(adj))
+        return self._graph_cache[1]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, adj):
+        """(emb [N,K*d], link_pred [N,N]) exactly as model.py:105-114; ``adj`` is the dense adj_sym
+        (or a prebuilt ``Graph``)."""
+        graph = adj if isinstance(adj, Graph) else self._graph_for(adj)
+        Z = self.project(x)
+        H = ops.RouteAggregate.apply(Z, graph, float(self.beta), float(self.temperature))
+        link_pred = ops.ScoreAllPairs.apply(Z, H, float(self.temperature))
+        return H.view(H.shape[0], -1), link_pred
+
+    def forward_pairs(self, x, graph: Graph, pairs: PairList):
+        """(emb [N,K*d], prob [P]) — the same model evaluated on a pair list only."""
+        Z = self.project(x)
+        H = ops.RouteAggregate.apply(Z, graph, float(self.beta), float(self.temperature))
+        prob = ops.ScorePairs.apply(Z, H, pairs, float(self.temperature))
+        return H.view(H.shape[0], -1), prob

@@ -1,0 +1,215 @@
+"""Operators of the DisenLink hot path over libdisenlink_hip.so.
+
+Raw wrappers (``route_fwd`` ...) take/return device tensors and launch on torch's current
+stream; the ``autograd.Function``s stitch them into the graph so that the reference's
+training loop (``loss.backward()``, main_disentangled.py:198) works unchanged.
+
+There is no fallback: tensors must be CUDA(HIP) fp32 tensors and the library must be built.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .graph import Graph, PairList
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise _lib.DisenlinkHipError(
+                "disenlink_amd operators run only on the GPU through libdisenlink_hip.so "
+                "(there is no CPU fallback); got a tensor on " + str(t.device))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _nkd(Z: torch.Tensor):
+    if Z.dim() != 3:
+        raise ValueError("Z/H must be [N, K, d]")
+    return Z.shape[0], Z.shape[1], Z.shape[2]
+
+
+class _Workspace:
+    """Grow-only scratch per device; the C ABI never allocates."""
+
+    def __init__(self):
+        self.buf: dict = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        cur = self.buf.get(device)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=device)
+            self.buf[device] = cur
+        return cur
+
+
+_ws = _Workspace()
+
+
+def _workspace(g: Graph, K: int, d: int):
+    lib = _lib.load()
+    need = int(lib.dl_workspace_bytes(g.c_struct(), K, d))
+    buf = _ws.get(need, g.device)
+    return buf, need
+
+
+# ---------------------------------------------------------------------- raw wrappers
+def route_fwd(g: Graph, Z: torch.Tensor, t: float):
+    """-> p uint8[E], a f32[E], s f32[N,K] (raw sums).  model.py:56-72 on the edges of adj."""
+    lib = _lib.load()
+    Z = _f32c(Z)
+    _need_cuda(Z, g.rowptr)
+    N, K, d = _nkd(Z)
+    if N != g.n_nodes:
+        raise ValueError(f"Z has {N} rows, graph has {g.n_nodes} nodes")
+    p = torch.empty(g.n_edges, dtype=torch.uint8, device=Z.device)
+    a = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
+    s = torch.empty((N, K), dtype=torch.float32, device=Z.device)
+    ws, nb = _workspace(g, K, d)
+    _lib.check(lib.dl_route_fwd(g.c_struct(), Z.data_ptr(), K, d, float(t), p.data_ptr(), a.data_ptr(),
+                                s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_route_fwd")
+    return p, a, s
+
+
+def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s) -> torch.Tensor:
+    """-> H f32[N,K,d].  model.py:73-75."""
+    lib = _lib.load()
+    Z = _f32c(Z)
+    _need_cuda(Z, g.rowptr, p, a, s)
+    N, K, d = _nkd(Z)
+    if N != g.n_nodes:
+        raise ValueError(f"Z has {N} rows, graph has {g.n_nodes} nodes")
+    H = torch.empty_like(Z)
+    ws, nb = _workspace(g, K, d)
+    _lib.check(lib.dl_aggregate_fwd(g.c_struct(), Z.data_ptr(), K, d, float(beta), p.data_ptr(), a.data_ptr(),
+                                    s.data_ptr(), H.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "dl_aggregate_fwd")
+    return H
+
+
+def score_pairs_fwd(Z, H, pu, pv, t: float) -> torch.Tensor:
+    """-> prob f32[P].  model.py:109-113 at the listed pairs."""
+    lib = _lib.load()
+    Z, H = _f32c(Z), _f32c(H)
+    _need_cuda(Z, H, pu, pv)
+    N, K, d = _nkd(Z)
+    if H.shape != Z.shape:
+        raise ValueError("Z and H differ in shape")
+    if pu.dtype != torch.int32 or pv.dtype != torch.int32:
+        raise TypeError("pair indices must be int32")
+    P = int(pu.numel())
+    prob = torch.empty(P, dtype=torch.float32, device=Z.device)
+    _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pu.data_ptr(), pv.data_ptr(),
+                                      P, prob.data_ptr(), _stream()), "dl_score_pairs_fwd")
+    return prob
+
+
+def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob):
+    """-> dZ, dH f32[N,K,d]."""
+    lib = _lib.load()
+    Z, H, prob, g_prob = _f32c(Z), _f32c(H), _f32c(prob), _f32c(g_prob)
+    _need_cuda(Z, H, prob, g_prob, pairs.inc_ptr)
+    N, K, d = _nkd(Z)
+    if prob.numel() != pairs.n_pairs or g_prob.numel() != pairs.n_pairs:
+        raise ValueError("prob / g_prob length differs from the pair list")
+    dZ = torch.empty_like(Z)
+    dH = torch.empty_like(Z)
+    _lib.check(lib.dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pairs.c_struct(),
+                                      prob.data_ptr(), g_prob.data_ptr(), dZ.data_ptr(), dH.data_ptr(), _stream()),
+               "dl_score_pairs_bwd")
+    return dZ, dH
+
+
+def route_aggregate_bwd(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_accum=None) -> torch.Tensor:
+    """-> dZ f32[N,K,d] (added onto ``dZ_accum`` in place when given)."""
+    lib = _lib.load()
+    Z, dH = _f32c(Z), _f32c(dH)
+    _need_cuda(Z, dH, g.rowptr, p, a, s)
+    N, K, d = _nkd(Z)
+    if dZ_accum is None:
+        dZ, acc = torch.empty_like(Z), 0
+    else:
+        if not dZ_accum.is_contiguous() or dZ_accum.shape != Z.shape:
+            raise ValueError("dZ_accum must be a contiguous [N,K,d] tensor")
+        dZ, acc = dZ_accum, 1
+    ws, nb = _workspace(g, K, d)
+    _lib.check(lib.dl_route_aggregate_bwd(g.c_struct(), Z.data_ptr(), K, d, float(beta), float(t), p.data_ptr(),
+                                          a.data_ptr(), s.data_ptr(), dH.data_ptr(), dZ.data_ptr(), acc,
+                                          ws.data_ptr(), ws.numel(), _stream()), "dl_route_aggregate_bwd")
+    return dZ
+
+
+# ---------------------------------------------------------------------- autograd
+class RouteAggregate(torch.autograd.Function):
+    """Z [N,K,d] -> H [N,K,d]: Disentangle_layer.forward (model.py:55-77) on the CSR of adj."""
+
+    @staticmethod
+    def forward(ctx, Z, graph: Graph, beta: float, t: float):
+        Z = _f32c(Z)
+        p, a, s = route_fwd(graph, Z, t)
+        H = aggregate_fwd(graph, Z, beta, p, a, s)
+        ctx.graph, ctx.beta, ctx.t = graph, beta, t
+        ctx.save_for_backward(Z, a, s)
+        ctx.p = p
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        Z, a, s = ctx.saved_tensors
+        dZ = route_aggregate_bwd(ctx.graph, Z, ctx.beta, ctx.t, ctx.p, a, s, dH.contiguous())
+        return dZ, None, None, None
+
+
+class ScorePairs(torch.autograd.Function):
+    """(Z, H) -> prob[P] at the listed pairs: model.py:109-113 + sigmoid."""
+
+    @staticmethod
+    def forward(ctx, Z, H, pairs: PairList, t: float):
+        Z, H = _f32c(Z), _f32c(H)
+        prob = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        ctx.pairs, ctx.t = pairs, t
+        ctx.save_for_backward(Z, H, prob)
+        return prob
+
+    @staticmethod
+    def backward(ctx, g_prob):
+        Z, H, prob = ctx.saved_tensors
+        dZ, dH = score_pairs_bwd(Z, H, ctx.pairs, ctx.t, prob, g_prob.contiguous())
+        return dZ, dH, None, None
+
+
+class ScoreAllPairs(torch.autograd.Function):
+    """(Z, H) -> prob [N,N], the dense output the reference's caller indexes with masks
+    (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero."""
+
+    @staticmethod
+    def forward(ctx, Z, H, t: float):
+        Z, H = _f32c(Z), _f32c(H)
+        N = Z.shape[0]
+        idx = torch.arange(N, device=Z.device, dtype=torch.int32)
+        pu = idx.repeat_interleave(N)
+        pv = idx.repeat(N)
+        prob = score_pairs_fwd(Z, H, pu, pv, t).view(N, N)
+        ctx.t = t
+        ctx.save_for_backward(Z, H, prob)
+        return prob
+
+    @staticmethod
+    def backward(ctx, g_prob):
+        Z, H, prob = ctx.saved_tensors
+        N = Z.shape[0]
+        nz = torch.nonzero(g_prob)
+        pairs = PairList.build(nz[:, 0], nz[:, 1], N)
+        flat = nz[:, 0] * N + nz[:, 1]
+        dZ, dH = score_pairs_bwd(Z, H, pairs, ctx.t, prob.reshape(-1)[flat].contiguous(),
+                                 g_prob.reshape(-1)[flat].contiguous())
+        return dZ, dH, None

@@ -1,0 +1,230 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors of the reference and
+against the CPU oracle on seeded inputs.  Tolerances: fp32, abs/rel 1e-5 on embeddings and
+probabilities, 1e-4 relative on parameter gradients, AUC 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case_names, load_golden
+from oracle import dense_ref, metrics_ref, sparse_ref
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from disenlink_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.load()
+
+
+def _sd(g):
+    return {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+
+
+def _Z(g):
+    Z = dense_ref.project(torch.from_numpy(g["x"]), _sd(g)).permute(1, 0, 2).contiguous()
+    return Z.numpy()
+
+
+def _decisive(alpha, margin=1e-5):
+    """edges whose top-2 routing weights differ by more than `margin` (ties may flip in fp32)."""
+    if alpha.shape[1] == 1:
+        return np.ones(alpha.shape[0], bool)
+    top = np.sort(alpha, axis=1)
+    return (top[:, -1] - top[:, -2]) > margin
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("name", golden_case_names())
+def test_forward_kernels_match_reference_golden(name, force_generic):
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph
+    g = load_golden(name)
+    m = g["meta"]
+    N, K, d = m["N"], m["K"], m["d"]
+    old = _lib.load().dl_set_force_generic(force_generic)
+    try:
+        Zh = _Z(g)
+        Z = torch.from_numpy(Zh).to(DEV)
+        G = Graph.from_dense(torch.from_numpy(g["adj"]).to(DEV), seg_len=8)
+        p, a, s = ops.route_fwd(G, Z, m["t"])
+        rowptr, col, _rev = sparse_ref.csr_from_dense(g["adj"])
+        src = sparse_ref.edge_rows(rowptr)
+        _p, _a, alpha, _s = sparse_ref.route(Zh, rowptr, col, m["t"])
+        ok = _decisive(alpha)
+        assert ok.mean() > 0.95
+        assert (p.cpu().numpy()[ok] == g["p"][src, col][ok]).all()
+        np.testing.assert_allclose(a.cpu().numpy()[ok], g["a"][src, col][ok], rtol=1e-5)
+        if ok.all():
+            s_h = s.cpu().numpy()
+            np.testing.assert_allclose(np.where(s_h == 0, 1, s_h), g["s"], rtol=1e-5)
+        H = ops.aggregate_fwd(G, Z, m["beta"], p, a, s)
+        if ok.all():
+            np.testing.assert_allclose(H.cpu().numpy().reshape(N, K * d), g["emb"], rtol=1e-5, atol=1e-5)
+        idx = torch.arange(N, dtype=torch.int32, device=DEV)
+        prob = ops.score_pairs_fwd(Z, H, idx.repeat_interleave(N), idx.repeat(N), m["t"]).view(N, N)
+        if ok.all():
+            np.testing.assert_allclose(prob.cpu().numpy(), g["link_pred"], rtol=1e-5, atol=1e-5)
+    finally:
+        _lib.load().dl_set_force_generic(old)
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("name", golden_case_names())
+def test_dropin_module_loss_and_grads_match_reference(name, force_generic):
+    """The reference's own call sequence (model(x, adj_sym) -> masked BCE -> backward,
+    main_disentangled.py:194-198) on the drop-in module vs. the reference's loss and gradients."""
+    from disenlink_amd import _lib
+    from disenlink_amd.model import Disentangle
+    import torch.nn.functional as F
+    g = load_golden(name)
+    m = g["meta"]
+    old = _lib.load().dl_set_force_generic(force_generic)
+    try:
+        model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
+        model.load_state_dict(_sd(g))
+        model = model.to(DEV)
+        x = torch.from_numpy(g["x"]).to(DEV)
+        adj = torch.from_numpy(g["adj"]).to(DEV)
+        ori = torch.from_numpy(g["ori_adj"]).to(DEV)
+        pm = torch.from_numpy(g["pos_mask"]).to(DEV)
+        nm = torch.from_numpy(g["neg_mask"]).to(DEV)
+        emb, a_pred = model(x, adj)
+        assert emb.shape == (m["N"], m["K"] * m["d"]) and a_pred.shape == (m["N"], m["N"])
+        loss = (F.binary_cross_entropy(a_pred[pm == 1].unsqueeze(0), ori[pm == 1].unsqueeze(0))
+                + F.binary_cross_entropy(a_pred[nm == 1].unsqueeze(0), ori[nm == 1].unsqueeze(0)) / m["m"])
+        model.zero_grad()
+        loss.backward()
+        np.testing.assert_allclose(emb.detach().cpu().numpy(), g["emb"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(a_pred.detach().cpu().numpy(), g["link_pred"], rtol=1e-5, atol=1e-5)
+        assert abs(loss.item() - float(g["loss"])) <= 2e-5 * max(1.0, abs(float(g["loss"])))
+        for k, prm in model.named_parameters():
+            ref = g["grad__" + k]
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(prm.grad.cpu().numpy() - ref).max()
+            assert err <= 1e-4 * scale, (k, err, scale)
+        # AUC on fp32 probabilities with tie-averaged ranks (main_disentangled.py:202-204)
+        mask = (g["pos_mask"] + g["neg_mask"]) > 0
+        y = g["ori_adj"][mask]
+        if 0 < y.sum() < y.size:
+            auc_gpu = metrics_ref.auc_tie_avg(y, a_pred.detach().cpu().numpy()[mask])
+            auc_ref = metrics_ref.auc_tie_avg(y, g["link_pred"][mask])
+            assert abs(auc_gpu - auc_ref) <= 1e-4
+    finally:
+        _lib.load().dl_set_force_generic(old)
+
+
+def _random_problem(seed, N, K, d, avg_deg, hub=True, scale=0.35):
+    rng = np.random.default_rng(seed)
+    E = N * avg_deg // 2
+    src = rng.integers(0, N, E)
+    dst = rng.integers(0, N, E)
+    if hub:
+        hub_nb = rng.choice(N, size=min(N - 1, 40 * avg_deg), replace=False)
+        src = np.r_[src, np.zeros_like(hub_nb)]
+        dst = np.r_[dst, hub_nb]
+    iso = N - 1
+    keep = (src != iso) & (dst != iso)
+    src, dst = src[keep], dst[keep]
+    Z = (rng.standard_normal((N, K, d)) * scale).astype(np.float32)
+    return src, dst, Z, rng
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("K,d,N,deg", [(8, 64, 600, 12), (4, 32, 500, 9), (16, 128, 200, 8), (5, 64, 300, 10),
+                                        (3, 5, 97, 6), (1, 16, 64, 5), (8, 64, 2000, 30)])
+def test_forward_and_backward_match_oracle_on_random_graphs(K, d, N, deg, force_generic):
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph, PairList
+    beta, t = 0.6, 1.0
+    src, dst, Zh, rng = _random_problem(K * 1000 + d, N, K, d, deg)
+    old = _lib.load().dl_set_force_generic(force_generic)
+    try:
+        G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+        rowptr, col, rev = sparse_ref.csr_from_pairs(src, dst, N, symmetrise=True)
+        assert np.array_equal(G.rowptr.cpu().numpy(), rowptr) and np.array_equal(G.rev.cpu().numpy(), rev)
+        Z = torch.from_numpy(Zh).to(DEV)
+        p, a, s = ops.route_fwd(G, Z, t)
+        p_o, a_o, alpha, s_o = sparse_ref.route(Zh, rowptr, col, t)
+        ok = _decisive(alpha)
+        assert (p.cpu().numpy()[ok] == p_o[ok]).all()
+        np.testing.assert_allclose(a.cpu().numpy()[ok], a_o[ok], rtol=1e-5)
+        # continue from the GPU's own routing so a flipped near-tie does not poison the rest
+        p_h, a_h, s_h = p.cpu().numpy(), a.cpu().numpy(), s.cpu().numpy()
+        s_chk = np.zeros_like(s_h)
+        np.add.at(s_chk, (sparse_ref.edge_rows(rowptr), p_h.astype(np.int64)), a_h)
+        np.testing.assert_allclose(s_h, s_chk, rtol=1e-5, atol=1e-7)
+        assert (s_h[N - 1] == 0).all()                                   # isolated node
+        H = ops.aggregate_fwd(G, Z, beta, p, a, s)
+        H_o = sparse_ref.aggregate(Zh, rowptr, col, p_h, a_h, s_h, beta)
+        np.testing.assert_allclose(H.cpu().numpy(), H_o, rtol=1e-5, atol=1e-5)
+        P = 4000
+        pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
+        pu[:5] = pv[:5]
+        pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        prob_o = sparse_ref.score_pairs(Zh, H_o, pu, pv, t)
+        np.testing.assert_allclose(prob.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
+        # backward
+        gp = (rng.standard_normal(P) * 0.1).astype(np.float32)
+        dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, torch.from_numpy(gp).to(DEV))
+        dZs_o, dH_o = sparse_ref.score_pairs_bwd(Zh, H_o, pu, pv, t, gp)
+        tol = lambda ref: 1e-4 * max(np.abs(ref).max(), 1e-6)
+        assert np.abs(dH.cpu().numpy() - dH_o).max() <= tol(dH_o)
+        assert np.abs(dZs.cpu().numpy() - dZs_o).max() <= tol(dZs_o)
+        dZ = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH)
+        dZ_o = sparse_ref.route_aggregate_bwd(Zh, rowptr, col, rev, p_h, a_h, s_h, beta, t, dH_o)
+        assert np.abs(dZ.cpu().numpy() - dZ_o).max() <= tol(dZ_o)
+        # accumulate flag adds onto an existing buffer
+        base = torch.full_like(Z, 0.5)
+        dZ2 = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH, dZ_accum=base)
+        np.testing.assert_allclose(dZ2.cpu().numpy(), dZ.cpu().numpy() + 0.5, rtol=1e-5, atol=1e-5)
+        # bitwise reproducible: no float atomics anywhere
+        p2, a2, s2 = ops.route_fwd(G, Z, t)
+        H2 = ops.aggregate_fwd(G, Z, beta, p2, a2, s2)
+        dZ3 = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH)
+        assert torch.equal(p, p2) and torch.equal(a, a2) and torch.equal(s, s2)
+        assert torch.equal(H, H2) and torch.equal(dZ, dZ3)
+    finally:
+        _lib.load().dl_set_force_generic(old)
+
+
+def test_empty_and_degenerate_inputs():
+    from disenlink_amd import ops
+    from disenlink_amd.graph import Graph, PairList
+    z0 = torch.zeros(0, dtype=torch.long)
+    N, K, d = 5, 4, 32
+    G = Graph.from_edge_rows(z0, z0, N).to(DEV)                          # no edges at all
+    Z = torch.randn(N, K, d, device=DEV)
+    p, a, s = ops.route_fwd(G, Z, 1.0)
+    assert p.numel() == 0 and bool((s == 0).all())
+    H = ops.aggregate_fwd(G, Z, 0.7, p, a, s)
+    np.testing.assert_allclose(H.cpu().numpy(), 0.7 * Z.cpu().numpy(), rtol=1e-6)   # h = beta z
+    pairs = PairList.build(z0.to(DEV), z0.to(DEV), N)
+    prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, 1.0)
+    assert prob.numel() == 0
+    dZ, dH = ops.score_pairs_bwd(Z, H, pairs, 1.0, prob, prob)
+    assert bool((dZ == 0).all()) and bool((dH == 0).all())
+    dZ = ops.route_aggregate_bwd(G, Z, 0.7, 1.0, p, a, s, torch.ones_like(Z))
+    np.testing.assert_allclose(dZ.cpu().numpy(), 0.7, rtol=1e-6)
+
+
+def test_exp_overflow_propagates_like_the_reference():
+    """No max-subtraction in the softmax (model.py:56-60): huge dots give inf/inf = NaN, as on the CPU."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import Graph
+    N, K, d = 4, 2, 8
+    Zh = np.full((N, K, d), 4.0, np.float32)                            # z.z = 128 > 88.7 -> exp = inf
+    Zh[3] = 0.1
+    src, dst = np.array([0, 1, 2]), np.array([1, 2, 3])
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+    rowptr, col, _ = sparse_ref.csr_from_pairs(src, dst, N, symmetrise=True)
+    p, a, s = ops.route_fwd(G, torch.from_numpy(Zh).to(DEV), 1.0)
+    p_o, a_o, _alpha, _s = sparse_ref.route(Zh, rowptr, col, 1.0)
+    assert np.array_equal(np.isnan(a.cpu().numpy()), np.isnan(a_o))
+    assert np.array_equal(p.cpu().numpy(), p_o)
+    fin = ~np.isnan(a_o)
+    np.testing.assert_allclose(a.cpu().numpy()[fin], a_o[fin], rtol=1e-6)

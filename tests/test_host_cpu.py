@@ -1,0 +1,130 @@
+"""CPU-only checks: the C-ABI library loads and exports what the header declares, the host-side
+graph/pair plumbing matches the oracle, and the product path refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_case_names, load_golden
+from oracle import dense_ref, sparse_ref
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "disenlink_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from disenlink_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/disenlink_hip.h but not exported"
+        assert n in _lib.EXPORTS, f"{n} has no ctypes signature in _lib.EXPORTS"
+    assert set(_lib.EXPORTS) == set(names)
+    assert b"gfx950" in lib.dl_version()
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from disenlink_amd import _lib
+    lib = _lib.load()
+    g = _lib.DlGraph()
+    rc = lib.dl_route_fwd(None, None, 4, 8, 1.0, None, None, None, None, 0, None)
+    assert rc == -1 and b"NULL" in lib.dl_last_error()
+    import ctypes as C
+    rc = lib.dl_route_fwd(C.byref(g), None, 0, 8, 1.0, None, None, None, None, 0, None)
+    assert rc == -1 and b"K=0" in lib.dl_last_error()
+    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, 0.0, None, None, None, None, 0, None)
+    assert rc == -1 and b"temperature" in lib.dl_last_error()
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph
+    g = Graph.from_edge_rows(torch.tensor([0, 1]), torch.tensor([1, 2]), 3)
+    Z = torch.randn(3, 2, 4)
+    with pytest.raises(_lib.DisenlinkHipError, match="no CPU fallback"):
+        ops.route_fwd(g, Z, 1.0)
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_graph_builder_matches_oracle_csr(name):
+    from disenlink_amd.graph import Graph
+    g = load_golden(name)
+    rowptr, col, rev = sparse_ref.csr_from_dense(g["adj"])
+    for seg_len in (1, 4, 32):
+        G = Graph.from_dense(torch.from_numpy(g["adj"]), seg_len=seg_len)
+        assert np.array_equal(G.rowptr.numpy(), rowptr)
+        assert np.array_equal(G.col.numpy(), col)
+        assert np.array_equal(G.rev.numpy(), rev)
+        # segment plan: every row covered exactly once, in order, by segments of <= seg_len edges
+        deg = np.diff(rowptr)
+        seg_row, seg_beg, row_seg0 = G.seg_row.numpy(), G.seg_beg.numpy(), G.row_seg0.numpy()
+        assert row_seg0[0] == 0 and row_seg0[-1] == G.n_seg
+        for i in range(G.n_nodes):
+            segs = range(row_seg0[i], row_seg0[i + 1])
+            assert len(segs) == max(1, -(-deg[i] // seg_len))
+            assert all(seg_row[s] == i for s in segs)
+            assert [seg_beg[s] for s in segs] == [rowptr[i] + q * seg_len for q in range(len(segs))]
+        assert np.array_equal(G.multi_row.numpy(), np.flatnonzero(deg > seg_len))
+
+
+def test_graph_from_edge_rows_symmetrises_and_collapses_duplicates():
+    from disenlink_amd.graph import Graph
+    src = torch.tensor([0, 0, 2, 2, 3, 0])
+    dst = torch.tensor([1, 1, 0, 2, 1, 1])          # duplicates, a self-loop, one-directional rows
+    G = Graph.from_edge_rows(src, dst, 5)
+    dense = np.zeros((5, 5), np.float32)
+    dense[src.numpy(), dst.numpy()] = 1
+    dense = ((dense + dense.T) != 0).astype(np.float32)
+    rowptr, col, rev = sparse_ref.csr_from_dense(dense)
+    assert np.array_equal(G.rowptr.numpy(), rowptr) and np.array_equal(G.col.numpy(), col)
+    assert np.array_equal(G.rev.numpy(), rev)
+    with pytest.raises(ValueError, match="not symmetric"):
+        Graph.from_edge_rows(src, dst, 5, symmetrise=False)
+    with pytest.raises(ValueError, match="outside"):
+        Graph.from_edge_rows(torch.tensor([0]), torch.tensor([7]), 5)
+    empty = Graph.from_edge_rows(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 4)
+    assert empty.n_edges == 0 and empty.n_seg == 4 and empty.rowptr.tolist() == [0] * 5
+
+
+def test_pair_incidence_lists_every_slot_once():
+    from disenlink_amd.graph import PairList
+    rng = np.random.default_rng(0)
+    n, P = 11, 60
+    pu, pv = rng.integers(0, n, P), rng.integers(0, n, P)
+    pu[:3] = pv[:3]                                   # self pairs
+    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n)
+    ptr, other, pair = pl.inc_ptr.numpy(), pl.inc_other.numpy(), pl.inc_pair.numpy()
+    assert ptr[-1] == 2 * P
+    seen = np.zeros(P, int)
+    for u in range(n):
+        ids = pair[ptr[u]:ptr[u + 1]]
+        oth = other[ptr[u]:ptr[u + 1]]
+        for q, o in zip(ids, oth):
+            assert (pu[q] == u and pv[q] == o) or (pv[q] == u and pu[q] == o)
+            seen[q] += 1
+    assert (seen == 2).all()
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_module_state_dict_and_projection_match_reference(name):
+    """Same state_dict keys/shapes as the reference, and the batched projection equals K separate MLPs."""
+    from disenlink_amd.model import Disentangle
+    g = load_golden(name)
+    m = g["meta"]
+    model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    x = torch.from_numpy(g["x"])
+    Z = model.project(x)
+    Zref = dense_ref.project(x, sd).permute(1, 0, 2)
+    assert Z.shape == (m["N"], m["K"], m["d"]) and Z.is_contiguous()
+    np.testing.assert_allclose(Z.detach().numpy(), Zref.numpy(), rtol=1e-5, atol=1e-6)
+    model.train(); model.eval()                      # must stay no-ops (main_disentangled.py:193,201)
