@@ -55,6 +55,20 @@ class DisenlinkHipError(RuntimeError):
     pass
 
 
+def _hip_runtime_global() -> None:
+    """libdisenlink_hip.so is linked without a HIP runtime (-no-hip-rt) and binds to the one the host
+    process uses.  Under PyTorch that is torch's bundled libamdhip64.so, so that torch's streams and
+    allocations are valid in our launches; promote it to the global symbol scope before loading."""
+    import torch  # noqa: F401  (loads torch's HIP runtime first)
+    cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"),
+            "/opt/rocm/lib/libamdhip64.so"]
+    for path in cand:
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return
+    raise DisenlinkHipError("no libamdhip64.so found (looked in torch/lib and /opt/rocm/lib)")
+
+
 def load() -> C.CDLL:
     """Load the library once.  Raises if it was not built (python -m disenlink_amd.build)."""
     global _lib
@@ -64,6 +78,7 @@ def load() -> C.CDLL:
         raise DisenlinkHipError(
             f"{LIB_PATH} not found: the HIP library is required (there is no CPU fallback). "
             "Build it with `python -m disenlink_amd.build` or __graft_entry__.build().")
+    _hip_runtime_global()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol

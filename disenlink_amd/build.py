@@ -54,7 +54,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(lambda so: _compile(so[0], so[1], verbose), jobs))
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        # -no-hip-rt: leave the HIP runtime symbols undefined so the library binds to the runtime the
+        # host process already uses (torch bundles its own libamdhip64; two runtimes in one process
+        # would not share streams).  disenlink_amd/_lib.py puts that runtime in the global scope.
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", LIB, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

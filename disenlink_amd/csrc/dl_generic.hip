@@ -194,10 +194,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_da_kernel(
         float sr = s[(size_t)row * K + lane];
         ds = sr == 0.0f ? 0.0f : -acc / (sr * sr);
     }
-    for (int e = beg + lane; e < end; e += DL_WAVE) {
-        const int k = p[e];
-        const float sj = one_if_zero(s[(size_t)col[e] * K + k]);
-        da[e] = dw[e] / sj + __shfl(ds, k, DL_WAVE);
+    for (int base = beg; base < end; base += DL_WAVE) {     // uniform trip count: the shuffle needs all lanes
+        const int e = base + lane;
+        const bool live = e < end;
+        const int k = live ? p[e] : 0;
+        const float dsk = __shfl(ds, k, DL_WAVE);
+        if (live) da[e] = dw[e] / one_if_zero(s[(size_t)col[e] * K + k]) + dsk;
     }
 }
 
