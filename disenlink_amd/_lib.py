@@ -16,8 +16,8 @@ class DlGraph(C.Structure):
         ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("rev", C.c_void_p),
         ("seg_len", C.c_int32), ("n_seg", C.c_int32),
-        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("row_seg0", C.c_void_p),
-        ("n_multi", C.c_int32), ("multi_row", C.c_void_p),
+        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("seg_slot", C.c_void_p), ("row_seg0", C.c_void_p),
+        ("n_multi", C.c_int32), ("n_slots", C.c_int32), ("multi_row", C.c_void_p), ("multi_slot0", C.c_void_p),
     ]
 
 

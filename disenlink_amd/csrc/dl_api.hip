@@ -41,6 +41,40 @@ static int check_graph(const dl_graph* g) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Workspace layout (all 256-byte aligned): dw[E] | da[E] | s_part[n_slots*K] | h_part[n_slots*K*d]
+struct Workspace {
+    float *dw, *da, *s_part, *h_part;
+    size_t bytes;
+};
+
+static Workspace carve(const dl_graph* g, int K, int d, void* ws) {
+    Workspace w;
+    const size_t e = align256((size_t)g->n_edges * sizeof(float));
+    const size_t sp = align256((size_t)g->n_slots * K * sizeof(float));
+    const size_t hp = align256((size_t)g->n_slots * K * d * sizeof(float));
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    w.dw = (float*)base;
+    w.da = (float*)(base + e);
+    w.s_part = (float*)(base + 2 * e);
+    w.h_part = (float*)(base + 2 * e + sp);
+    w.bytes = 2 * e + sp + hp + 256;
+    return w;
+}
+
+static int check_workspace(const dl_graph* g, int K, int d, void* ws, size_t ws_bytes, Workspace* out) {
+    *out = carve(g, K, d, ws);
+    if (!ws || ws_bytes < out->bytes) {
+        set_error("workspace too small: have %zu, need %zu (dl_workspace_bytes)", ws ? ws_bytes : (size_t)0, out->bytes);
+        return DL_E_WORKSPACE;
+    }
+    return DL_OK;
+}
+
+static bool use_fast(const dl_graph* g, int K, int d) {
+    return !g_force_generic && fast_supported(K, d) && g->seg_len > 0 && g->n_seg > 0 && g->seg_row && g->seg_beg &&
+           g->seg_slot && (g->n_multi == 0 || (g->multi_row && g->multi_slot0));
+}
+
 }  // namespace dl
 
 using namespace dl;
@@ -50,10 +84,7 @@ extern "C" {
 const char* dl_version(void) { return "disenlink_hip 0.1 (gfx950)"; }
 const char* dl_last_error(void) { return g_err; }
 
-int dl_has_fast_path(int K, int d) {
-    (void)K; (void)d;
-    return 0;
-}
+int dl_has_fast_path(int K, int d) { return fast_supported(K, d) ? 1 : 0; }
 
 int dl_set_force_generic(int on) {
     int old = g_force_generic;
@@ -62,32 +93,38 @@ int dl_set_force_generic(int on) {
 }
 
 size_t dl_workspace_bytes(const dl_graph* g, int K, int d) {
-    if (!g) return 0;
-    (void)K; (void)d;
-    // backward: dw[E], da[E]
-    return 2 * align256((size_t)g->n_edges * sizeof(float)) + 256;
+    if (!g || K < 1 || d < 1) return 0;
+    return carve(g, K, d, nullptr).bytes;
 }
 
 int dl_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
                  void* ws, size_t ws_bytes, void* stream) {
-    (void)ws; (void)ws_bytes;
     if (int rc = check_graph(g)) return rc;
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (g->n_nodes == 0) return DL_OK;
     DL_REQUIRE(Z && s, "Z or s is NULL");
     if (g->n_edges > 0) DL_REQUIRE(p && a, "p or a is NULL");
+    if (use_fast(g, K, d)) {
+        Workspace w;
+        if (int rc = check_workspace(g, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_route_fwd(g, Z, K, d, t, p, a, s, w.s_part, (hipStream_t)stream);
+    }
     return generic_route_fwd(g, Z, K, d, t, p, a, s, (hipStream_t)stream);
 }
 
 int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
                      const float* a, const float* s, float* H, void* ws, size_t ws_bytes, void* stream) {
-    (void)ws; (void)ws_bytes;
     if (int rc = check_graph(g)) return rc;
     if (int rc = check_shape(K, d)) return rc;
     if (g->n_nodes == 0) return DL_OK;
     DL_REQUIRE(Z && s && H, "Z, s or H is NULL");
     if (g->n_edges > 0) DL_REQUIRE(p && a, "p or a is NULL");
+    if (use_fast(g, K, d)) {
+        Workspace w;
+        if (int rc = check_workspace(g, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_aggregate_fwd(g, Z, K, d, beta, p, a, s, H, w.h_part, (hipStream_t)stream);
+    }
     return generic_aggregate_fwd(g, Z, K, d, beta, p, a, s, H, (hipStream_t)stream);
 }
 
@@ -123,15 +160,9 @@ int dl_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, floa
     if (g->n_nodes == 0) return DL_OK;
     DL_REQUIRE(Z && s && dH && dZ, "NULL argument");
     if (g->n_edges > 0) DL_REQUIRE(p && a, "p or a is NULL");
-    size_t need = dl_workspace_bytes(g, K, d);
-    if (!ws || ws_bytes < need) {
-        set_error("workspace too small: have %zu, need %zu", ws_bytes, need);
-        return DL_E_WORKSPACE;
-    }
-    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    float* dw = (float*)base;
-    float* da = (float*)(base + align256((size_t)g->n_edges * sizeof(float)));
-    return generic_route_aggregate_bwd(g, Z, K, d, beta, t, p, a, s, dH, dZ, accumulate, dw, da,
+    Workspace w;
+    if (int rc = check_workspace(g, K, d, ws, ws_bytes, &w)) return rc;
+    return generic_route_aggregate_bwd(g, Z, K, d, beta, t, p, a, s, dH, dZ, accumulate, w.dw, w.da,
                                        (hipStream_t)stream);
 }
 

@@ -19,4 +19,11 @@ int generic_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d,
                                 const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
                                 int accumulate, float* dw, float* da, hipStream_t st);
 
+// tuned, per-(K,D) instantiations (dl_fast.hip)
+bool fast_supported(int K, int d);
+int fast_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
+                   float* s_part, hipStream_t st);
+int fast_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+                       const float* a, const float* s, float* H, float* h_part, hipStream_t st);
+
 }  // namespace dl

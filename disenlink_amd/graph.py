@@ -33,8 +33,10 @@ class Graph:
     seg_len: int
     seg_row: torch.Tensor
     seg_beg: torch.Tensor
+    seg_slot: torch.Tensor
     row_seg0: torch.Tensor
     multi_row: torch.Tensor
+    multi_slot0: torch.Tensor
     _struct: _lib.DlGraph | None = field(default=None, repr=False)
 
     @property
@@ -44,6 +46,10 @@ class Graph:
     @property
     def n_seg(self) -> int:
         return int(self.seg_row.numel())
+
+    @property
+    def n_slots(self) -> int:
+        return int(self.multi_slot0[-1]) if self.multi_slot0.numel() else 0
 
     @property
     def device(self) -> torch.device:
@@ -105,13 +111,20 @@ class Graph:
         seg_idx = torch.arange(seg_row.numel(), device=dev) - row_seg0[seg_row]
         seg_beg = rowptr[seg_row] + seg_idx * seg_len
         multi_row = torch.nonzero(nseg_row > 1).reshape(-1)
+        # partial-sum slots: only segments of multi-segment rows get one, numbered consecutively per row
+        multi_slot0 = torch.zeros(multi_row.numel() + 1, dtype=torch.int64, device=dev)
+        multi_slot0[1:] = torch.cumsum(nseg_row[multi_row], dim=0)
+        row_slot0 = torch.full((n_nodes,), -1, dtype=torch.int64, device=dev)
+        row_slot0[multi_row] = multi_slot0[:-1]
+        seg_slot = torch.where(row_slot0[seg_row] >= 0, row_slot0[seg_row] + seg_idx, row_slot0[seg_row])
         return Graph(n_nodes, _i32(rowptr), _i32(col), _i32(rev), seg_len, _i32(seg_row), _i32(seg_beg),
-                     _i32(row_seg0), _i32(multi_row))
+                     _i32(seg_slot), _i32(row_seg0), _i32(multi_row), _i32(multi_slot0))
 
     def to(self, device) -> "Graph":
-        return Graph(self.n_nodes, self.rowptr.to(device), self.col.to(device), self.rev.to(device), self.seg_len,
-                     self.seg_row.to(device), self.seg_beg.to(device), self.row_seg0.to(device),
-                     self.multi_row.to(device))
+        mv = lambda t: t.to(device)
+        return Graph(self.n_nodes, mv(self.rowptr), mv(self.col), mv(self.rev), self.seg_len, mv(self.seg_row),
+                     mv(self.seg_beg), mv(self.seg_slot), mv(self.row_seg0), mv(self.multi_row),
+                     mv(self.multi_slot0))
 
     # ------------------------------------------------------------------ C view
     def c_struct(self) -> "C.POINTER(_lib.DlGraph)":
@@ -119,7 +132,8 @@ class Graph:
             self._struct = _lib.DlGraph(
                 self.n_nodes, self.n_edges, self.rowptr.data_ptr(), self.col.data_ptr(), self.rev.data_ptr(),
                 self.seg_len, self.n_seg, self.seg_row.data_ptr(), self.seg_beg.data_ptr(),
-                self.row_seg0.data_ptr(), int(self.multi_row.numel()), self.multi_row.data_ptr())
+                self.seg_slot.data_ptr(), self.row_seg0.data_ptr(), int(self.multi_row.numel()), self.n_slots,
+                self.multi_row.data_ptr(), self.multi_slot0.data_ptr())
         return C.byref(self._struct)
 
 

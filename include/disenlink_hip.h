@@ -50,9 +50,12 @@ typedef struct dl_graph {
     int32_t n_seg;
     const int32_t* seg_row;     /* [n_seg] */
     const int32_t* seg_beg;     /* [n_seg] first edge of the segment */
+    const int32_t* seg_slot;    /* [n_seg] partial-sum slot of the segment, -1 if its row has one segment */
     const int32_t* row_seg0;    /* [n_nodes+1] first segment of each row */
     int32_t n_multi;
+    int32_t n_slots;            /* segments that belong to multi-segment rows */
     const int32_t* multi_row;   /* [n_multi] rows with more than one segment */
+    const int32_t* multi_slot0; /* [n_multi+1] first slot of each such row (slots are consecutive) */
 } dl_graph;
 
 /* Node-incidence list of a scored pair list: for node u, entries inc_ptr[u]..inc_ptr[u+1]-1 name
