@@ -48,6 +48,8 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0):
                                  torch.from_numpy(split.train_dst).to(device), sg.n_nodes)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    order = np.lexsort((pv, pu))                      # pair list laid out by u: long runs share the u rows
+    pu, pv = pu[order], pv[order]
     pairs = PairList.build(torch.from_numpy(pu).to(device), torch.from_numpy(pv).to(device), sg.n_nodes)
     torch.manual_seed(seed)
     model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.5, t=1).to(device)
@@ -133,7 +135,7 @@ def main():
     def step():
         p, a, s = ops.route_fwd(graph, Z, t)
         H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
         return p, a, s, H, prob
 
     for _ in range(args.warmup):
@@ -155,7 +157,7 @@ def main():
         ev[i][1].record()
         H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
         ev[i][2].record()
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
         ev[i][3].record()
     torch.cuda.synchronize()
     ktime = {n: float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(args.steps)])) * 1e-3
@@ -167,6 +169,22 @@ def main():
     dom = max(names, key=lambda n: ktime[n])
     scatter_t = ktime["route"] + ktime["aggregate"]
     scatter_b = abytes["route"] + abytes["aggregate"]
+
+    # extra: forward+backward of the same path (what one training epoch adds on top), not the headline
+    gp = torch.full((P,), 1.0 / P, device=device)
+    def train_step():
+        p, a, s, H, prob = step()
+        dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp)
+        return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
+    for _ in range(3):
+        train_step()
+    torch.cuda.synchronize()
+    nb = max(5, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(nb):
+        train_step()
+    torch.cuda.synchronize()
+    fb_ms = (time.perf_counter() - t0) / nb * 1e3
 
     units = E + P
     result = {
@@ -188,6 +206,7 @@ def main():
                          "achieved_GBs": scatter_b / scatter_t / 1e9, "frac": scatter_b / scatter_t / 1e9 / HBM_PEAK_GBS,
                          "edges_per_s": E / scatter_t},
         "kernels": kernels,
+        "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},
     }
     if not args.no_cpu_baseline:
         gcpu = graph.to("cpu")

@@ -11,41 +11,41 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdisenlink_hip.so")
 
 
-class DlGraph(C.Structure):
+class DlCsrPlan(C.Structure):
     _fields_ = [
-        ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
-        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("rev", C.c_void_p),
+        ("n_rows", C.c_int32), ("row_offset", C.c_int32), ("n_total", C.c_int32), ("n_entries", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p),
         ("seg_len", C.c_int32), ("n_seg", C.c_int32),
-        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("seg_slot", C.c_void_p), ("row_seg0", C.c_void_p),
+        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("seg_slot", C.c_void_p),
         ("n_multi", C.c_int32), ("n_slots", C.c_int32), ("multi_row", C.c_void_p), ("multi_slot0", C.c_void_p),
     ]
 
 
+class DlGraph(C.Structure):
+    _fields_ = [("csr", DlCsrPlan)]
+
+
 class DlPairIncidence(C.Structure):
-    _fields_ = [
-        ("n_nodes", C.c_int32), ("n_pairs", C.c_int32),
-        ("inc_ptr", C.c_void_p), ("inc_other", C.c_void_p), ("inc_pair", C.c_void_p),
-    ]
+    _fields_ = [("csr", DlCsrPlan), ("inc_pair", C.c_void_p), ("n_pairs", C.c_int32)]
 
 
 _P = C.c_void_p          # device pointers travel as integers
+_G, _I = C.POINTER(DlGraph), C.POINTER(DlPairIncidence)
+_i, _f, _z = C.c_int, C.c_float, C.c_size_t
 EXPORTS = {
     # name: (restype, argtypes) -- one entry per symbol declared in include/disenlink_hip.h
     "dl_version": (C.c_char_p, []),
     "dl_last_error": (C.c_char_p, []),
-    "dl_has_fast_path": (C.c_int, [C.c_int, C.c_int]),
-    "dl_set_force_generic": (C.c_int, [C.c_int]),
-    "dl_workspace_bytes": (C.c_size_t, [C.POINTER(DlGraph), C.c_int, C.c_int]),
-    "dl_route_fwd": (C.c_int, [C.POINTER(DlGraph), _P, C.c_int, C.c_int, C.c_float,
-                               _P, _P, _P, _P, C.c_size_t, _P]),
-    "dl_aggregate_fwd": (C.c_int, [C.POINTER(DlGraph), _P, C.c_int, C.c_int, C.c_float,
-                                   _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "dl_score_pairs_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
-                                     _P, _P, C.c_int, _P, _P]),
-    "dl_score_pairs_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
-                                     C.POINTER(DlPairIncidence), _P, _P, _P, _P, _P]),
-    "dl_route_aggregate_bwd": (C.c_int, [C.POINTER(DlGraph), _P, C.c_int, C.c_int, C.c_float, C.c_float,
-                                         _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "dl_has_fast_path": (_i, [_i, _i]),
+    "dl_set_force_generic": (_i, [_i]),
+    "dl_workspace_bytes": (_z, [C.POINTER(DlCsrPlan), _i, _i]),
+    "dl_route_fwd": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
+    "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _i, _P, _i, _P, _P]),
+    "dl_score_pairs_bwd": (_i, [_P, _P, _i, _i, _f, _I, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_route_aggregate_bwd_phase2": (_i, [_G, _P, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
+    "dl_route_aggregate_bwd": (_i, [_G, _P, _i, _i, _f, _f, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
 }
 
 _lib = None

@@ -31,38 +31,43 @@ static int check_shape(int K, int d) {
     return DL_OK;
 }
 
-static int check_graph(const dl_graph* g) {
-    DL_REQUIRE(g != nullptr, "graph is NULL");
-    DL_REQUIRE(g->n_nodes >= 0 && g->n_edges >= 0, "negative graph size");
-    if (g->n_nodes > 0) DL_REQUIRE(g->rowptr != nullptr, "graph.rowptr is NULL");
-    if (g->n_edges > 0) DL_REQUIRE(g->col != nullptr && g->rev != nullptr, "graph.col/rev is NULL");
+static int check_plan(const dl_csr_plan* c, const char* what) {
+    DL_REQUIRE(c != nullptr, "%s is NULL", what);
+    DL_REQUIRE(c->n_rows >= 0 && c->n_entries >= 0 && c->row_offset >= 0, "%s: negative size", what);
+    DL_REQUIRE((long long)c->row_offset + c->n_rows <= c->n_total, "%s: rows [%d, %d) exceed n_total=%d", what,
+               c->row_offset, c->row_offset + c->n_rows, c->n_total);
+    if (c->n_rows > 0) DL_REQUIRE(c->rowptr != nullptr, "%s.rowptr is NULL", what);
+    if (c->n_entries > 0) DL_REQUIRE(c->col != nullptr, "%s.col is NULL", what);
     return DL_OK;
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Workspace layout (all 256-byte aligned): dw[E] | da[E] | s_part[n_slots*K] | h_part[n_slots*K*d]
+// Workspace layout (256-byte aligned blocks):
+//   dw[E] | dwr[E] | ds[n_total*K] | vec_part[n_slots*K] | row_part[n_slots*2*K*d]
 struct Workspace {
-    float *dw, *da, *s_part, *h_part;
+    float *dw, *dwr, *ds, *vec_part, *row_part;
     size_t bytes;
 };
 
-static Workspace carve(const dl_graph* g, int K, int d, void* ws) {
+static Workspace carve(const dl_csr_plan* c, int K, int d, void* ws) {
     Workspace w;
-    const size_t e = align256((size_t)g->n_edges * sizeof(float));
-    const size_t sp = align256((size_t)g->n_slots * K * sizeof(float));
-    const size_t hp = align256((size_t)g->n_slots * K * d * sizeof(float));
+    const size_t e = align256((size_t)c->n_entries * sizeof(float));
+    const size_t nk = align256((size_t)c->n_total * K * sizeof(float));
+    const size_t vp = align256((size_t)c->n_slots * K * sizeof(float));
+    const size_t rp = align256((size_t)c->n_slots * 2 * K * d * sizeof(float));
     char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     w.dw = (float*)base;
-    w.da = (float*)(base + e);
-    w.s_part = (float*)(base + 2 * e);
-    w.h_part = (float*)(base + 2 * e + sp);
-    w.bytes = 2 * e + sp + hp + 256;
+    w.dwr = (float*)(base + e);
+    w.ds = (float*)(base + 2 * e);
+    w.vec_part = (float*)(base + 2 * e + nk);
+    w.row_part = (float*)(base + 2 * e + nk + vp);
+    w.bytes = 2 * e + nk + vp + rp + 256;
     return w;
 }
 
-static int check_workspace(const dl_graph* g, int K, int d, void* ws, size_t ws_bytes, Workspace* out) {
-    *out = carve(g, K, d, ws);
+static int check_workspace(const dl_csr_plan* c, int K, int d, void* ws, size_t ws_bytes, Workspace* out) {
+    *out = carve(c, K, d, ws);
     if (!ws || ws_bytes < out->bytes) {
         set_error("workspace too small: have %zu, need %zu (dl_workspace_bytes)", ws ? ws_bytes : (size_t)0, out->bytes);
         return DL_E_WORKSPACE;
@@ -70,9 +75,13 @@ static int check_workspace(const dl_graph* g, int K, int d, void* ws, size_t ws_
     return DL_OK;
 }
 
-static bool use_fast(const dl_graph* g, int K, int d) {
-    return !g_force_generic && fast_supported(K, d) && g->seg_len > 0 && g->n_seg > 0 && g->seg_row && g->seg_beg &&
-           g->seg_slot && (g->n_multi == 0 || (g->multi_row && g->multi_slot0));
+static bool has_seg_plan(const dl_csr_plan* c) {
+    return c->seg_len > 0 && c->n_seg > 0 && c->seg_row && c->seg_beg && c->seg_slot &&
+           (c->n_multi == 0 || (c->multi_row && c->multi_slot0));
+}
+
+static bool use_fast(const dl_csr_plan* c, int K, int d) {
+    return !g_force_generic && fast_supported(K, d) && has_seg_plan(c);
 }
 
 }  // namespace dl
@@ -81,9 +90,8 @@ using namespace dl;
 
 extern "C" {
 
-const char* dl_version(void) { return "disenlink_hip 0.1 (gfx950)"; }
+const char* dl_version(void) { return "disenlink_hip 0.2 (gfx950)"; }
 const char* dl_last_error(void) { return g_err; }
-
 int dl_has_fast_path(int K, int d) { return fast_supported(K, d) ? 1 : 0; }
 
 int dl_set_force_generic(int on) {
@@ -92,78 +100,132 @@ int dl_set_force_generic(int on) {
     return old;
 }
 
-size_t dl_workspace_bytes(const dl_graph* g, int K, int d) {
-    if (!g || K < 1 || d < 1) return 0;
-    return carve(g, K, d, nullptr).bytes;
+size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d) {
+    if (!plan || K < 1 || d < 1) return 0;
+    return carve(plan, K, d, nullptr).bytes;
 }
 
 int dl_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
                  void* ws, size_t ws_bytes, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    DL_REQUIRE(g != nullptr, "graph is NULL");
+    const dl_csr_plan* c = &g->csr;
+    if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(t != 0.0f, "temperature is 0");
-    if (g->n_nodes == 0) return DL_OK;
+    if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && s, "Z or s is NULL");
-    if (g->n_edges > 0) DL_REQUIRE(p && a, "p or a is NULL");
-    if (use_fast(g, K, d)) {
+    if (c->n_entries > 0) DL_REQUIRE(p && a, "p or a is NULL");
+    if (use_fast(c, K, d)) {
         Workspace w;
-        if (int rc = check_workspace(g, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_route_fwd(g, Z, K, d, t, p, a, s, w.s_part, (hipStream_t)stream);
+        if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_route_fwd(c, Z, K, d, t, p, a, s, w.vec_part, (hipStream_t)stream);
     }
-    return generic_route_fwd(g, Z, K, d, t, p, a, s, (hipStream_t)stream);
+    return generic_route_fwd(c, Z, K, d, t, p, a, s, (hipStream_t)stream);
 }
 
 int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
                      const float* a, const float* s, float* H, void* ws, size_t ws_bytes, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    DL_REQUIRE(g != nullptr, "graph is NULL");
+    const dl_csr_plan* c = &g->csr;
+    if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
-    if (g->n_nodes == 0) return DL_OK;
+    if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && s && H, "Z, s or H is NULL");
-    if (g->n_edges > 0) DL_REQUIRE(p && a, "p or a is NULL");
-    if (use_fast(g, K, d)) {
+    if (c->n_entries > 0) DL_REQUIRE(p && a, "p or a is NULL");
+    if (use_fast(c, K, d)) {
         Workspace w;
-        if (int rc = check_workspace(g, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_aggregate_fwd(g, Z, K, d, beta, p, a, s, H, w.h_part, (hipStream_t)stream);
+        if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_aggregate_fwd(c, Z, K, d, beta, p, a, s, H, w.row_part, (hipStream_t)stream);
     }
-    return generic_aggregate_fwd(g, Z, K, d, beta, p, a, s, H, (hipStream_t)stream);
+    return generic_aggregate_fwd(c, Z, K, d, beta, p, a, s, H, (hipStream_t)stream);
 }
 
 int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, const int32_t* pu,
-                       const int32_t* pv, int n_pairs, float* prob, void* stream) {
+                       const int32_t* pv, int n_pairs, const int32_t* run_ptr, int n_runs, float* prob,
+                       void* stream) {
     if (int rc = check_shape(K, d)) return rc;
-    DL_REQUIRE(N >= 0 && n_pairs >= 0, "negative size");
+    DL_REQUIRE(N >= 0 && n_pairs >= 0 && n_runs >= 0, "negative size");
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (n_pairs == 0) return DL_OK;
     DL_REQUIRE(Z && H && pu && pv && prob, "NULL argument");
+    if (!g_force_generic && fast_supported(K, d) && run_ptr && n_runs > 0)
+        return fast_score_pairs_fwd(Z, H, K, d, t, pu, pv, run_ptr, n_runs, prob, (hipStream_t)stream);
     return generic_score_pairs_fwd(Z, H, K, d, t, pu, pv, n_pairs, prob, (hipStream_t)stream);
 }
 
-int dl_score_pairs_bwd(const float* Z, const float* H, int N, int K, int d, float t,
-                       const dl_pair_incidence* inc, const float* prob, const float* g_prob, float* dZ,
-                       float* dH, void* stream) {
+int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t, const dl_pair_incidence* inc,
+                       const float* prob, const float* g_prob, float* dZ, float* dH, void* ws, size_t ws_bytes,
+                       void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(inc != nullptr, "incidence is NULL");
-    DL_REQUIRE(N >= 0 && inc->n_nodes == N, "incidence.n_nodes=%d != N=%d", inc->n_nodes, N);
+    const dl_csr_plan* c = &inc->csr;
+    if (int rc = check_plan(c, "incidence")) return rc;
     DL_REQUIRE(t != 0.0f, "temperature is 0");
-    if (N == 0) return DL_OK;
-    DL_REQUIRE(Z && H && dZ && dH && inc->inc_ptr, "NULL argument");
-    if (inc->n_pairs > 0) DL_REQUIRE(inc->inc_other && inc->inc_pair && prob && g_prob, "NULL pair argument");
-    return generic_score_pairs_bwd(Z, H, N, K, d, t, inc, prob, g_prob, dZ, dH, (hipStream_t)stream);
+    if (c->n_rows == 0) return DL_OK;
+    DL_REQUIRE(Z && H && dZ && dH, "NULL argument");
+    if (c->n_entries > 0) DL_REQUIRE(inc->inc_pair && prob && g_prob, "NULL pair argument");
+    if (use_fast(c, K, d)) {
+        Workspace w;
+        if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_score_pairs_bwd(inc, Z, H, K, d, t, prob, g_prob, dZ, dH, w.row_part, (hipStream_t)stream);
+    }
+    return generic_score_pairs_bwd(inc, Z, H, K, d, t, prob, g_prob, dZ, dH, (hipStream_t)stream);
+}
+
+int dl_route_aggregate_bwd_phase1(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+                                  const float* a, const float* s, const float* dH, float* dw, float* dwr,
+                                  float* ds, void* ws, size_t ws_bytes, void* stream) {
+    DL_REQUIRE(g != nullptr, "graph is NULL");
+    const dl_csr_plan* c = &g->csr;
+    if (int rc = check_plan(c, "graph")) return rc;
+    if (int rc = check_shape(K, d)) return rc;
+    if (c->n_rows == 0) return DL_OK;
+    DL_REQUIRE(Z && s && dH && ds, "NULL argument");
+    if (c->n_entries > 0) DL_REQUIRE(p && a && dw && dwr, "NULL per-edge argument");
+    if (use_fast(c, K, d)) {
+        Workspace w;
+        if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_bwd_phase1(c, Z, K, d, beta, p, a, s, dH, dw, dwr, ds, w.vec_part, (hipStream_t)stream);
+    }
+    return generic_bwd_phase1(c, Z, K, d, beta, p, a, s, dH, dw, dwr, ds, (hipStream_t)stream);
+}
+
+int dl_route_aggregate_bwd_phase2(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
+                                  const uint8_t* p, const float* a, const float* s, const float* dH,
+                                  const float* dw, const float* dwr, const float* ds, float* dZ, int accumulate,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    DL_REQUIRE(g != nullptr, "graph is NULL");
+    const dl_csr_plan* c = &g->csr;
+    if (int rc = check_plan(c, "graph")) return rc;
+    if (int rc = check_shape(K, d)) return rc;
+    DL_REQUIRE(t != 0.0f, "temperature is 0");
+    if (c->n_rows == 0) return DL_OK;
+    DL_REQUIRE(Z && s && dH && ds && dZ, "NULL argument");
+    if (c->n_entries > 0) DL_REQUIRE(p && a && dw && dwr, "NULL per-edge argument");
+    if (use_fast(c, K, d)) {
+        Workspace w;
+        if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+        return fast_bwd_phase2(c, Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, w.row_part,
+                               (hipStream_t)stream);
+    }
+    return generic_bwd_phase2(c, Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, (hipStream_t)stream);
 }
 
 int dl_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
                            const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
                            int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    DL_REQUIRE(g != nullptr, "graph is NULL");
+    const dl_csr_plan* c = &g->csr;
+    if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
-    DL_REQUIRE(t != 0.0f, "temperature is 0");
-    if (g->n_nodes == 0) return DL_OK;
-    DL_REQUIRE(Z && s && dH && dZ, "NULL argument");
-    if (g->n_edges > 0) DL_REQUIRE(p && a, "p or a is NULL");
+    DL_REQUIRE(c->row_offset == 0 && c->n_rows == c->n_total,
+               "dl_route_aggregate_bwd needs an unsharded plan; call the two phases with an all-gather of ds between");
     Workspace w;
-    if (int rc = check_workspace(g, K, d, ws, ws_bytes, &w)) return rc;
-    return generic_route_aggregate_bwd(g, Z, K, d, beta, t, p, a, s, dH, dZ, accumulate, w.dw, w.da,
-                                       (hipStream_t)stream);
+    if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+    if (int rc = dl_route_aggregate_bwd_phase1(g, Z, K, d, beta, p, a, s, dH, w.dw, w.dwr, w.ds, ws, ws_bytes, stream))
+        return rc;
+    return dl_route_aggregate_bwd_phase2(g, Z, K, d, beta, t, p, a, s, dH, w.dw, w.dwr, w.ds, dZ, accumulate, ws,
+                                         ws_bytes, stream);
 }
 
 }  // extern "C"

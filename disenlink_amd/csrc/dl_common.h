@@ -21,6 +21,10 @@ int check_launch(const char* what);
         }                                     \
     } while (0)
 
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = WAVES_PER_BLOCK * DL_WAVE;
+static inline unsigned wave_blocks(int n) { return (unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+
 // ---- device helpers ---------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (DL_WAVE - 1); }
 
@@ -39,6 +43,14 @@ __device__ __forceinline__ float group_allreduce_sum(float v) {
     return v;
 }
 
+// Sum over the 64/G groups of a wave: lanes with equal (lane % G) are added together.
+template <int G>
+__device__ __forceinline__ float across_groups_sum(float v) {
+#pragma unroll
+    for (int off = G; off < DL_WAVE; off <<= 1) v += __shfl_xor(v, off, DL_WAVE);
+    return v;
+}
+
 // torch.argmax order on floats: NaN beats everything, otherwise strictly greater wins, so the
 // first maximal element is kept when scanning k upward.
 __device__ __forceinline__ bool beats(float v, float best) {
@@ -49,5 +61,24 @@ __device__ __forceinline__ float one_if_zero(float s) { return s == 0.0f ? 1.0f 
 
 // sigmoid as ATen's CPU kernel writes it: 1 / (1 + exp(-x)).
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// d s_raw -> ds of the normaliser: -(acc) / s~^2, zero where the raw sum was zero (model.py:72).
+__device__ __forceinline__ float ds_from_acc(float acc, float s_raw) {
+    return s_raw == 0.0f ? 0.0f : -acc / (s_raw * s_raw);
+}
+
+struct SegInfo {
+    int row, grow, beg, end, slot;
+};
+
+__device__ __forceinline__ SegInfo load_seg(const dl_csr_plan& c, int seg) {
+    SegInfo s;
+    s.row = c.seg_row[seg];
+    s.grow = s.row + c.row_offset;
+    s.beg = c.seg_beg[seg];
+    s.end = min(s.beg + c.seg_len, c.rowptr[s.row + 1]);
+    s.slot = c.seg_slot[seg];
+    return s;
+}
 
 }  // namespace dl

@@ -8,9 +8,6 @@
 namespace dl {
 namespace generic {
 
-constexpr int WAVES_PER_BLOCK = 4;
-constexpr int BLOCK = WAVES_PER_BLOCK * DL_WAVE;
-
 // sigma_k = z_k[i].z_k[j] over d, lanes stride the d index; result identical in all lanes.
 __device__ __forceinline__ float wave_dot(const float* __restrict__ x, const float* __restrict__ y, int d) {
     float part = 0.0f;
@@ -21,10 +18,9 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ x, const flo
 // Computes e_k (lane k keeps it), S = sum_k e_k (sequential in k, like the reference's sum over
 // dim 0) and returns alpha_k in lane k.  Lanes >= K return 0.
 __device__ __forceinline__ float edge_softmax(const float* __restrict__ zi, const float* __restrict__ zj,
-                                              int K, int d, float t, float& mine_e) {
+                                              int K, int d, float t) {
     const int lane = lane_id();
-    float S = 0.0f;
-    mine_e = 0.0f;
+    float S = 0.0f, mine_e = 0.0f;
     for (int k = 0; k < K; ++k) {
         float ek = expf(wave_dot(zi + k * d, zj + k * d, d) / t);
         S += ek;
@@ -49,51 +45,49 @@ __device__ __forceinline__ int wave_argmax_first(float v, int K) {
     return idx;
 }
 
-__global__ __launch_bounds__(BLOCK) void route_fwd_kernel(
-    const float* __restrict__ Z, int N, int K, int d, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ col, float t, uint8_t* __restrict__ p, float* __restrict__ a,
-    float* __restrict__ s) {
+__global__ __launch_bounds__(BLOCK) void route_fwd_kernel(dl_csr_plan c, const float* __restrict__ Z, int K, int d,
+                                                          float t, uint8_t* __restrict__ p, float* __restrict__ a,
+                                                          float* __restrict__ s) {
     const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= N) return;
+    if (row >= c.n_rows) return;
     const int lane = lane_id();
     const size_t stride = (size_t)K * d;
-    const float* zi = Z + (size_t)row * stride;
+    const size_t grow = (size_t)row + c.row_offset;
+    const float* zi = Z + grow * stride;
     float s_acc = 0.0f;                          // lane k accumulates s_k
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int e = beg; e < end; ++e) {
-        const float* zj = Z + (size_t)col[e] * stride;
-        float mine_e;
-        float alpha = edge_softmax(zi, zj, K, d, t, mine_e);
+    for (int e = c.rowptr[row]; e < c.rowptr[row + 1]; ++e) {
+        const float* zj = Z + (size_t)c.col[e] * stride;
+        float alpha = edge_softmax(zi, zj, K, d, t);
         int win = wave_argmax_first(alpha, K);
         float aw = __shfl(alpha, win, DL_WAVE);
         if (lane == win) s_acc += aw;
         if (lane == 0) { p[e] = (uint8_t)win; a[e] = aw; }
     }
-    if (lane < K) s[(size_t)row * K + lane] = s_acc;
+    if (lane < K) s[grow * K + lane] = s_acc;
 }
 
-__global__ __launch_bounds__(BLOCK) void aggregate_fwd_kernel(
-    const float* __restrict__ Z, int N, int K, int d, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ col, float beta, const uint8_t* __restrict__ p,
-    const float* __restrict__ a, const float* __restrict__ s, float* __restrict__ H) {
+__global__ __launch_bounds__(BLOCK) void aggregate_fwd_kernel(dl_csr_plan c, const float* __restrict__ Z, int K,
+                                                              int d, float beta, const uint8_t* __restrict__ p,
+                                                              const float* __restrict__ a,
+                                                              const float* __restrict__ s, float* __restrict__ H) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6;
     const int row = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (row >= N) return;
+    if (row >= c.n_rows) return;
     const int lane = lane_id();
     const int KD = K * d;
+    const size_t grow = (size_t)row + c.row_offset;
     float* acc = lds + (size_t)wave * KD;
     for (int x = lane; x < KD; x += DL_WAVE) acc[x] = 0.0f;
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int e = beg; e < end; ++e) {
-        const int j = col[e];
+    for (int e = c.rowptr[row]; e < c.rowptr[row + 1]; ++e) {
+        const int j = c.col[e];
         const int k = p[e];
         const float w = a[e] / one_if_zero(s[(size_t)j * K + k]);
         const float* zj = Z + (size_t)j * KD + k * d;
-        for (int c = lane; c < d; c += DL_WAVE) acc[k * d + c] = fmaf(w, zj[c], acc[k * d + c]);
+        for (int x = lane; x < d; x += DL_WAVE) acc[k * d + x] = fmaf(w, zj[x], acc[k * d + x]);
     }
-    const float* zi = Z + (size_t)row * KD;
-    float* hi = H + (size_t)row * KD;
+    const float* zi = Z + grow * KD;
+    float* hi = H + grow * KD;
     const float omb = 1.0f - beta;
     for (int x = lane; x < KD; x += DL_WAVE) hi[x] = beta * zi[x] + omb * acc[x];
 }
@@ -119,23 +113,23 @@ __global__ __launch_bounds__(BLOCK) void score_pairs_fwd_kernel(
 
 // dH[u] = sum_inc gl*e_k*h_k[v],  dZ[u] = sum_inc gl*q_k*e_k/t*z_k[v]  over the pair slots of node u.
 __global__ __launch_bounds__(BLOCK) void score_pairs_bwd_kernel(
-    const float* __restrict__ Z, const float* __restrict__ H, int N, int K, int d, float t,
-    const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_other,
-    const int32_t* __restrict__ inc_pair, const float* __restrict__ prob,
-    const float* __restrict__ g_prob, float* __restrict__ dZ, float* __restrict__ dH) {
+    dl_csr_plan c, const int32_t* __restrict__ inc_pair, const float* __restrict__ Z, const float* __restrict__ H,
+    int K, int d, float t, const float* __restrict__ prob, const float* __restrict__ g_prob,
+    float* __restrict__ dZ, float* __restrict__ dH) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6;
-    const int u = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (u >= N) return;
+    const int row = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (row >= c.n_rows) return;
     const int lane = lane_id();
     const int KD = K * d;
+    const size_t u = (size_t)row + c.row_offset;
     float* accZ = lds + (size_t)wave * 2 * KD;
     float* accH = accZ + KD;
     for (int x = lane; x < KD; x += DL_WAVE) { accZ[x] = 0.0f; accH[x] = 0.0f; }
-    const float* zu = Z + (size_t)u * KD;
-    const float* hu = H + (size_t)u * KD;
-    for (int it = inc_ptr[u]; it < inc_ptr[u + 1]; ++it) {
-        const int v = inc_other[it];
+    const float* zu = Z + u * KD;
+    const float* hu = H + u * KD;
+    for (int it = c.rowptr[row]; it < c.rowptr[row + 1]; ++it) {
+        const int v = c.col[it];
         const int q = inc_pair[it];
         const float pr = prob[q];
         const float gl = g_prob[q] * pr * (1.0f - pr);      // sigmoid backward p(1-p)
@@ -146,107 +140,90 @@ __global__ __launch_bounds__(BLOCK) void score_pairs_bwd_kernel(
             float ek = expf(wave_dot(zu + k * d, zv + k * d, d) / t);
             float ch = gl * ek;
             float cz = gl * qk * ek / t;
-            for (int c = lane; c < d; c += DL_WAVE) {
-                accH[k * d + c] = fmaf(ch, hv[k * d + c], accH[k * d + c]);
-                accZ[k * d + c] = fmaf(cz, zv[k * d + c], accZ[k * d + c]);
+            for (int x = lane; x < d; x += DL_WAVE) {
+                accH[k * d + x] = fmaf(ch, hv[k * d + x], accH[k * d + x]);
+                accZ[k * d + x] = fmaf(cz, zv[k * d + x], accZ[k * d + x]);
             }
         }
     }
     for (int x = lane; x < KD; x += DL_WAVE) {
-        dZ[(size_t)u * KD + x] = accZ[x];
-        dH[(size_t)u * KD + x] = accH[x];
+        dZ[u * KD + x] = accZ[x];
+        dH[u * KD + x] = accH[x];
     }
 }
 
-// B1: dw[e] = (1-beta) * dH[i][p].Z[j][p]
-__global__ __launch_bounds__(BLOCK) void bwd_dw_kernel(
-    const float* __restrict__ Z, const float* __restrict__ dH, int N, int K, int d,
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, float beta,
-    const uint8_t* __restrict__ p, float* __restrict__ dw) {
+// phase 1: dw[e], dwr[e] and ds[i][k] (see include/disenlink_hip.h)
+__global__ __launch_bounds__(BLOCK) void bwd_phase1_kernel(dl_csr_plan c, const float* __restrict__ Z,
+                                                           const float* __restrict__ dH, int K, int d, float beta,
+                                                           const uint8_t* __restrict__ p,
+                                                           const float* __restrict__ a,
+                                                           const float* __restrict__ s, float* __restrict__ dw,
+                                                           float* __restrict__ dwr, float* __restrict__ ds) {
     const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const size_t stride = (size_t)K * d;
-    const float omb = 1.0f - beta;
-    for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
-        const int k = p[e];
-        float v = wave_dot(dH + (size_t)row * stride + k * d, Z + (size_t)col[e] * stride + k * d, d);
-        if (lane_id() == 0) dw[e] = omb * v;
-    }
-}
-
-// B2: ds_k[i] = -(1/s~^2) sum_{e in row i} [p[rev e]=k] dw[rev e] a[rev e]   (0 where raw s == 0)
-//     da[e]  = dw[e]/s~[j][p] + ds_p[i]
-__global__ __launch_bounds__(BLOCK) void bwd_da_kernel(
-    int N, int K, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ rev, const uint8_t* __restrict__ p, const float* __restrict__ a,
-    const float* __restrict__ s, const float* __restrict__ dw, float* __restrict__ da) {
-    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= N) return;
+    if (row >= c.n_rows) return;
     const int lane = lane_id();
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    float acc = 0.0f;                            // lane k: sum for factor k, edge order
-    for (int e = beg; e < end; ++e) {
-        const int r = rev[e];
-        if (lane == p[r]) acc += dw[r] * a[r];
+    const size_t stride = (size_t)K * d;
+    const size_t grow = (size_t)row + c.row_offset;
+    const float omb = 1.0f - beta;
+    float acc = 0.0f;                            // lane k: sum_e [p=k] dwr*a, edge order
+    for (int e = c.rowptr[row]; e < c.rowptr[row + 1]; ++e) {
+        const int k = p[e];
+        const size_t j = (size_t)c.col[e];
+        const float v = omb * wave_dot(dH + grow * stride + k * d, Z + j * stride + k * d, d);
+        const float vr = omb * wave_dot(dH + j * stride + k * d, Z + grow * stride + k * d, d);
+        if (lane == 0) { dw[e] = v; dwr[e] = vr; }
+        if (lane == k) acc += vr * a[e];
     }
-    float ds = 0.0f;
-    if (lane < K) {
-        float sr = s[(size_t)row * K + lane];
-        ds = sr == 0.0f ? 0.0f : -acc / (sr * sr);
-    }
-    for (int base = beg; base < end; base += DL_WAVE) {     // uniform trip count: the shuffle needs all lanes
-        const int e = base + lane;
-        const bool live = e < end;
-        const int k = live ? p[e] : 0;
-        const float dsk = __shfl(ds, k, DL_WAVE);
-        if (live) da[e] = dw[e] / one_if_zero(s[(size_t)col[e] * K + k]) + dsk;
-    }
+    if (lane < K) ds[grow * K + lane] = ds_from_acc(acc, s[grow * K + lane]);
 }
 
-// B3: dZ[i] (+)= beta*dH[i] + sum_e (1-beta) a[rev e]/s~[i][p_rev] dH[j][p_rev]
-//                           + sum_e sum_k (da[e]+da[rev e]) a[e] ([k==p[e]]-alpha_k)/t * Z[j][k]
-__global__ __launch_bounds__(BLOCK) void bwd_dz_kernel(
-    const float* __restrict__ Z, const float* __restrict__ dH, int N, int K, int d,
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ rev, float beta, float t, const uint8_t* __restrict__ p,
-    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ da,
-    float* __restrict__ dZ, int accumulate) {
+// phase 2: dZ[i] (+)= beta*dH[i] + sum_e (1-beta) a/s~[i][p] dH[j][p] + sum_e sum_k c_k Z[j][k]
+__global__ __launch_bounds__(BLOCK) void bwd_phase2_kernel(dl_csr_plan c, const float* __restrict__ Z,
+                                                           const float* __restrict__ dH, int K, int d, float beta,
+                                                           float t, const uint8_t* __restrict__ p,
+                                                           const float* __restrict__ a,
+                                                           const float* __restrict__ s,
+                                                           const float* __restrict__ dw,
+                                                           const float* __restrict__ dwr,
+                                                           const float* __restrict__ ds, float* __restrict__ dZ,
+                                                           int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6;
     const int row = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (row >= N) return;
+    if (row >= c.n_rows) return;
     const int lane = lane_id();
     const int KD = K * d;
+    const size_t grow = (size_t)row + c.row_offset;
     float* acc = lds + (size_t)wave * KD;
-    const float* zi = Z + (size_t)row * KD;
-    const float* dhi = dH + (size_t)row * KD;
+    const float* zi = Z + grow * KD;
+    const float* dhi = dH + grow * KD;
     for (int x = lane; x < KD; x += DL_WAVE) acc[x] = beta * dhi[x];
     const float omb = 1.0f - beta;
-    for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
-        const int j = col[e];
-        const int r = rev[e];
-        const float* zj = Z + (size_t)j * KD;
-        {   // aggregation term seen from the neighbour's row: edge r = (j -> row)
-            const int kr = p[r];
-            const float w = omb * a[r] / one_if_zero(s[(size_t)row * K + kr]);
-            const float* dhj = dH + (size_t)j * KD + kr * d;
-            for (int c = lane; c < d; c += DL_WAVE) acc[kr * d + c] = fmaf(w, dhj[c], acc[kr * d + c]);
+    for (int e = c.rowptr[row]; e < c.rowptr[row + 1]; ++e) {
+        const size_t j = (size_t)c.col[e];
+        const int k = p[e];
+        const float ae = a[e];
+        const float si = one_if_zero(s[grow * K + k]);
+        const float sj = one_if_zero(s[j * K + k]);
+        const float* zj = Z + j * KD;
+        {   // aggregation term of the reverse edge (j -> i): a and p are symmetric
+            const float w = omb * ae / si;
+            const float* dhj = dH + j * KD + k * d;
+            for (int x = lane; x < d; x += DL_WAVE) acc[k * d + x] = fmaf(w, dhj[x], acc[k * d + x]);
         }
-        float mine_e;
-        const float alpha = edge_softmax(zi, zj, K, d, t, mine_e);
-        const int pe = p[e];
-        const float cc = (da[e] + da[r]) * a[e];
-        const float ck_mine = cc * ((lane == pe ? 1.0f : 0.0f) - alpha) / t;
-        for (int k = 0; k < K; ++k) {
-            const float ck = __shfl(ck_mine, k, DL_WAVE);
-            for (int c = lane; c < d; c += DL_WAVE) acc[k * d + c] = fmaf(ck, zj[k * d + c], acc[k * d + c]);
+        const float alpha = edge_softmax(zi, zj, K, d, t);
+        const float da = dw[e] / sj + ds[grow * K + k];
+        const float dar = dwr[e] / si + ds[j * K + k];
+        const float cc = (da + dar) * ae;
+        const float ck_mine = cc * ((lane == k ? 1.0f : 0.0f) - alpha) / t;
+        for (int kk = 0; kk < K; ++kk) {
+            const float ck = __shfl(ck_mine, kk, DL_WAVE);
+            for (int x = lane; x < d; x += DL_WAVE) acc[kk * d + x] = fmaf(ck, zj[kk * d + x], acc[kk * d + x]);
         }
     }
-    float* out = dZ + (size_t)row * KD;
+    float* out = dZ + grow * KD;
     for (int x = lane; x < KD; x += DL_WAVE) out[x] = (accumulate ? out[x] : 0.0f) + acc[x];
 }
-
-static inline unsigned blocks_for(int n) { return (unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
 }  // namespace generic
 
@@ -263,57 +240,53 @@ static int check_lds(int K, int d, int rows_per_wave) {
     return DL_OK;
 }
 
-int generic_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a,
+int generic_route_fwd(const dl_csr_plan* c, const float* Z, int K, int d, float t, uint8_t* p, float* a,
                       float* s, hipStream_t st) {
-    if (g->n_nodes == 0) return DL_OK;
-    hipLaunchKernelGGL(route_fwd_kernel, dim3(blocks_for(g->n_nodes)), dim3(BLOCK), 0, st, Z, g->n_nodes, K, d,
-                       g->rowptr, g->col, t, p, a, s);
+    hipLaunchKernelGGL(route_fwd_kernel, dim3(wave_blocks(c->n_rows)), dim3(BLOCK), 0, st, *c, Z, K, d, t, p, a, s);
     return check_launch("route_fwd(generic)");
 }
 
-int generic_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+int generic_aggregate_fwd(const dl_csr_plan* c, const float* Z, int K, int d, float beta, const uint8_t* p,
                           const float* a, const float* s, float* H, hipStream_t st) {
-    if (g->n_nodes == 0) return DL_OK;
     if (int rc = check_lds(K, d, 1)) return rc;
     size_t lds = (size_t)WAVES_PER_BLOCK * K * d * sizeof(float);
-    hipLaunchKernelGGL(aggregate_fwd_kernel, dim3(blocks_for(g->n_nodes)), dim3(BLOCK), lds, st, Z, g->n_nodes, K,
-                       d, g->rowptr, g->col, beta, p, a, s, H);
+    hipLaunchKernelGGL(aggregate_fwd_kernel, dim3(wave_blocks(c->n_rows)), dim3(BLOCK), lds, st, *c, Z, K, d, beta, p,
+                       a, s, H);
     return check_launch("aggregate_fwd(generic)");
 }
 
 int generic_score_pairs_fwd(const float* Z, const float* H, int K, int d, float t, const int32_t* pu,
                             const int32_t* pv, int P, float* prob, hipStream_t st) {
-    if (P == 0) return DL_OK;
-    hipLaunchKernelGGL(score_pairs_fwd_kernel, dim3(blocks_for(P)), dim3(BLOCK), 0, st, Z, H, K, d, t, pu, pv, P,
+    hipLaunchKernelGGL(score_pairs_fwd_kernel, dim3(wave_blocks(P)), dim3(BLOCK), 0, st, Z, H, K, d, t, pu, pv, P,
                        prob);
     return check_launch("score_pairs_fwd(generic)");
 }
 
-int generic_score_pairs_bwd(const float* Z, const float* H, int N, int K, int d, float t,
-                            const dl_pair_incidence* inc, const float* prob, const float* g_prob, float* dZ,
-                            float* dH, hipStream_t st) {
-    if (N == 0) return DL_OK;
+int generic_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
+                            const float* prob, const float* g_prob, float* dZ, float* dH, hipStream_t st) {
     if (int rc = check_lds(K, d, 2)) return rc;
     size_t lds = (size_t)WAVES_PER_BLOCK * 2 * K * d * sizeof(float);
-    hipLaunchKernelGGL(score_pairs_bwd_kernel, dim3(blocks_for(N)), dim3(BLOCK), lds, st, Z, H, N, K, d, t,
-                       inc->inc_ptr, inc->inc_other, inc->inc_pair, prob, g_prob, dZ, dH);
+    hipLaunchKernelGGL(score_pairs_bwd_kernel, dim3(wave_blocks(inc->csr.n_rows)), dim3(BLOCK), lds, st, inc->csr,
+                       inc->inc_pair, Z, H, K, d, t, prob, g_prob, dZ, dH);
     return check_launch("score_pairs_bwd(generic)");
 }
 
-int generic_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
-                                const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
-                                int accumulate, float* dw, float* da, hipStream_t st) {
-    const int N = g->n_nodes;
-    if (N == 0) return DL_OK;
+int generic_bwd_phase1(const dl_csr_plan* c, const float* Z, int K, int d, float beta, const uint8_t* p,
+                       const float* a, const float* s, const float* dH, float* dw, float* dwr, float* ds,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(bwd_phase1_kernel, dim3(wave_blocks(c->n_rows)), dim3(BLOCK), 0, st, *c, Z, dH, K, d, beta, p,
+                       a, s, dw, dwr, ds);
+    return check_launch("route_aggregate_bwd_phase1(generic)");
+}
+
+int generic_bwd_phase2(const dl_csr_plan* c, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
+                       const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
+                       const float* ds, float* dZ, int accumulate, hipStream_t st) {
     if (int rc = check_lds(K, d, 1)) return rc;
     size_t lds = (size_t)WAVES_PER_BLOCK * K * d * sizeof(float);
-    hipLaunchKernelGGL(bwd_dw_kernel, dim3(blocks_for(N)), dim3(BLOCK), 0, st, Z, dH, N, K, d, g->rowptr, g->col,
-                       beta, p, dw);
-    hipLaunchKernelGGL(bwd_da_kernel, dim3(blocks_for(N)), dim3(BLOCK), 0, st, N, K, g->rowptr, g->col, g->rev, p,
-                       a, s, dw, da);
-    hipLaunchKernelGGL(bwd_dz_kernel, dim3(blocks_for(N)), dim3(BLOCK), lds, st, Z, dH, N, K, d, g->rowptr, g->col,
-                       g->rev, beta, t, p, a, s, da, dZ, accumulate);
-    return check_launch("route_aggregate_bwd(generic)");
+    hipLaunchKernelGGL(bwd_phase2_kernel, dim3(wave_blocks(c->n_rows)), dim3(BLOCK), lds, st, *c, Z, dH, K, d, beta, t,
+                       p, a, s, dw, dwr, ds, dZ, accumulate);
+    return check_launch("route_aggregate_bwd_phase2(generic)");
 }
 
 }  // namespace dl

@@ -6,24 +6,36 @@
 namespace dl {
 
 // generic: any K <= 64, any d (dl_generic.hip)
-int generic_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
+int generic_route_fwd(const dl_csr_plan* c, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
                       hipStream_t st);
-int generic_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+int generic_aggregate_fwd(const dl_csr_plan* c, const float* Z, int K, int d, float beta, const uint8_t* p,
                           const float* a, const float* s, float* H, hipStream_t st);
 int generic_score_pairs_fwd(const float* Z, const float* H, int K, int d, float t, const int32_t* pu,
                             const int32_t* pv, int P, float* prob, hipStream_t st);
-int generic_score_pairs_bwd(const float* Z, const float* H, int N, int K, int d, float t,
-                            const dl_pair_incidence* inc, const float* prob, const float* g_prob, float* dZ,
-                            float* dH, hipStream_t st);
-int generic_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
-                                const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
-                                int accumulate, float* dw, float* da, hipStream_t st);
+int generic_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
+                            const float* prob, const float* g_prob, float* dZ, float* dH, hipStream_t st);
+int generic_bwd_phase1(const dl_csr_plan* c, const float* Z, int K, int d, float beta, const uint8_t* p,
+                       const float* a, const float* s, const float* dH, float* dw, float* dwr, float* ds,
+                       hipStream_t st);
+int generic_bwd_phase2(const dl_csr_plan* c, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
+                       const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
+                       const float* ds, float* dZ, int accumulate, hipStream_t st);
 
 // tuned, per-(K,D) instantiations (dl_fast.hip)
 bool fast_supported(int K, int d);
-int fast_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
+int fast_route_fwd(const dl_csr_plan* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
                    float* s_part, hipStream_t st);
-int fast_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+int fast_aggregate_fwd(const dl_csr_plan* g, const float* Z, int K, int d, float beta, const uint8_t* p,
                        const float* a, const float* s, float* H, float* h_part, hipStream_t st);
+int fast_bwd_phase1(const dl_csr_plan* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+                    const float* a, const float* s, const float* dH, float* dw, float* dwr, float* ds,
+                    float* ds_part, hipStream_t st);
+int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
+                    const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
+                    const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
+int fast_score_pairs_fwd(const float* Z, const float* H, int K, int d, float t, const int32_t* pu,
+                         const int32_t* pv, const int32_t* run_ptr, int n_runs, float* prob, hipStream_t st);
+int fast_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
+                         const float* prob, const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st);
 
 }  // namespace dl

@@ -55,48 +55,51 @@ class _Workspace:
 _ws = _Workspace()
 
 
-def _workspace(g: Graph, K: int, d: int):
+def _workspace(plan_ref, device, K: int, d: int):
     lib = _lib.load()
-    need = int(lib.dl_workspace_bytes(g.c_struct(), K, d))
-    buf = _ws.get(need, g.device)
-    return buf, need
+    need = int(lib.dl_workspace_bytes(plan_ref, K, d))
+    return _ws.get(need, device)
 
 
-# ---------------------------------------------------------------------- raw wrappers
-def route_fwd(g: Graph, Z: torch.Tensor, t: float):
-    """-> p uint8[E], a f32[E], s f32[N,K] (raw sums).  model.py:56-72 on the edges of adj."""
-    lib = _lib.load()
-    Z = _f32c(Z)
-    _need_cuda(Z, g.rowptr)
+def _check_rows(g: Graph, Z: torch.Tensor):
     N, K, d = _nkd(Z)
     if N != g.n_nodes:
         raise ValueError(f"Z has {N} rows, graph has {g.n_nodes} nodes")
+    return N, K, d
+
+
+# ---------------------------------------------------------------------- raw wrappers
+def route_fwd(g: Graph, Z: torch.Tensor, t: float, s_out: torch.Tensor | None = None):
+    """-> p uint8[E], a f32[E], s f32[N,K] (raw sums; only the graph's rows are written).
+    model.py:56-72 on the edges of adj."""
+    lib = _lib.load()
+    Z = _f32c(Z)
+    _need_cuda(Z, g.rowptr)
+    N, K, d = _check_rows(g, Z)
     p = torch.empty(g.n_edges, dtype=torch.uint8, device=Z.device)
     a = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
-    s = torch.empty((N, K), dtype=torch.float32, device=Z.device)
-    ws, nb = _workspace(g, K, d)
+    s = torch.empty((N, K), dtype=torch.float32, device=Z.device) if s_out is None else s_out
+    ws = _workspace(g.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_route_fwd(g.c_struct(), Z.data_ptr(), K, d, float(t), p.data_ptr(), a.data_ptr(),
                                 s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_route_fwd")
     return p, a, s
 
 
-def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s) -> torch.Tensor:
-    """-> H f32[N,K,d].  model.py:73-75."""
+def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s, H_out: torch.Tensor | None = None):
+    """-> H f32[N,K,d] (only the graph's rows are written).  model.py:73-75."""
     lib = _lib.load()
     Z = _f32c(Z)
     _need_cuda(Z, g.rowptr, p, a, s)
-    N, K, d = _nkd(Z)
-    if N != g.n_nodes:
-        raise ValueError(f"Z has {N} rows, graph has {g.n_nodes} nodes")
-    H = torch.empty_like(Z)
-    ws, nb = _workspace(g, K, d)
+    N, K, d = _check_rows(g, Z)
+    H = torch.empty_like(Z) if H_out is None else H_out
+    ws = _workspace(g.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_aggregate_fwd(g.c_struct(), Z.data_ptr(), K, d, float(beta), p.data_ptr(), a.data_ptr(),
                                     s.data_ptr(), H.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                "dl_aggregate_fwd")
     return H
 
 
-def score_pairs_fwd(Z, H, pu, pv, t: float) -> torch.Tensor:
+def score_pairs_fwd(Z, H, pu, pv, t: float, run_ptr: torch.Tensor | None = None) -> torch.Tensor:
     """-> prob f32[P].  model.py:109-113 at the listed pairs."""
     lib = _lib.load()
     Z, H = _f32c(Z), _f32c(H)
@@ -108,44 +111,78 @@ def score_pairs_fwd(Z, H, pu, pv, t: float) -> torch.Tensor:
         raise TypeError("pair indices must be int32")
     P = int(pu.numel())
     prob = torch.empty(P, dtype=torch.float32, device=Z.device)
+    rp, nr = (run_ptr.data_ptr(), int(run_ptr.numel()) - 1) if run_ptr is not None else (None, 0)
     _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pu.data_ptr(), pv.data_ptr(),
-                                      P, prob.data_ptr(), _stream()), "dl_score_pairs_fwd")
+                                      P, rp, nr, prob.data_ptr(), _stream()), "dl_score_pairs_fwd")
     return prob
 
 
-def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob):
-    """-> dZ, dH f32[N,K,d]."""
+def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, dH_out=None):
+    """-> dZ, dH f32[N,K,d] (rows of the incidence plan are written)."""
     lib = _lib.load()
     Z, H, prob, g_prob = _f32c(Z), _f32c(H), _f32c(prob), _f32c(g_prob)
-    _need_cuda(Z, H, prob, g_prob, pairs.inc_ptr)
+    _need_cuda(Z, H, prob, g_prob, pairs.inc.rowptr)
     N, K, d = _nkd(Z)
-    if prob.numel() != pairs.n_pairs or g_prob.numel() != pairs.n_pairs:
-        raise ValueError("prob / g_prob length differs from the pair list")
-    dZ = torch.empty_like(Z)
-    dH = torch.empty_like(Z)
-    _lib.check(lib.dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pairs.c_struct(),
-                                      prob.data_ptr(), g_prob.data_ptr(), dZ.data_ptr(), dH.data_ptr(), _stream()),
-               "dl_score_pairs_bwd")
+    if prob.numel() != g_prob.numel():
+        raise ValueError("prob / g_prob lengths differ")
+    dZ = torch.empty_like(Z) if dZ_out is None else dZ_out
+    dH = torch.empty_like(Z) if dH_out is None else dH_out
+    inc = pairs.c_struct(int(prob.numel()))
+    ws = _workspace(pairs.c_plan(), Z.device, K, d)
+    _lib.check(lib.dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), K, d, float(t), inc, prob.data_ptr(),
+                                      g_prob.data_ptr(), dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream()), "dl_score_pairs_bwd")
     return dZ, dH
 
 
 def route_aggregate_bwd(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_accum=None) -> torch.Tensor:
-    """-> dZ f32[N,K,d] (added onto ``dZ_accum`` in place when given)."""
+    """-> dZ f32[N,K,d] (added onto ``dZ_accum`` in place when given).  Unsharded graphs only."""
     lib = _lib.load()
     Z, dH = _f32c(Z), _f32c(dH)
     _need_cuda(Z, dH, g.rowptr, p, a, s)
-    N, K, d = _nkd(Z)
+    N, K, d = _check_rows(g, Z)
     if dZ_accum is None:
         dZ, acc = torch.empty_like(Z), 0
     else:
         if not dZ_accum.is_contiguous() or dZ_accum.shape != Z.shape:
             raise ValueError("dZ_accum must be a contiguous [N,K,d] tensor")
         dZ, acc = dZ_accum, 1
-    ws, nb = _workspace(g, K, d)
+    ws = _workspace(g.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_route_aggregate_bwd(g.c_struct(), Z.data_ptr(), K, d, float(beta), float(t), p.data_ptr(),
                                           a.data_ptr(), s.data_ptr(), dH.data_ptr(), dZ.data_ptr(), acc,
                                           ws.data_ptr(), ws.numel(), _stream()), "dl_route_aggregate_bwd")
     return dZ
+
+
+def route_aggregate_bwd_phase1(g: Graph, Z, beta: float, p, a, s, dH, ds_out: torch.Tensor):
+    """-> dw, dwr f32[E]; writes ds[N,K] rows of the graph (all-gather ds before phase 2 when sharded)."""
+    lib = _lib.load()
+    Z, dH = _f32c(Z), _f32c(dH)
+    _need_cuda(Z, dH, g.rowptr, p, a, s, ds_out)
+    N, K, d = _check_rows(g, Z)
+    dw = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
+    dwr = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
+    ws = _workspace(g.c_plan(), Z.device, K, d)
+    _lib.check(lib.dl_route_aggregate_bwd_phase1(g.c_struct(), Z.data_ptr(), K, d, float(beta), p.data_ptr(),
+                                                 a.data_ptr(), s.data_ptr(), dH.data_ptr(), dw.data_ptr(),
+                                                 dwr.data_ptr(), ds_out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _stream()), "dl_route_aggregate_bwd_phase1")
+    return dw, dwr
+
+
+def route_aggregate_bwd_phase2(g: Graph, Z, beta: float, t: float, p, a, s, dH, dw, dwr, ds, dZ_out: torch.Tensor,
+                               accumulate: bool):
+    lib = _lib.load()
+    Z, dH = _f32c(Z), _f32c(dH)
+    _need_cuda(Z, dH, g.rowptr, p, a, s, ds, dZ_out)
+    N, K, d = _check_rows(g, Z)
+    ws = _workspace(g.c_plan(), Z.device, K, d)
+    _lib.check(lib.dl_route_aggregate_bwd_phase2(g.c_struct(), Z.data_ptr(), K, d, float(beta), float(t),
+                                                 p.data_ptr(), a.data_ptr(), s.data_ptr(), dH.data_ptr(),
+                                                 dw.data_ptr(), dwr.data_ptr(), ds.data_ptr(), dZ_out.data_ptr(),
+                                                 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()),
+               "dl_route_aggregate_bwd_phase2")
+    return dZ_out
 
 
 # ---------------------------------------------------------------------- autograd
@@ -175,7 +212,7 @@ class ScorePairs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Z, H, pairs: PairList, t: float):
         Z, H = _f32c(Z), _f32c(H)
-        prob = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        prob = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
         ctx.pairs, ctx.t = pairs, t
         ctx.save_for_backward(Z, H, prob)
         return prob
@@ -198,7 +235,12 @@ class ScoreAllPairs(torch.autograd.Function):
         idx = torch.arange(N, device=Z.device, dtype=torch.int32)
         pu = idx.repeat_interleave(N)
         pv = idx.repeat(N)
-        prob = score_pairs_fwd(Z, H, pu, pv, t).view(N, N)
+        if N * N >= 2 ** 31:
+            raise ValueError("dense [N,N] scoring needs N*N < 2^31; use forward_pairs for large graphs")
+        starts = torch.arange(0, N, 64, device=Z.device, dtype=torch.int32)        # runs of <= 64 pairs sharing u
+        run_ptr = torch.cat([(idx.unsqueeze(1) * N + starts.unsqueeze(0)).reshape(-1),
+                             torch.tensor([N * N], device=Z.device, dtype=torch.int32)])
+        prob = score_pairs_fwd(Z, H, pu, pv, t, run_ptr).view(N, N)
         ctx.t = t
         ctx.save_for_backward(Z, H, prob)
         return prob

@@ -8,15 +8,20 @@
  *
  * Conventions (all entry points):
  *   - extern "C", plain pointers and sizes, no torch types.
- *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - every pointer is a DEVICE pointer.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Nothing here
  *     allocates, frees or synchronises; scratch comes from the caller (`ws`, sized by
  *     dl_workspace_bytes).  Launches are asynchronous on `stream`.
+ *   - the library is linked WITHOUT a HIP runtime and binds to the one the host process uses,
+ *     so the caller's streams and allocations are valid here.
  *   - return 0 on success, a negative DL_E_* code on error; dl_last_error() returns the
  *     message of the calling thread's last failing call.
- *   - layouts: Z, H, dZ, dH are fp32 [N][K][d] row-major (== torch.cat(h_k, dim=1) of
- *     model.py:114); indices int32; factor ids uint8; s is [N][K] RAW row sums (the
+ *   - layouts: Z, H, dZ, dH are fp32 [n_total][K][d] row-major (== torch.cat(h_k, dim=1) of
+ *     model.py:114); indices int32; factor ids uint8; s is [n_total][K] RAW row sums (the
  *     zero -> 1 substitution of model.py:72 is applied where s is read).
+ *   - sharding: a plan may cover only rows [row_offset, row_offset + n_rows) of the n_total
+ *     nodes (one shard per GPU).  Node-indexed arrays are always indexed by GLOBAL node id and
+ *     only the plan's rows are written; per-entry arrays (p, a, ...) are local to the plan.
  *   - results do not depend on launch order / placement; no float atomics are used, so every
  *     entry point is bitwise reproducible run to run.
  */
@@ -37,35 +42,39 @@ extern "C" {
 
 #define DL_MAX_FACTORS  64   /* K <= 64 */
 
-/* CSR of the binarised, symmetrised training adjacency (main_disentangled.py:137-142) plus the
- * row-segment plan used to balance skewed degrees.  All arrays live on the device. */
-typedef struct dl_graph {
-    int32_t n_nodes;
-    int32_t n_edges;            /* directed non-zeros of adj_sym (both directions present) */
-    const int32_t* rowptr;      /* [n_nodes+1] */
-    const int32_t* col;         /* [n_edges], ascending inside a row */
-    const int32_t* rev;         /* [n_edges], rev[e] = index of the edge (col[e], row(e)) */
-    /* segment plan: every row is cut into >=1 segments of <= seg_len consecutive edges */
+/* A CSR over (a shard of) the nodes plus the segment plan that balances skewed rows: every row is
+ * cut into >= 1 segments of <= seg_len consecutive entries; one wavefront owns one segment.  Rows
+ * with several segments reduce through per-segment partial slots in the workspace. */
+typedef struct dl_csr_plan {
+    int32_t n_rows;             /* rows of this plan */
+    int32_t row_offset;         /* global node id of row 0 */
+    int32_t n_total;            /* global node count (extent of node-indexed arrays) */
+    int32_t n_entries;
+    const int32_t* rowptr;      /* [n_rows+1] */
+    const int32_t* col;         /* [n_entries] global node ids */
     int32_t seg_len;
     int32_t n_seg;
-    const int32_t* seg_row;     /* [n_seg] */
-    const int32_t* seg_beg;     /* [n_seg] first edge of the segment */
-    const int32_t* seg_slot;    /* [n_seg] partial-sum slot of the segment, -1 if its row has one segment */
-    const int32_t* row_seg0;    /* [n_nodes+1] first segment of each row */
-    int32_t n_multi;
-    int32_t n_slots;            /* segments that belong to multi-segment rows */
-    const int32_t* multi_row;   /* [n_multi] rows with more than one segment */
+    const int32_t* seg_row;     /* [n_seg] local row of the segment */
+    const int32_t* seg_beg;     /* [n_seg] first entry of the segment */
+    const int32_t* seg_slot;    /* [n_seg] partial slot, -1 if the row has a single segment */
+    int32_t n_multi;            /* rows with more than one segment */
+    int32_t n_slots;            /* segments belonging to such rows */
+    const int32_t* multi_row;   /* [n_multi] local row */
     const int32_t* multi_slot0; /* [n_multi+1] first slot of each such row (slots are consecutive) */
+} dl_csr_plan;
+
+/* The binarised, symmetrised training adjacency (main_disentangled.py:137-142): entries are the
+ * directed non-zeros of adj_sym, col ascending inside a row, both directions present. */
+typedef struct dl_graph {
+    dl_csr_plan csr;
 } dl_graph;
 
-/* Node-incidence list of a scored pair list: for node u, entries inc_ptr[u]..inc_ptr[u+1]-1 name
- * the other endpoint and the pair id of every pair slot u occupies (a pair (u,u) appears twice). */
+/* Node-incidence list of a scored pair list: row u lists, for every pair slot u occupies, the
+ * other endpoint (csr.col) and the pair id (inc_pair); a pair (u,u) appears twice. */
 typedef struct dl_pair_incidence {
-    int32_t n_nodes;
-    int32_t n_pairs;
-    const int32_t* inc_ptr;     /* [n_nodes+1] */
-    const int32_t* inc_other;   /* [2*n_pairs] */
-    const int32_t* inc_pair;    /* [2*n_pairs] */
+    dl_csr_plan csr;
+    const int32_t* inc_pair;    /* [csr.n_entries] */
+    int32_t n_pairs;            /* extent of the prob / g_prob arrays */
 } dl_pair_incidence;
 
 const char* dl_version(void);
@@ -76,8 +85,8 @@ int dl_has_fast_path(int K, int d);
 /* Force the generic kernels (parity cross-check of the two implementations).  Returns old value. */
 int dl_set_force_generic(int on);
 
-/* Scratch needed by the calls below for this graph and shape. */
-size_t dl_workspace_bytes(const dl_graph* g, int K, int d);
+/* Scratch needed by the calls below for this plan and shape. */
+size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
 
 /* Routing: replaces model.py:56-72 restricted to adj==1 entries.
  *   per edge e=(i,j):  sigma_k = z_k[i].z_k[j] / t ; e_k = exp(sigma_k) ; alpha_k = e_k / sum_k e_k
@@ -88,25 +97,44 @@ int dl_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t,
 
 /* Aggregation ("K-factor edge scatter"): replaces model.py:73-75.
  *   H[i][k] = beta*Z[i][k] + (1-beta) * sum_{e=(i,j), p[e]=k} a[e] / s~[j][k] * Z[j][k]
- *   with s~ = (s==0 ? 1 : s) and the normaliser taken at the NEIGHBOUR j (model.py:73 broadcast). */
+ *   with s~ = (s==0 ? 1 : s) and the normaliser taken at the NEIGHBOUR j (model.py:73 broadcast);
+ *   s must hold the rows of every neighbour (all-gathered when sharded). */
 int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta,
                      const uint8_t* p, const float* a, const float* s,
                      float* H, void* ws, size_t ws_bytes, void* stream);
 
 /* Pair-list link scorer: replaces model.py:109-113 evaluated at the listed (u,v) only.
- *   prob[q] = sigmoid( sum_k (h_k[u].h_k[v]) * exp(z_k[u].z_k[v] / t) )    (raw exp, not softmax) */
+ *   prob[q] = sigmoid( sum_k (h_k[u].h_k[v]) * exp(z_k[u].z_k[v] / t) )    (raw exp, not softmax)
+ * run_ptr (optional, may be NULL): [n_runs+1] boundaries of consecutive pairs that share pu (long
+ * runs cut into chunks); lets a wavefront keep the u rows in LDS for the whole run. */
 int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t,
                        const int32_t* pu, const int32_t* pv, int n_pairs,
+                       const int32_t* run_ptr, int n_runs,
                        float* prob, void* stream);
 
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
- * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for all N rows. */
-int dl_score_pairs_bwd(const float* Z, const float* H, int N, int K, int d, float t,
+ * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows. */
+int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t,
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob,
-                       float* dZ, float* dH, void* stream);
+                       float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of aggregate + normaliser + routing softmax (autograd of model.py:56-75; argmax and
- * masks carry no gradient).  dZ_out = (accumulate ? dZ_out : 0) + d/dZ.  SURVEY.md Appendix A.3. */
+ * masks carry no gradient), SURVEY.md Appendix A.3, split at its one global dependency:
+ *   phase 1:  dw[e] = (1-beta) dH[i][p].Z[j][p],  dwr[e] = (1-beta) dH[j][p].Z[i][p]  (reverse edge)
+ *             ds[i][k] = -(sum_{e in row i, p=k} dwr[e] a[e]) / s~[i][k]^2          (0 where s == 0)
+ *   phase 2:  da = dw/s~[j][p] + ds[i][p],  dar = dwr/s~[i][p] + ds[j][p]
+ *             dZ[i] (+)= beta dH[i] + sum_e (1-beta) a/s~[i][p] dH[j][p]
+ *                                   + sum_e sum_k (da+dar) a ([k==p]-alpha_k)/t Z[j][k]
+ * dH and (for phase 2) ds must hold the rows of every neighbour (all-gathered when sharded).
+ * dw, dwr are per-entry scratch of the caller ([n_entries] each).
+ * dl_route_aggregate_bwd runs both phases back to back (single GPU). */
+int dl_route_aggregate_bwd_phase1(const dl_graph* g, const float* Z, int K, int d, float beta,
+                                  const uint8_t* p, const float* a, const float* s, const float* dH,
+                                  float* dw, float* dwr, float* ds, void* ws, size_t ws_bytes, void* stream);
+int dl_route_aggregate_bwd_phase2(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
+                                  const uint8_t* p, const float* a, const float* s, const float* dH,
+                                  const float* dw, const float* dwr, const float* ds,
+                                  float* dZ, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int dl_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
                            const uint8_t* p, const float* a, const float* s,
                            const float* dH, float* dZ, int accumulate,

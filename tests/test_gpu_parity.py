@@ -165,9 +165,17 @@ def test_forward_and_backward_match_oracle_on_random_graphs(K, d, N, deg, force_
         pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
         pu[:5] = pv[:5]
         pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N)
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
         prob_o = sparse_ref.score_pairs(Zh, H_o, pu, pv, t)
         np.testing.assert_allclose(prob.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
+        # pairs sorted by u give long runs (the LDS-staged path); no runs at all takes the per-pair path
+        order = np.argsort(pu, kind="stable")
+        spairs = PairList.build(torch.from_numpy(pu[order]).to(DEV), torch.from_numpy(pv[order]).to(DEV), N)
+        assert spairs.n_runs < pairs.n_runs
+        prob_s = ops.score_pairs_fwd(Z, H, spairs.pu, spairs.pv, t, spairs.run_ptr)
+        np.testing.assert_allclose(prob_s.cpu().numpy(), prob_o[order], rtol=1e-5, atol=1e-5)
+        prob_n = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, None)
+        np.testing.assert_allclose(prob_n.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
         # backward
         gp = (rng.standard_normal(P) * 0.1).astype(np.float32)
         dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, torch.from_numpy(gp).to(DEV))
@@ -228,3 +236,78 @@ def test_exp_overflow_propagates_like_the_reference():
     assert np.array_equal(p.cpu().numpy(), p_o)
     fin = ~np.isnan(a_o)
     np.testing.assert_allclose(a.cpu().numpy()[fin], a_o[fin], rtol=1e-6)
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic):
+    """Three row shards on one GPU, sharing the node-indexed arrays the way all-gathers would:
+    forward and both backward phases must equal the unsharded run bit for bit."""
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph, PairList
+    K, d, N, beta, t = 8, 64, 700, 0.7, 1.0
+    src, dst, Zh, rng = _random_problem(42, N, K, d, 14)
+    old = _lib.load().dl_set_force_generic(force_generic)
+    try:
+        ts, td = torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV)
+        G = Graph.from_edge_rows(ts, td, N)
+        Z = torch.from_numpy(Zh).to(DEV)
+        p, a, s = ops.route_fwd(G, Z, t)
+        H = ops.aggregate_fwd(G, Z, beta, p, a, s)
+        P = 5000
+        pu, pv = np.sort(rng.integers(0, N, P)), rng.integers(0, N, P)
+        tpu, tpv = torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV)
+        pairs = PairList.build(tpu, tpv, N)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        gp = torch.from_numpy((rng.standard_normal(P) * 0.1).astype(np.float32)).to(DEV)
+        dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp)
+        dZ = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH, dZ_accum=dZs.clone())
+
+        bounds = [0, 230, 231, N]                      # uneven shards, one of a single row
+        shards = [Graph.from_edge_rows(ts, td, N, row_range=(lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+        s2 = torch.full_like(s, float("nan"))
+        H2 = torch.full_like(H, float("nan"))
+        routed = [ops.route_fwd(g, Z, t, s_out=s2)[:2] for g in shards]          # "all-gather" of s = shared buffer
+        for g, (pp, aa) in zip(shards, routed):
+            ops.aggregate_fwd(g, Z, beta, pp, aa, s2, H_out=H2)
+        assert torch.equal(s, s2) and torch.equal(H, H2)
+        assert torch.equal(torch.cat([r[0] for r in routed]), p) and torch.equal(torch.cat([r[1] for r in routed]), a)
+        # scorer: each shard scores a slice of the pairs and owns the incidence rows of its nodes
+        cut = [0, 1700, 1701, P]
+        prob2 = torch.cat([ops.score_pairs_fwd(Z, H2, pairs.pu[b:e].contiguous(), pairs.pv[b:e].contiguous(), t, None)
+                           for b, e in zip(cut[:-1], cut[1:])])
+        np.testing.assert_allclose(prob2.cpu().numpy(), prob.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        dZs2 = torch.full_like(Z, float("nan"))
+        dH2 = torch.full_like(Z, float("nan"))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            inc = PairList.build(tpu, tpv, N, row_range=(lo, hi))
+            ops.score_pairs_bwd(Z, H, inc, t, prob, gp, dZ_out=dZs2, dH_out=dH2)
+        assert torch.equal(dZs, dZs2) and torch.equal(dH, dH2)
+        ds = torch.full_like(s, float("nan"))
+        ph1 = [ops.route_aggregate_bwd_phase1(g, Z, beta, pp, aa, s, dH, ds) for g, (pp, aa) in zip(shards, routed)]
+        dZ2 = dZs.clone()
+        for g, (pp, aa), (dw, dwr) in zip(shards, routed, ph1):
+            ops.route_aggregate_bwd_phase2(g, Z, beta, t, pp, aa, s, dH, dw, dwr, ds, dZ2, accumulate=True)
+        assert torch.equal(dZ, dZ2)
+    finally:
+        _lib.load().dl_set_force_generic(old)
+
+
+def test_launches_follow_the_callers_stream():
+    """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import Graph
+    K, d, N = 8, 64, 3000
+    src, dst, Zh, _rng = _random_problem(7, N, K, d, 20)
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+    Z = torch.from_numpy(Zh).to(DEV)
+    p0, a0, s0 = ops.route_fwd(G, Z, 1.0)
+    H0 = ops.aggregate_fwd(G, Z, 0.5, p0, a0, s0)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        Zs = Z * 1.0                                   # produced on the side stream, consumed by our kernels
+        for _ in range(5):
+            p1, a1, s1 = ops.route_fwd(G, Zs, 1.0)
+            H1 = ops.aggregate_fwd(G, Zs, 0.5, p1, a1, s1)
+    side.synchronize()
+    assert torch.equal(H0, H1) and torch.equal(p0, p1)

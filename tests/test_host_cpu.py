@@ -41,6 +41,10 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1 and b"K=0" in lib.dl_last_error()
     rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, 0.0, None, None, None, None, 0, None)
     assert rc == -1 and b"temperature" in lib.dl_last_error()
+    g.csr.n_rows, g.csr.row_offset, g.csr.n_total = 5, 3, 6          # shard sticking out of the node range
+    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, 1.0, None, None, None, None, 0, None)
+    assert rc == -1 and b"exceed n_total" in lib.dl_last_error()
+    assert lib.dl_has_fast_path(8, 64) == 1 and lib.dl_has_fast_path(3, 5) == 0
 
 
 def test_ops_fail_loudly_on_cpu_tensors():
@@ -50,6 +54,29 @@ def test_ops_fail_loudly_on_cpu_tensors():
     Z = torch.randn(3, 2, 4)
     with pytest.raises(_lib.DisenlinkHipError, match="no CPU fallback"):
         ops.route_fwd(g, Z, 1.0)
+
+
+def _check_plan(plan, rowptr, seg_len):
+    """segment plan: every row covered exactly once, in order, by segments of <= seg_len entries;
+    multi-segment rows own consecutive partial slots"""
+    deg = np.diff(rowptr)
+    seg_row, seg_beg, seg_slot = plan.seg_row.numpy(), plan.seg_beg.numpy(), plan.seg_slot.numpy()
+    row_seg0 = plan.row_seg0.numpy()
+    assert row_seg0[0] == 0 and row_seg0[-1] == plan.n_seg
+    for i in range(plan.n_rows):
+        segs = range(row_seg0[i], row_seg0[i + 1])
+        assert len(segs) == max(1, -(-deg[i] // seg_len))
+        assert all(seg_row[s] == i for s in segs)
+        assert [seg_beg[s] for s in segs] == [rowptr[i] + q * seg_len for q in range(len(segs))]
+    multi = np.flatnonzero(deg > seg_len)
+    assert np.array_equal(plan.multi_row.numpy(), multi)
+    slot0 = plan.multi_slot0.numpy()
+    assert slot0[0] == 0 and slot0[-1] == plan.n_slots
+    for m, i in enumerate(multi):
+        segs = list(range(row_seg0[i], row_seg0[i + 1]))
+        assert [seg_slot[s] for s in segs] == list(range(slot0[m], slot0[m + 1]))
+    single = np.setdiff1d(np.arange(plan.n_rows), multi)
+    assert all(seg_slot[row_seg0[i]] == -1 for i in single)
 
 
 @pytest.mark.parametrize("name", golden_case_names())
@@ -62,16 +89,16 @@ def test_graph_builder_matches_oracle_csr(name):
         assert np.array_equal(G.rowptr.numpy(), rowptr)
         assert np.array_equal(G.col.numpy(), col)
         assert np.array_equal(G.rev.numpy(), rev)
-        # segment plan: every row covered exactly once, in order, by segments of <= seg_len edges
-        deg = np.diff(rowptr)
-        seg_row, seg_beg, row_seg0 = G.seg_row.numpy(), G.seg_beg.numpy(), G.row_seg0.numpy()
-        assert row_seg0[0] == 0 and row_seg0[-1] == G.n_seg
-        for i in range(G.n_nodes):
-            segs = range(row_seg0[i], row_seg0[i + 1])
-            assert len(segs) == max(1, -(-deg[i] // seg_len))
-            assert all(seg_row[s] == i for s in segs)
-            assert [seg_beg[s] for s in segs] == [rowptr[i] + q * seg_len for q in range(len(segs))]
-        assert np.array_equal(G.multi_row.numpy(), np.flatnonzero(deg > seg_len))
+        _check_plan(G.plan, rowptr, seg_len)
+        # a shard keeps global column ids and re-bases rowptr
+        lo, hi = G.n_nodes // 3, G.n_nodes - 2
+        nz = np.nonzero(g["adj"])
+        S = Graph.from_edge_rows(torch.from_numpy(nz[0]), torch.from_numpy(nz[1]), G.n_nodes, symmetrise=False,
+                                 seg_len=seg_len, row_range=(lo, hi))
+        assert S.n_rows == hi - lo and S.row_offset == lo and S.n_nodes == G.n_nodes
+        assert np.array_equal(S.rowptr.numpy(), rowptr[lo:hi + 1] - rowptr[lo])
+        assert np.array_equal(S.col.numpy(), col[rowptr[lo]:rowptr[hi]])
+        _check_plan(S.plan, S.rowptr.numpy(), seg_len)
 
 
 def test_graph_from_edge_rows_symmetrises_and_collapses_duplicates():
@@ -91,6 +118,7 @@ def test_graph_from_edge_rows_symmetrises_and_collapses_duplicates():
         Graph.from_edge_rows(torch.tensor([0]), torch.tensor([7]), 5)
     empty = Graph.from_edge_rows(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 4)
     assert empty.n_edges == 0 and empty.n_seg == 4 and empty.rowptr.tolist() == [0] * 5
+    assert empty.plan.n_slots == 0 and empty.plan.multi_row.numel() == 0
 
 
 def test_pair_incidence_lists_every_slot_once():
@@ -99,8 +127,20 @@ def test_pair_incidence_lists_every_slot_once():
     n, P = 11, 60
     pu, pv = rng.integers(0, n, P), rng.integers(0, n, P)
     pu[:3] = pv[:3]                                   # self pairs
-    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n)
-    ptr, other, pair = pl.inc_ptr.numpy(), pl.inc_other.numpy(), pl.inc_pair.numpy()
+    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, run_len=4)
+    ptr, other, pair = pl.inc.rowptr.numpy(), pl.inc.col.numpy(), pl.inc_pair.numpy()
+    # runs: consecutive pairs sharing pu, at most run_len long, covering the list exactly
+    rp = pl.run_ptr.numpy()
+    assert rp[0] == 0 and rp[-1] == P and (np.diff(rp) > 0).all() and (np.diff(rp) <= 4).all()
+    for b, e in zip(rp[:-1], rp[1:]):
+        assert (pu[b:e] == pu[b]).all()
+    sorted_pl = PairList.build(torch.from_numpy(np.sort(pu)), torch.from_numpy(pv), n, run_len=4)
+    assert sorted_pl.n_runs < pl.n_runs
+    # a shard lists only its own nodes' slots
+    sh = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, row_range=(3, 8))
+    assert sh.inc.n_rows == 5 and sh.inc.row_offset == 3
+    assert np.array_equal(sh.inc.rowptr.numpy(), ptr[3:9] - ptr[3])
+    assert np.array_equal(sh.inc.col.numpy(), other[ptr[3]:ptr[8]])
     assert ptr[-1] == 2 * P
     seen = np.zeros(P, int)
     for u in range(n):
