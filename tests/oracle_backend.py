@@ -1,0 +1,104 @@
+"""CPU stand-in for the HIP backend of disenlink_amd.dist, built on the oracle (numpy).  TEST ONLY.
+
+It lets the world_size-2 gloo tests exercise the sharding choreography (partition, padding,
+collectives, autograd glue, gradient all-reduce) without a GPU.  Same contract as
+``disenlink_amd.dist.HipBackend``: node-indexed outputs are written at GLOBAL row ids for the
+plan's rows only; per-edge arrays are local to the plan.
+"""
+import numpy as np
+import torch
+
+from oracle import sparse_ref
+from oracle.sparse_ref import _edge_dots, f32
+
+
+def _rows(plan):
+    rowptr = plan.rowptr.numpy().astype(np.int64)
+    src = np.repeat(np.arange(plan.n_rows, dtype=np.int64), np.diff(rowptr)) + plan.row_offset
+    return src, plan.col.numpy().astype(np.int64)
+
+
+class OracleBackend:
+    def route_fwd(self, g, Z, t, s_out):
+        src, dst = _rows(g.plan)
+        Zh = Z.numpy()
+        K = Zh.shape[1]
+        with np.errstate(over="ignore", invalid="ignore"):
+            ex = np.exp(_edge_dots(Zh, src, dst) / f32(t), dtype=f32)
+            alpha = ex / ex.sum(axis=1, dtype=f32, keepdims=True)
+        p = np.argmax(alpha, axis=1) if src.size else np.zeros(0, np.int64)
+        a = alpha[np.arange(p.size), p].astype(f32) if src.size else np.zeros(0, f32)
+        s_loc = np.zeros((g.n_rows, K), dtype=f32)
+        np.add.at(s_loc, (src - g.row_offset, p), a)
+        s_out[g.row_offset:g.row_offset + g.n_rows] = torch.from_numpy(s_loc)
+        return torch.from_numpy(p.astype(np.uint8)), torch.from_numpy(a)
+
+    def aggregate_fwd(self, g, Z, beta, p, a, s, H_out):
+        src, dst = _rows(g.plan)
+        Zh, sh = Z.numpy(), s.numpy()
+        sh = np.where(sh == 0, f32(1), sh)
+        pk = p.numpy().astype(np.int64)
+        w = (a.numpy() / sh[dst, pk]).astype(f32)
+        acc = np.zeros((g.n_rows,) + Zh.shape[1:], dtype=f32)
+        np.add.at(acc, (src - g.row_offset, pk), w[:, None] * Zh[dst, pk])
+        lo, hi = g.row_offset, g.row_offset + g.n_rows
+        H_out[lo:hi] = torch.from_numpy((f32(beta) * Zh[lo:hi] + f32(1 - beta) * acc).astype(f32))
+
+    def score_pairs_fwd(self, Z, H, pairs, t):
+        return torch.from_numpy(sparse_ref.score_pairs(Z.numpy(), H.numpy(), pairs.pu.numpy(), pairs.pv.numpy(), t))
+
+    def score_pairs_bwd(self, Z, H, inc, t, prob, g_prob, dZ_out, dH_out):
+        u, v = _rows(inc.inc)
+        q = inc.inc_pair.numpy().astype(np.int64)
+        Zh, Hh = Z.numpy(), H.numpy()
+        pr, gq = prob.numpy()[q], g_prob.numpy()[q]
+        _prob, qk, ex = sparse_ref.score_pairs(Zh, Hh, u, v, t, return_parts=True)
+        gl = (gq * pr * (f32(1) - pr)).astype(f32)
+        n = inc.inc.n_rows
+        dH = np.zeros((n,) + Zh.shape[1:], dtype=f32)
+        dZ = np.zeros_like(dH)
+        np.add.at(dH, u - inc.inc.row_offset, (gl[:, None] * ex)[:, :, None] * Hh[v])
+        np.add.at(dZ, u - inc.inc.row_offset, (gl[:, None] * qk * ex / f32(t))[:, :, None] * Zh[v])
+        lo = inc.inc.row_offset
+        dZ_out[lo:lo + n] = torch.from_numpy(dZ)
+        dH_out[lo:lo + n] = torch.from_numpy(dH)
+
+    def bwd_phase1(self, g, Z, beta, p, a, s, dH, ds_out):
+        src, dst = _rows(g.plan)
+        Zh, Dh, sh = Z.numpy(), dH.numpy(), s.numpy()
+        pk = p.numpy().astype(np.int64)
+        dw = f32(1 - beta) * np.einsum("ed,ed->e", Dh[src, pk], Zh[dst, pk], dtype=f32)
+        dwr = f32(1 - beta) * np.einsum("ed,ed->e", Dh[dst, pk], Zh[src, pk], dtype=f32)
+        acc = np.zeros((g.n_rows, Zh.shape[1]), dtype=f32)
+        np.add.at(acc, (src - g.row_offset, pk), dwr * a.numpy())
+        lo, hi = g.row_offset, g.row_offset + g.n_rows
+        s_loc = sh[lo:hi]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ds = np.where(s_loc == 0, f32(0), -acc / (s_loc * s_loc)).astype(f32)
+        ds_out[lo:hi] = torch.from_numpy(ds)
+        return torch.from_numpy(dw.astype(f32)), torch.from_numpy(dwr.astype(f32))
+
+    def bwd_phase2(self, g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ_out, accumulate):
+        src, dst = _rows(g.plan)
+        Zh, Dh, sh, dsh = Z.numpy(), dH.numpy(), s.numpy(), ds.numpy()
+        sh = np.where(sh == 0, f32(1), sh)
+        pk = p.numpy().astype(np.int64)
+        ah = a.numpy()
+        E, K = src.size, Zh.shape[1]
+        lo, hi = g.row_offset, g.row_offset + g.n_rows
+        acc = (f32(beta) * Dh[lo:hi]).astype(f32)
+        np.add.at(acc, (src - lo, pk), (f32(1 - beta) * ah / sh[src, pk])[:, None] * Dh[dst, pk])
+        with np.errstate(over="ignore", invalid="ignore"):
+            ex = np.exp(_edge_dots(Zh, src, dst) / f32(t), dtype=f32)
+            alpha = ex / ex.sum(axis=1, dtype=f32, keepdims=True)
+        onehot = np.zeros((E, K), dtype=f32)
+        onehot[np.arange(E), pk] = 1
+        da = dw.numpy() / sh[dst, pk] + dsh[src, pk]
+        dar = dwr.numpy() / sh[src, pk] + dsh[dst, pk]
+        c = ((da + dar) * ah)[:, None] * (onehot - alpha) / f32(t)
+        np.add.at(acc, src - lo, c[:, :, None] * Zh[dst])
+        out = torch.from_numpy(acc.astype(f32))
+        if accumulate:
+            dZ_out[lo:hi] += out
+        else:
+            dZ_out[lo:hi] = out
