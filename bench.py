@@ -111,9 +111,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("DL_FORCE_SHARDED"))     # the env var rehearses the N>1 code on 1 GPU
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from disenlink_amd import _lib, ops
     lib = _lib.load()
@@ -122,11 +125,13 @@ def main():
 
     K, d = args.K, args.d
     beta, t = 0.5, 1.0
-    if world > 1:
+    if sharded:
+        import torch.distributed as dist
         from disenlink_amd import dist as dl_dist
         result = dl_dist.bench_sharded(args, rank, world, device)
         if rank == 0:
             print(json.dumps(result))
+        dist.destroy_process_group()
         return
 
     sg, split, graph, pairs, model, x, Z = build_workload(args.workload, device, K, d, args.nhidden, scale=args.scale)

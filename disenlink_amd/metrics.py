@@ -1,0 +1,43 @@
+"""Caller-side loss and AUC on pair lists, on the device.
+
+  pair_bce_loss   main_disentangled.py:195 — BCE(mean, log clamped at -100 by torch) on the positive
+                  pairs + BCE on the negative pairs / m, in PROBABILITY space (finding 4 of SURVEY.md §0:
+                  saturated fp32 sigmoids must give exactly zero gradient, so no with-logits fusion).
+  auc_tie_avg     main_disentangled.py:202-204, :217-219 — sklearn.roc_auc_score on fp32 probabilities,
+                  i.e. Mann-Whitney U with tie-averaged ranks; computed with torch ops on the device so
+                  the per-epoch device->host copy of all validation scores disappears.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def pair_bce_loss(prob_pos, label_pos, prob_neg, label_neg, m: int) -> torch.Tensor:
+    return F.binary_cross_entropy(prob_pos, label_pos) + F.binary_cross_entropy(prob_neg, label_neg) / m
+
+
+def auc_tie_avg(label: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+    """0-dim float64 tensor on score.device.  Raises if only one class is present."""
+    label = label.reshape(-1)
+    score = score.reshape(-1).detach()
+    n = score.numel()
+    pos = label > 0.5
+    n_pos = pos.sum()
+    n_neg = n - n_pos
+    if int(n_pos) == 0 or int(n_neg) == 0:
+        raise ValueError("AUC undefined with one class")
+    order = torch.argsort(score, stable=True)
+    ss = score[order]
+    # runs of equal scores -> average 1-based rank (lo+1+hi)/2 with [lo, hi) the run
+    new_run = torch.ones(n, dtype=torch.bool, device=score.device)
+    new_run[1:] = ss[1:] != ss[:-1]
+    run_id = torch.cumsum(new_run, dim=0) - 1
+    starts = torch.nonzero(new_run).reshape(-1)
+    ends = torch.cat([starts[1:], torch.tensor([n], device=score.device)])
+    avg = (starts + 1 + ends).to(torch.float64) / 2.0
+    rank_sorted = avg[run_id]
+    r_pos = rank_sorted[pos[order]].sum()
+    n_pos = n_pos.to(torch.float64)
+    n_neg = n_neg.to(torch.float64)
+    return (r_pos - n_pos * (n_pos + 1.0) / 2.0) / (n_pos * n_neg)

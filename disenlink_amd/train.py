@@ -1,0 +1,92 @@
+"""The reference's train / early-stop / eval loop (main_disentangled.py:191-224) on pair lists.
+
+Same schedule as the reference: Adam(lr, weight_decay=5e-4) (:150, the flag is ignored there too),
+one full-batch forward per epoch, validation AUC computed from THAT forward's probabilities (i.e.
+the weights before the step, :202-204), best weights snapshotted after the step (:209), patience
+200 (:212), test AUC with the best weights (:215-219).
+
+`model` is any module with ``forward_pairs(x, graph, pairs) -> (emb, prob)``: the drop-in
+``disenlink_amd.model.Disentangle`` on the GPU, or (in tests only) an oracle-backed module on CPU.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+from torch.optim import Adam
+
+from .graph import Graph, PairList
+from .metrics import auc_tie_avg, pair_bce_loss
+from .splits import LinkSplit
+
+
+@dataclass
+class PreparedRun:
+    graph: Graph
+    train_val_pairs: PairList       # [pos_train | neg_train | val], scored by one forward per epoch
+    n_pos: int
+    n_neg: int
+    label_pos: torch.Tensor
+    label_neg: torch.Tensor
+    label_val: torch.Tensor
+    test_pairs: PairList
+    label_test: torch.Tensor
+    m: int
+
+
+def prepare_run(split: LinkSplit, device, seg_len: int = 32) -> PreparedRun:
+    t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
+    graph = Graph.from_edge_rows(t(split.train_src), t(split.train_dst), split.n_nodes, seg_len=seg_len)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u, split.val.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v, split.val.v])
+    tv = PairList.build(t(pu), t(pv), split.n_nodes, seg_len=seg_len)
+    te = PairList.build(t(split.test.u), t(split.test.v), split.n_nodes, seg_len=seg_len)
+    return PreparedRun(graph, tv, split.pos_train.u.size, split.neg_train.u.size,
+                       t(split.pos_train.label, torch.float32), t(split.neg_train.label, torch.float32),
+                       t(split.val.label, torch.float32), te, t(split.test.label, torch.float32), split.m)
+
+
+@dataclass
+class RunResult:
+    test_auc: float
+    best_val_auc: float
+    epochs_run: int
+    losses: list = field(default_factory=list)
+    val_aucs: list = field(default_factory=list)
+
+
+def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 2000, lr: float = 1e-4,
+                        patience: int = 200, weight_decay: float = 5e-4, log=None) -> RunResult:
+    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+    best_auc, stale, weights = 0.0, 0, deepcopy(model.state_dict())
+    res = RunResult(float("nan"), 0.0, 0)
+    a, b = run.n_pos, run.n_pos + run.n_neg
+    for epoch in range(epochs):
+        model.train()
+        _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
+        loss = pair_bce_loss(prob[:a], run.label_pos, prob[a:b], run.label_neg, run.m)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        model.eval()
+        auc = float(auc_tie_avg(run.label_val, prob[b:]))          # from the pre-step forward, like :202-204
+        res.losses.append(float(loss.detach()))
+        res.val_aucs.append(auc)
+        res.epochs_run = epoch + 1
+        if auc > best_auc:
+            stale, best_auc = 0, auc
+            weights = deepcopy(model.state_dict())
+        else:
+            stale += 1
+        if stale > patience:
+            break
+        if log is not None:
+            log(f"epoch: {epoch} loss: {res.losses[-1]} val_auc: {best_auc}")
+    model.load_state_dict(weights)
+    with torch.no_grad():
+        _emb, prob = model.forward_pairs(x, run.graph, run.test_pairs)
+    res.test_auc = float(auc_tie_avg(run.label_test, prob))
+    res.best_val_auc = best_auc
+    return res

@@ -311,3 +311,35 @@ def test_launches_follow_the_callers_stream():
             H1 = ops.aggregate_fwd(G, Zs, 0.5, p1, a1, s1)
     side.synchronize()
     assert torch.equal(H0, H1) and torch.equal(p0, p1)
+
+
+def test_training_trajectory_matches_cpu_oracle():
+    """Same splits, same init, same schedule (main_disentangled.py:191-224): the HIP module's loss and
+    validation-AUC trajectory vs the dense CPU oracle's.  Trajectories drift apart with training
+    (hard arg-max routing + fp32 sigmoid saturation), so the gate is tight on
+    the first epochs and statistical (1e-3 level) at the end."""
+    from test_train_cpu import OraclePairModule
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sg = synthetic_graph("chameleon", seed=3, scale=0.12)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=1)
+    F, nhid, d, K = 32, 24, 32, 4
+    x = sg.features()[:, :F].copy()
+    torch.manual_seed(1)
+    ref_inner = Disentangle(F, nhid, d, nfactor=K, beta=0.7, t=1)
+    sd = {k: v.clone() for k, v in ref_inner.state_dict().items()}
+    res_cpu = run_link_prediction(OraclePairModule(ref_inner), torch.from_numpy(x), prepare_run(split, "cpu"),
+                                  epochs=12, lr=1e-3)
+    gpu = Disentangle(F, nhid, d, nfactor=K, beta=0.7, t=1)
+    gpu.load_state_dict(sd)
+    gpu = gpu.to(DEV)
+    res_gpu = run_link_prediction(gpu, torch.from_numpy(x).to(DEV), prepare_run(split, DEV), epochs=12, lr=1e-3)
+    assert abs(res_gpu.losses[0] - res_cpu.losses[0]) <= 1e-5 * abs(res_cpu.losses[0])
+    assert abs(res_gpu.val_aucs[0] - res_cpu.val_aucs[0]) <= 1e-4            # fixed weights: the hard gate
+    for lg, lc in zip(res_gpu.losses[:4], res_cpu.losses[:4]):
+        assert abs(lg - lc) <= 1e-3 * abs(lc)
+    assert abs(res_gpu.val_aucs[-1] - res_cpu.val_aucs[-1]) <= 5e-3
+    assert abs(res_gpu.test_auc - res_cpu.test_auc) <= 5e-3
+    assert res_gpu.losses[-1] < res_gpu.losses[0]

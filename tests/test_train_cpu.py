@@ -1,0 +1,116 @@
+"""Caller-side pieces on CPU: on-device AUC vs the sklearn golden vectors, pair-list loss vs the
+dense masked loss of the reference, the split builder's contract, and the train loop's schedule
+(run here with an oracle-backed module standing in for the HIP module)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN_DIR, golden_case_names, load_golden
+from oracle import dense_ref, metrics_ref
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN_DIR, "auc_*.npz"))))
+def test_device_auc_matches_sklearn_vectors(path):
+    from disenlink_amd.metrics import auc_tie_avg
+    g = np.load(path)
+    got = float(auc_tie_avg(torch.from_numpy(g["y"]), torch.from_numpy(g["score"])))
+    assert abs(got - float(g["auc"])) < 1e-12
+    assert abs(got - metrics_ref.auc_tie_avg(g["y"], g["score"])) < 1e-12
+    with pytest.raises(ValueError):
+        auc_tie_avg(torch.ones(4), torch.rand(4))
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_pair_loss_equals_the_references_masked_loss(name):
+    from disenlink_amd.metrics import pair_bce_loss
+    g = load_golden(name)
+    P = torch.from_numpy(g["link_pred"])
+    pu, pv = np.nonzero(g["pos_mask"])
+    nu, nv = np.nonzero(g["neg_mask"])
+    ori = g["ori_adj"]
+    loss = pair_bce_loss(P[pu, pv], torch.from_numpy(ori[pu, pv]), P[nu, nv], torch.from_numpy(ori[nu, nv]),
+                         g["meta"]["m"])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * max(1.0, abs(float(g["loss"])))
+
+
+def test_split_builder_contract():
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.splits import make_link_split
+    sg = synthetic_graph("chameleon", seed=1, scale=0.2)
+    N, E = sg.n_nodes, sg.src.size
+    sp = make_link_split(sg.src, sg.dst, N, m=3, seed=5)
+    n_tr = int(0.85 * E)
+    assert sp.train_src.size == n_tr                                     # 85 % of the edge ROWS
+    keys = set((sg.src * N + sg.dst).tolist())
+    for ps, want in ((sp.pos_train, 1.0), (sp.neg_train, 0.0)):
+        k = ps.u * N + ps.v
+        assert np.unique(k).size == k.size and (np.diff(k) > 0).all()    # unique, row-major order
+        assert (ps.label == want).all()
+        assert all(((int(x) in keys) == bool(want)) for x in k.tolist())
+    assert sp.neg_train.u.size <= 3 * n_tr and sp.neg_train.u.size > 2.5 * n_tr
+    # every negative shares its source with a positive edge row
+    assert set(sp.neg_train.u.tolist()) <= set(sg.src.tolist())
+    # val / test: positives and negatives together, labels from the directed edge rows
+    for ps in (sp.val, sp.test):
+        k = ps.u * N + ps.v
+        assert np.array_equal(ps.label, np.array([float(int(x) in keys) for x in k.tolist()], np.float32))
+        assert 0 < ps.label.mean() < 0.5
+    sp2 = make_link_split(sg.src, sg.dst, N, m=3, seed=5)
+    assert np.array_equal(sp.test.u, sp2.test.u) and np.array_equal(sp.neg_train.v, sp2.neg_train.v)
+
+
+class OraclePairModule(nn.Module):
+    """TEST stand-in with the drop-in module's parameters, computing through oracle/dense_ref on CPU."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward_pairs(self, x, graph, pairs):
+        N = graph.n_nodes
+        adj = torch.zeros(N, N)
+        src = torch.repeat_interleave(torch.arange(N), (graph.rowptr[1:] - graph.rowptr[:-1]).long())
+        adj[src, graph.col.long()] = 1
+        sd = dict(self.inner.named_parameters())
+        emb, P = dense_ref.forward(x, adj, sd, self.inner.beta, self.inner.temperature)
+        return emb, P[pairs.pu.long(), pairs.pv.long()]
+
+    def state_dict(self, *a, **k):
+        return self.inner.state_dict(*a, **k)
+
+    def load_state_dict(self, sd, *a, **k):
+        return self.inner.load_state_dict(sd, *a, **k)
+
+
+def test_train_loop_schedule_on_cpu():
+    """Loss falls, validation AUC is taken from the pre-step forward, early stopping and best-weight
+    restore follow main_disentangled.py:191-224."""
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sg = synthetic_graph("chameleon", seed=2, scale=0.06)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=2, seed=0)
+    run = prepare_run(split, "cpu")
+    torch.manual_seed(0)
+    inner = Disentangle(16, 8, 8, nfactor=3, beta=0.7, t=1)
+    model = OraclePairModule(inner)
+    x = torch.from_numpy(sg.features()[:, :16].copy())
+    # epoch-0 validation AUC must equal the AUC of the untrained weights
+    with torch.no_grad():
+        _e, p0 = model.forward_pairs(x, run.graph, run.train_val_pairs)
+    from disenlink_amd.metrics import auc_tie_avg
+    auc0 = float(auc_tie_avg(run.label_val, p0[run.n_pos + run.n_neg:]))
+    res = run_link_prediction(model, x, run, epochs=25, lr=5e-3, patience=3)
+    assert abs(res.val_aucs[0] - auc0) < 1e-12
+    assert res.losses[-1] < res.losses[0]
+    assert res.epochs_run <= 25 and 0.0 <= res.test_auc <= 1.0
+    assert res.best_val_auc == max(res.val_aucs)
+    # patience: stops `patience`+1 epochs after the last improvement
+    last_best = int(np.argmax(res.val_aucs))
+    if res.epochs_run < 25:
+        assert res.epochs_run == last_best + 1 + 3 + 1
