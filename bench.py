@@ -140,7 +140,7 @@ def main():
     def step():
         p, a, s = ops.route_fwd(graph, Z, t)
         H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
         return p, a, s, H, prob
 
     for _ in range(args.warmup):
@@ -162,7 +162,7 @@ def main():
         ev[i][1].record()
         H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
         ev[i][2].record()
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
         ev[i][3].record()
     torch.cuda.synchronize()
     ktime = {n: float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(args.steps)])) * 1e-3

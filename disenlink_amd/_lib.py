@@ -16,7 +16,8 @@ class DlCsrPlan(C.Structure):
         ("n_rows", C.c_int32), ("row_offset", C.c_int32), ("n_total", C.c_int32), ("n_entries", C.c_int32),
         ("rowptr", C.c_void_p), ("col", C.c_void_p),
         ("seg_len", C.c_int32), ("n_seg", C.c_int32),
-        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("seg_slot", C.c_void_p),
+        ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("seg_end", C.c_void_p), ("seg_slot", C.c_void_p),
+        ("n_slices", C.c_int32), ("slice_max_seg", C.c_int32), ("slice_seg0", C.c_void_p),
         ("n_multi", C.c_int32), ("n_slots", C.c_int32), ("multi_row", C.c_void_p), ("multi_slot0", C.c_void_p),
     ]
 
@@ -41,7 +42,7 @@ EXPORTS = {
     "dl_workspace_bytes": (_z, [C.POINTER(DlCsrPlan), _i, _i]),
     "dl_route_fwd": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
     "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
-    "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _i, _P, _i, _P, _P]),
+    "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P]),
     "dl_score_pairs_bwd": (_i, [_P, _P, _i, _i, _f, _I, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_aggregate_bwd_phase2": (_i, [_G, _P, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _z, _P]),

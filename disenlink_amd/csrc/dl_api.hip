@@ -76,7 +76,8 @@ static int check_workspace(const dl_csr_plan* c, int K, int d, void* ws, size_t 
 }
 
 static bool has_seg_plan(const dl_csr_plan* c) {
-    return c->seg_len > 0 && c->n_seg > 0 && c->seg_row && c->seg_beg && c->seg_slot &&
+    return c->seg_len > 0 && c->n_seg > 0 && c->seg_row && c->seg_beg && c->seg_end && c->seg_slot &&
+           c->n_slices >= 1 && c->slice_seg0 && c->slice_max_seg > 0 &&
            (c->n_multi == 0 || (c->multi_row && c->multi_slot0));
 }
 
@@ -141,15 +142,20 @@ int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta
 }
 
 int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, const int32_t* pu,
-                       const int32_t* pv, int n_pairs, const int32_t* run_ptr, int n_runs, float* prob,
-                       void* stream) {
+                       const int32_t* pv, int n_pairs, const dl_pair_incidence* by_u, float* prob, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
-    DL_REQUIRE(N >= 0 && n_pairs >= 0 && n_runs >= 0, "negative size");
+    DL_REQUIRE(N >= 0 && n_pairs >= 0, "negative size");
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (n_pairs == 0) return DL_OK;
     DL_REQUIRE(Z && H && pu && pv && prob, "NULL argument");
-    if (!g_force_generic && fast_supported(K, d) && run_ptr && n_runs > 0)
-        return fast_score_pairs_fwd(Z, H, K, d, t, pu, pv, run_ptr, n_runs, prob, (hipStream_t)stream);
+    if (by_u) {
+        if (int rc = check_plan(&by_u->csr, "by_u")) return rc;
+        DL_REQUIRE(by_u->csr.n_entries == n_pairs && by_u->n_pairs == n_pairs && by_u->inc_pair,
+                   "by_u must list each of the %d pairs exactly once", n_pairs);
+        DL_REQUIRE(by_u->csr.n_total == N, "by_u.n_total=%d != N=%d", by_u->csr.n_total, N);
+        if (use_fast(&by_u->csr, K, d))
+            return fast_score_pairs_fwd(by_u, Z, H, K, d, t, prob, (hipStream_t)stream);
+    }
     return generic_score_pairs_fwd(Z, H, K, d, t, pu, pv, n_pairs, prob, (hipStream_t)stream);
 }
 

@@ -24,6 +24,10 @@ int check_launch(const char* what);
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = WAVES_PER_BLOCK * DL_WAVE;
 static inline unsigned wave_blocks(int n) { return (unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+// grid of a segment kernel: n_slices interleaved streams of workgroups, one per column slice
+static inline unsigned seg_blocks(const dl_csr_plan* c) {
+    return (unsigned)c->n_slices * wave_blocks(c->slice_max_seg);
+}
 
 // ---- device helpers ---------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (DL_WAVE - 1); }
@@ -76,9 +80,19 @@ __device__ __forceinline__ SegInfo load_seg(const dl_csr_plan& c, int seg) {
     s.row = c.seg_row[seg];
     s.grow = s.row + c.row_offset;
     s.beg = c.seg_beg[seg];
-    s.end = min(s.beg + c.seg_len, c.rowptr[s.row + 1]);
+    s.end = c.seg_end[seg];
     s.slot = c.seg_slot[seg];
     return s;
+}
+
+// Segment served by this wave, or -1.  Segments are stored slice-major and workgroup b serves column
+// slice b % n_slices: workgroups b and b+8 are observed to land on the same XCD, so with 8 slices an
+// XCD's L2 only gathers rows of one eighth of the node table.  Placement changes speed only.
+__device__ __forceinline__ int wave_segment(const dl_csr_plan& c) {
+    const int x = blockIdx.x % c.n_slices;
+    const int i = (blockIdx.x / c.n_slices) * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int seg = c.slice_seg0[x] + i;
+    return seg < c.slice_seg0[x + 1] ? seg : -1;
 }
 
 }  // namespace dl

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const f
                                                           float* __restrict__ s, float* __restrict__ s_part) {
     constexpr int G = D / 4;            // lanes per edge
     constexpr int EPW = DL_WAVE / G;    // edges per wave iteration
-    const int seg = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (seg >= g.n_seg) return;
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, con
                                                               float* __restrict__ h_part) {
     constexpr int G = D / 4;
     constexpr int EPW = DL_WAVE / G;
-    const int seg = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (seg >= g.n_seg) return;
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, co
                                                                float* __restrict__ ds, float* __restrict__ ds_part) {
     constexpr int G = D / 4;
     constexpr int EPW = DL_WAVE / G;
-    const int seg = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (seg >= g.n_seg) return;
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     float* __restrict__ dZ, int accumulate, float* __restrict__ dz_part) {
     constexpr int G = D / 4;
     constexpr int EPW = DL_WAVE / G;
-    const int seg = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (seg >= g.n_seg) return;
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
@@ -365,40 +365,37 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
 }
 
 // ---------------------------------------------------------------------------- pair scorer
-// One wave per run of pairs sharing u: the u rows of Z and H are staged once in LDS, every
-// lane group then scores one pair per iteration from the gathered v rows.
+// One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
+// in LDS, every lane group then scores one pair per iteration from the gathered v rows.
 template <int K, int D>
-__global__ __launch_bounds__(BLOCK) void score_runs_kernel(const float* __restrict__ Z, const float* __restrict__ H,
-                                                           float t, const int32_t* __restrict__ pu,
-                                                           const int32_t* __restrict__ pv,
-                                                           const int32_t* __restrict__ run_ptr, int n_runs,
-                                                           float* __restrict__ prob) {
+__global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
+                                                              const float* __restrict__ Z,
+                                                              const float* __restrict__ H, float t,
+                                                              float* __restrict__ prob) {
     constexpr int G = D / 4;
     constexpr int EPW = DL_WAVE / G;
     constexpr int RS = K * G;                       // float4 per node row
     __shared__ float4 urow[WAVES_PER_BLOCK][2 * RS];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int run = blockIdx.x * WAVES_PER_BLOCK + wave;
-    const bool active = run < n_runs;
+    const int seg = wave_segment(g);
+    const bool active = seg >= 0;
     const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
     const float4* __restrict__ H4 = reinterpret_cast<const float4*>(H);
-    int beg = 0, end = 0;
+    SegInfo si{0, 0, 0, 0, -1};
     if (active) {
-        beg = run_ptr[run];
-        end = run_ptr[run + 1];
-        const size_t u = (size_t)pu[beg];
+        si = load_seg(g, seg);
         for (int x = lane; x < RS; x += DL_WAVE) {
-            urow[wave][x] = Z4[u * RS + x];
-            urow[wave][RS + x] = H4[u * RS + x];
+            urow[wave][x] = Z4[(size_t)si.grow * RS + x];
+            urow[wave][RS + x] = H4[(size_t)si.grow * RS + x];
         }
     }
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
-    for (int base = beg; base < end; base += EPW) {
-        const int q = base + grp;
-        const bool live = q < end;
-        const size_t v = (size_t)(live ? pv[q] : pv[beg]);
+    for (int base = si.beg; base < si.end; base += EPW) {
+        const int it = base + grp;
+        const bool live = it < si.end;
+        const size_t v = (size_t)(live ? g.col[it] : si.grow);
         float4 zv[K], hv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -412,7 +409,7 @@ __global__ __launch_bounds__(BLOCK) void score_runs_kernel(const float* __restri
             const float ek = expf(group_allreduce_sum<G>(dot4(urow[wave][k * G + c], zv[k])) / t);
             logit += qk * ek;
         }
-        if (live && c == 0) prob[q] = sigmoid_ref(logit);
+        if (live && c == 0) prob[pair_id[it]] = sigmoid_ref(logit);
     }
 }
 
@@ -431,8 +428,8 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     constexpr int RS = K * G;
     __shared__ float4 urow[WAVES_PER_BLOCK][2 * RS];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int seg = blockIdx.x * WAVES_PER_BLOCK + wave;
-    const bool active = seg < g.n_seg;
+    const int seg = wave_segment(g);
+    const bool active = seg >= 0;
     const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
     const float4* __restrict__ H4 = reinterpret_cast<const float4*>(H);
     SegInfo si{0, 0, 0, 0, -1};
@@ -507,7 +504,7 @@ static void launch_vec_combine(const dl_csr_plan* g, int K, const float* part, i
 template <int K, int D>
 int route_fwd_t(const dl_csr_plan* g, const float* Z, float t, uint8_t* p, float* a, float* s, float* s_part,
                 hipStream_t st) {
-    hipLaunchKernelGGL((route_seg_kernel<K, D>), dim3(wave_blocks(g->n_seg)), dim3(BLOCK), 0, st, *g, Z, t, p, a, s,
+    hipLaunchKernelGGL((route_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, t, p, a, s,
                        s_part);
     launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
     return check_launch("route_fwd(fast)");
@@ -517,7 +514,7 @@ template <int K, int D>
 int aggregate_fwd_t(const dl_csr_plan* g, const float* Z, float beta, const uint8_t* p, const float* a,
                     const float* s, float* H, float* h_part, hipStream_t st) {
     constexpr int TOT4 = K * D / 4;
-    hipLaunchKernelGGL((aggregate_seg_kernel<K, D>), dim3(wave_blocks(g->n_seg)), dim3(BLOCK), 0, st, *g, Z, beta, p,
+    hipLaunchKernelGGL((aggregate_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, beta, p,
                        a, s, H, h_part);
     if (g->n_multi > 0)
         hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, TOT4, 0, Z,
@@ -528,7 +525,7 @@ int aggregate_fwd_t(const dl_csr_plan* g, const float* Z, float beta, const uint
 template <int K, int D>
 int bwd_phase1_t(const dl_csr_plan* g, const float* Z, float beta, const uint8_t* p, const float* a, const float* s,
                  const float* dH, float* dw, float* dwr, float* ds, float* ds_part, hipStream_t st) {
-    hipLaunchKernelGGL((bwd_phase1_seg_kernel<K, D>), dim3(wave_blocks(g->n_seg)), dim3(BLOCK), 0, st, *g, Z, dH, beta,
+    hipLaunchKernelGGL((bwd_phase1_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, dH, beta,
                        p, a, s, dw, dwr, ds, ds_part);
     launch_vec_combine(g, K, ds_part, 1, s, ds, st);
     return check_launch("route_aggregate_bwd_phase1(fast)");
@@ -539,7 +536,7 @@ int bwd_phase2_t(const dl_csr_plan* g, const float* Z, float beta, float t, cons
                  const float* s, const float* dH, const float* dw, const float* dwr, const float* ds, float* dZ,
                  int accumulate, float* dz_part, hipStream_t st) {
     constexpr int TOT4 = K * D / 4;
-    hipLaunchKernelGGL((bwd_phase2_seg_kernel<K, D>), dim3(wave_blocks(g->n_seg)), dim3(BLOCK), 0, st, *g, Z, dH, beta,
+    hipLaunchKernelGGL((bwd_phase2_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, dH, beta,
                        t, p, a, s, dw, dwr, ds, dZ, accumulate, dz_part);
     if (g->n_multi > 0)
         hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, dz_part, TOT4, 0, dH,
@@ -548,10 +545,10 @@ int bwd_phase2_t(const dl_csr_plan* g, const float* Z, float beta, float t, cons
 }
 
 template <int K, int D>
-int score_fwd_t(const float* Z, const float* H, float t, const int32_t* pu, const int32_t* pv,
-                const int32_t* run_ptr, int n_runs, float* prob, hipStream_t st) {
-    hipLaunchKernelGGL((score_runs_kernel<K, D>), dim3(wave_blocks(n_runs)), dim3(BLOCK), 0, st, Z, H, t, pu, pv,
-                       run_ptr, n_runs, prob);
+int score_fwd_t(const dl_pair_incidence* by_u, const float* Z, const float* H, float t, float* prob, hipStream_t st) {
+    const dl_csr_plan* g = &by_u->csr;
+    hipLaunchKernelGGL((score_fwd_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, by_u->inc_pair, Z, H,
+                       t, prob);
     return check_launch("score_pairs_fwd(fast)");
 }
 
@@ -560,7 +557,7 @@ int score_bwd_t(const dl_pair_incidence* inc, const float* Z, const float* H, fl
                 const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st) {
     constexpr int TOT4 = K * D / 4;
     const dl_csr_plan* g = &inc->csr;
-    hipLaunchKernelGGL((score_bwd_seg_kernel<K, D>), dim3(wave_blocks(g->n_seg)), dim3(BLOCK), 0, st, *g,
+    hipLaunchKernelGGL((score_bwd_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
                        inc->inc_pair, Z, H, t, prob, g_prob, dZ, dH, part);
     if (g->n_multi > 0) {
         // X is unused (cx = 0) but must be a valid row pointer: pass Z
@@ -623,9 +620,9 @@ int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float be
 #undef X
 }
 
-int fast_score_pairs_fwd(const float* Z, const float* H, int K, int d, float t, const int32_t* pu,
-                         const int32_t* pv, const int32_t* run_ptr, int n_runs, float* prob, hipStream_t st) {
-#define X(KK, DD) if (K == KK && d == DD) return fast::score_fwd_t<KK, DD>(Z, H, t, pu, pv, run_ptr, n_runs, prob, st);
+int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const float* Z, const float* H, int K, int d, float t,
+                         float* prob, hipStream_t st) {
+#define X(KK, DD) if (K == KK && d == DD) return fast::score_fwd_t<KK, DD>(by_u, Z, H, t, prob, st);
     DL_DISPATCH(X)
 #undef X
 }

@@ -33,8 +33,8 @@ int fast_bwd_phase1(const dl_csr_plan* g, const float* Z, int K, int d, float be
 int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
                     const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
                     const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
-int fast_score_pairs_fwd(const float* Z, const float* H, int K, int d, float t, const int32_t* pu,
-                         const int32_t* pv, const int32_t* run_ptr, int n_runs, float* prob, hipStream_t st);
+int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const float* Z, const float* H, int K, int d, float t,
+                         float* prob, hipStream_t st);
 int fast_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
                          const float* prob, const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st);
 

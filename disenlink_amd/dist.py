@@ -80,7 +80,7 @@ class HipBackend:
         self.ops.aggregate_fwd(g, Z, beta, p, a, s, H_out=H_out)
 
     def score_pairs_fwd(self, Z, H, pairs, t):
-        return self.ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        return self.ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
 
     def score_pairs_bwd(self, Z, H, inc, t, prob, g_prob, dZ_out, dH_out):
         self.ops.score_pairs_bwd(Z, H, inc, t, prob, g_prob, dZ_out=dZ_out, dH_out=dH_out)
@@ -90,6 +90,14 @@ class HipBackend:
 
     def bwd_phase2(self, g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ_out, accumulate):
         self.ops.route_aggregate_bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ_out, accumulate)
+
+
+def _incidence_only(pu, pv, n_nodes, seg_len, lo, hi) -> PairList:
+    """PairList over the WHOLE pair list whose incidence rows are this shard's nodes; its forward
+    plan is left empty (the forward scores a slice through another PairList)."""
+    full = PairList.build(pu, pv, n_nodes, seg_len=seg_len, row_range=(lo, hi), by_u_range=(0, n_nodes),
+                          build_by_u=False)
+    return full
 
 
 # --------------------------------------------------------------------------- shard description
@@ -126,8 +134,8 @@ class Shard:
         cuts = pair_slices(pu, n_nodes, world)
         q0, q1 = int(cuts[rank]), int(cuts[rank + 1])
         tpu, tpv = torch.as_tensor(pu, device=device), torch.as_tensor(pv, device=device)
-        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, seg_len=seg_len, row_range=(lo, lo))
-        inc = PairList.build(tpu, tpv, n_pad, seg_len=seg_len, row_range=(lo, hi))
+        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, seg_len=seg_len, row_range=(lo, lo), by_u_range=(lo, hi))
+        inc = _incidence_only(tpu, tpv, n_pad, seg_len, lo, hi)
         block = int(np.max(np.diff(cuts))) if pu.size else 0
         return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts)
 

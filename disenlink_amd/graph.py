@@ -20,6 +20,7 @@ from . import _lib
 
 DEFAULT_SEG_LEN = 32
 DEFAULT_RUN_LEN = 64
+DEFAULT_SLICES = 8          # XCDs of an MI355X
 
 
 def _i32(t: torch.Tensor) -> torch.Tensor:
@@ -28,7 +29,11 @@ def _i32(t: torch.Tensor) -> torch.Tensor:
 
 @dataclass
 class CsrPlan:
-    """Rows [row_offset, row_offset + n_rows) of a CSR over n_total nodes + its segment plan."""
+    """Rows [row_offset, row_offset + n_rows) of a CSR over n_total nodes + its segment plan.
+
+    ``n_slices > 1`` makes the plan XCD-aware: the column space is cut into ``n_slices`` equal node
+    ranges, no segment spans two ranges (needs ``col`` ascending inside each row) and segments are
+    stored slice-major (``slice_seg0``)."""
     n_rows: int
     row_offset: int
     n_total: int
@@ -37,8 +42,11 @@ class CsrPlan:
     seg_len: int
     seg_row: torch.Tensor
     seg_beg: torch.Tensor
+    seg_end: torch.Tensor
     seg_slot: torch.Tensor
-    row_seg0: torch.Tensor
+    n_slices: int
+    slice_max_seg: int
+    slice_seg0: torch.Tensor
     multi_row: torch.Tensor
     multi_slot0: torch.Tensor
     n_slots: int
@@ -57,42 +65,76 @@ class CsrPlan:
 
     @staticmethod
     def build(rowptr: torch.Tensor, col: torch.Tensor, n_total: int, row_offset: int = 0,
-              seg_len: int = DEFAULT_SEG_LEN) -> "CsrPlan":
-        if seg_len < 1:
-            raise ValueError("seg_len must be >= 1")
+              seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1) -> "CsrPlan":
+        if seg_len < 1 or n_slices < 1:
+            raise ValueError("seg_len and n_slices must be >= 1")
         rowptr = rowptr.to(torch.int64)
+        col = col.to(torch.int64)
         n_rows = int(rowptr.numel()) - 1
         if row_offset < 0 or row_offset + n_rows > n_total:
             raise ValueError("row block outside [0, n_total)")
         dev = rowptr.device
+        E = int(col.numel())
         deg = rowptr[1:] - rowptr[:-1]
-        nseg_row = torch.clamp((deg + seg_len - 1) // seg_len, min=1)
-        row_seg0 = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
-        row_seg0[1:] = torch.cumsum(nseg_row, dim=0)
-        seg_row = torch.repeat_interleave(torch.arange(n_rows, device=dev), nseg_row)
-        seg_idx = torch.arange(seg_row.numel(), device=dev) - row_seg0[seg_row]
-        seg_beg = rowptr[seg_row] + seg_idx * seg_len
+        ar = lambda n: torch.arange(n, device=dev)
+        # groups = maximal entry ranges with equal (row, column slice); entries are sorted by (row, col)
+        width = max(1, (n_total + n_slices - 1) // n_slices)
+        row_of = torch.repeat_interleave(ar(n_rows), deg)
+        gid = row_of * n_slices + (torch.div(col, width, rounding_mode="floor") if n_slices > 1 else 0)
+        if E and n_slices > 1 and bool((gid[1:] < gid[:-1]).any()):
+            raise ValueError("sliced plans need col ascending inside every row")
+        new = torch.ones(E, dtype=torch.bool, device=dev)
+        if E:
+            new[1:] = gid[1:] != gid[:-1]
+        gstart = torch.nonzero(new).reshape(-1)
+        gend = torch.cat([gstart[1:], torch.tensor([E], device=dev)]) if E else gstart
+        g_id = gid[gstart] if E else gstart
+        nch = (gend - gstart + seg_len - 1) // seg_len
+        ch0 = torch.cumsum(nch, 0) - nch
+        seg_g = torch.repeat_interleave(ar(gstart.numel()), nch)
+        seg_beg = gstart[seg_g] + (ar(seg_g.numel()) - ch0[seg_g]) * seg_len
+        seg_end = torch.minimum(seg_beg + seg_len, gend[seg_g])
+        seg_row = torch.div(g_id[seg_g], n_slices, rounding_mode="floor")
+        seg_slice = g_id[seg_g] - seg_row * n_slices
+        # empty rows still own one (empty) segment: their outputs must be written
+        empty = torch.nonzero(deg == 0).reshape(-1)
+        seg_row = torch.cat([seg_row, empty])
+        seg_beg = torch.cat([seg_beg, rowptr[empty]])
+        seg_end = torch.cat([seg_end, rowptr[empty]])
+        seg_slice = torch.cat([seg_slice, torch.zeros_like(empty)])
+        # row order: index of a segment inside its row -> partial slots of multi-segment rows
+        order = torch.argsort(seg_row * (E + 1) + seg_beg, stable=True)
+        seg_row, seg_beg, seg_end, seg_slice = seg_row[order], seg_beg[order], seg_end[order], seg_slice[order]
+        nseg_row = torch.bincount(seg_row, minlength=n_rows)
+        row_seg0 = torch.cumsum(nseg_row, 0) - nseg_row
+        idx_in_row = ar(seg_row.numel()) - row_seg0[seg_row]
         multi_row = torch.nonzero(nseg_row > 1).reshape(-1)
-        # partial-sum slots: only segments of multi-segment rows get one, numbered consecutively per row
         multi_slot0 = torch.zeros(multi_row.numel() + 1, dtype=torch.int64, device=dev)
         multi_slot0[1:] = torch.cumsum(nseg_row[multi_row], dim=0)
         row_slot0 = torch.full((n_rows,), -1, dtype=torch.int64, device=dev)
         row_slot0[multi_row] = multi_slot0[:-1]
         rs = row_slot0[seg_row]
-        seg_slot = torch.where(rs >= 0, rs + seg_idx, rs)
-        return CsrPlan(n_rows, row_offset, n_total, _i32(rowptr), _i32(col), seg_len, _i32(seg_row), _i32(seg_beg),
-                       _i32(seg_slot), _i32(row_seg0), _i32(multi_row), _i32(multi_slot0), int(multi_slot0[-1]))
+        seg_slot = torch.where(rs >= 0, rs + idx_in_row, rs)
+        # storage order: slice-major (stable, so row order is kept inside a slice)
+        perm = torch.argsort(seg_slice, stable=True)
+        slice_seg0 = torch.zeros(n_slices + 1, dtype=torch.int64, device=dev)
+        slice_seg0[1:] = torch.cumsum(torch.bincount(seg_slice, minlength=n_slices), 0)
+        return CsrPlan(n_rows, row_offset, n_total, _i32(rowptr), _i32(col), seg_len, _i32(seg_row[perm]),
+                       _i32(seg_beg[perm]), _i32(seg_end[perm]), _i32(seg_slot[perm]), n_slices,
+                       int((slice_seg0[1:] - slice_seg0[:-1]).max()), _i32(slice_seg0),
+                       _i32(multi_row), _i32(multi_slot0), int(multi_slot0[-1]))
 
     def to(self, device) -> "CsrPlan":
         mv = lambda t: t.to(device)
         return CsrPlan(self.n_rows, self.row_offset, self.n_total, mv(self.rowptr), mv(self.col), self.seg_len,
-                       mv(self.seg_row), mv(self.seg_beg), mv(self.seg_slot), mv(self.row_seg0), mv(self.multi_row),
-                       mv(self.multi_slot0), self.n_slots)
+                       mv(self.seg_row), mv(self.seg_beg), mv(self.seg_end), mv(self.seg_slot), self.n_slices,
+                       self.slice_max_seg, mv(self.slice_seg0), mv(self.multi_row), mv(self.multi_slot0), self.n_slots)
 
     def c_value(self) -> _lib.DlCsrPlan:
         return _lib.DlCsrPlan(
             self.n_rows, self.row_offset, self.n_total, self.n_entries, self.rowptr.data_ptr(), self.col.data_ptr(),
-            self.seg_len, self.n_seg, self.seg_row.data_ptr(), self.seg_beg.data_ptr(), self.seg_slot.data_ptr(),
+            self.seg_len, self.n_seg, self.seg_row.data_ptr(), self.seg_beg.data_ptr(), self.seg_end.data_ptr(),
+            self.seg_slot.data_ptr(), self.n_slices, self.slice_max_seg, self.slice_seg0.data_ptr(),
             int(self.multi_row.numel()), self.n_slots, self.multi_row.data_ptr(), self.multi_slot0.data_ptr())
 
 
@@ -177,30 +219,32 @@ class Graph:
 
 @dataclass
 class PairList:
-    """Scored pairs ``(pu[q], pv[q])``, the runs of equal ``pu`` the forward scorer stages in LDS, and
-    the node-incidence plan the backward walks (rows = nodes ``[row_offset, row_offset+n_rows)``)."""
+    """Scored pairs ``(pu[q], pv[q])`` with the two CSR views the kernels walk:
+    ``by_u`` — every pair once, in the row of its first endpoint (forward scorer), and
+    ``inc``  — every pair twice, once per endpoint (backward; rows = nodes ``[row_offset, +n_rows)``).
+    Both are XCD-sliced by the second endpoint by default."""
     n_nodes: int
     pu: torch.Tensor
     pv: torch.Tensor
-    run_ptr: torch.Tensor
+    by_u: CsrPlan
+    by_u_pair: torch.Tensor
     inc: CsrPlan
     inc_pair: torch.Tensor
     _struct: _lib.DlPairIncidence | None = field(default=None, repr=False)
+    _struct_u: _lib.DlPairIncidence | None = field(default=None, repr=False)
 
     @property
     def n_pairs(self) -> int:
         return int(self.pu.numel())
 
-    @property
-    def n_runs(self) -> int:
-        return int(self.run_ptr.numel()) - 1
-
     @staticmethod
     def build(pu: torch.Tensor, pv: torch.Tensor, n_nodes: int, seg_len: int = DEFAULT_SEG_LEN,
               run_len: int = DEFAULT_RUN_LEN, row_range: tuple[int, int] | None = None,
-              n_pairs_total: int | None = None) -> "PairList":
-        """``row_range`` restricts the incidence rows to one shard's nodes; the pair ids in ``inc_pair``
-        then index prob / g_prob arrays of length ``n_pairs_total`` (all shards' pairs)."""
+              n_slices: int = DEFAULT_SLICES, by_u_range: tuple[int, int] | None = None,
+              build_by_u: bool = True) -> "PairList":
+        """``row_range`` restricts the incidence rows to one shard's nodes (the pair ids in ``inc_pair``
+        then index prob / g_prob arrays covering the whole pair list); ``by_u_range`` restricts the rows
+        of the forward plan (every pu must lie inside it)."""
         pu = pu.reshape(-1).to(torch.int64)
         pv = pv.reshape(-1).to(torch.int64)
         if pu.numel() != pv.numel():
@@ -211,34 +255,39 @@ class PairList:
         if P and (int(torch.minimum(pu.min(), pv.min())) < 0 or int(torch.maximum(pu.max(), pv.max())) >= n_nodes):
             raise ValueError("pair endpoint outside [0, n_nodes)")
         dev = pu.device
-        # runs of consecutive pairs with equal pu, cut into chunks of <= run_len pairs
-        if P:
-            change = torch.ones(P, dtype=torch.bool, device=dev)
-            change[1:] = pu[1:] != pu[:-1]
-            start_of = torch.cummax(torch.where(change, torch.arange(P, device=dev), 0), dim=0).values
-            cut = change | (((torch.arange(P, device=dev) - start_of) % run_len) == 0)
-            run_ptr = torch.cat([torch.nonzero(cut).reshape(-1), torch.tensor([P], device=dev)])
-        else:
-            run_ptr = torch.zeros(1, dtype=torch.int64, device=dev)
-        # node-incidence CSR
+        ids = torch.arange(P, device=dev)
+
+        def csr(node, other, pair, lo, hi, seg):
+            keep = (node >= lo) & (node < hi)
+            node, other, pair = node[keep], other[keep], pair[keep]
+            order = torch.argsort((node - lo) * n_nodes + other, stable=True)   # fixed order -> reproducible sums
+            rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
+            if node.numel():
+                rowptr[1:] = torch.cumsum(torch.bincount(node - lo, minlength=hi - lo), dim=0)
+            plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=n_slices)
+            return plan, _i32(pair[order])
+
+        ulo, uhi = (0, n_nodes) if by_u_range is None else by_u_range
+        if P and build_by_u and (int(pu.min()) < ulo or int(pu.max()) >= uhi):
+            raise ValueError("a first endpoint lies outside by_u_range")
+        if build_by_u:
+            by_u, by_u_pair = csr(pu, pv, ids, ulo, uhi, run_len)
+        else:                                              # backward-only list (sharded runs): empty forward plan
+            by_u, by_u_pair = csr(pu[:0], pv[:0], ids[:0], 0, 0, run_len)
         lo, hi = (0, n_nodes) if row_range is None else row_range
-        node = torch.cat([pu, pv])
-        other = torch.cat([pv, pu])
-        pair = torch.arange(P, device=dev).repeat(2)
-        keep = (node >= lo) & (node < hi)
-        node, other, pair = node[keep], other[keep], pair[keep]
-        order = torch.sort(node, stable=True).indices     # fixed order -> bitwise reproducible sums
-        rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
-        if node.numel():
-            rowptr[1:] = torch.cumsum(torch.bincount(node - lo, minlength=hi - lo), dim=0)
-        inc = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg_len)
-        return PairList(n_nodes, _i32(pu), _i32(pv), _i32(run_ptr), inc, _i32(pair[order]))
+        inc, inc_pair = csr(torch.cat([pu, pv]), torch.cat([pv, pu]), ids.repeat(2), lo, hi, seg_len)
+        return PairList(n_nodes, _i32(pu), _i32(pv), by_u, by_u_pair, inc, inc_pair)
 
     def c_struct(self, n_pairs_total: int | None = None):
         if self._struct is None:
             self._struct = _lib.DlPairIncidence(self.inc.c_value(), self.inc_pair.data_ptr(),
                                                 self.n_pairs if n_pairs_total is None else n_pairs_total)
         return C.byref(self._struct)
+
+    def c_struct_by_u(self):
+        if self._struct_u is None:
+            self._struct_u = _lib.DlPairIncidence(self.by_u.c_value(), self.by_u_pair.data_ptr(), self.n_pairs)
+        return C.byref(self._struct_u)
 
     def c_plan(self):
         self.c_struct()

@@ -99,8 +99,9 @@ def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s, H_out: torch.
     return H
 
 
-def score_pairs_fwd(Z, H, pu, pv, t: float, run_ptr: torch.Tensor | None = None) -> torch.Tensor:
-    """-> prob f32[P].  model.py:109-113 at the listed pairs."""
+def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None) -> torch.Tensor:
+    """-> prob f32[P].  model.py:109-113 at the listed pairs.  ``pairs`` (the PairList the index arrays
+    belong to) enables the LDS-staged, XCD-sliced kernel; without it every pair is scored on its own."""
     lib = _lib.load()
     Z, H = _f32c(Z), _f32c(H)
     _need_cuda(Z, H, pu, pv)
@@ -111,9 +112,9 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, run_ptr: torch.Tensor | None = None)
         raise TypeError("pair indices must be int32")
     P = int(pu.numel())
     prob = torch.empty(P, dtype=torch.float32, device=Z.device)
-    rp, nr = (run_ptr.data_ptr(), int(run_ptr.numel()) - 1) if run_ptr is not None else (None, 0)
+    by_u = pairs.c_struct_by_u() if pairs is not None else None
     _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pu.data_ptr(), pv.data_ptr(),
-                                      P, rp, nr, prob.data_ptr(), _stream()), "dl_score_pairs_fwd")
+                                      P, by_u, prob.data_ptr(), _stream()), "dl_score_pairs_fwd")
     return prob
 
 
@@ -212,7 +213,7 @@ class ScorePairs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Z, H, pairs: PairList, t: float):
         Z, H = _f32c(Z), _f32c(H)
-        prob = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        prob = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
         ctx.pairs, ctx.t = pairs, t
         ctx.save_for_backward(Z, H, prob)
         return prob
@@ -224,6 +225,19 @@ class ScorePairs(torch.autograd.Function):
         return dZ, dH, None, None
 
 
+_all_pairs_cache: dict = {}
+
+
+def _all_pairs(N: int, device) -> PairList:
+    """Pair plan of the dense [N,N] output (row-major pair ids), cached per (N, device)."""
+    key = (N, str(device))
+    if key not in _all_pairs_cache:
+        idx = torch.arange(N, device=device)
+        _all_pairs_cache.clear()
+        _all_pairs_cache[key] = PairList.build(idx.repeat_interleave(N), idx.repeat(N), N, row_range=(0, 0))
+    return _all_pairs_cache[key]
+
+
 class ScoreAllPairs(torch.autograd.Function):
     """(Z, H) -> prob [N,N], the dense output the reference's caller indexes with masks
     (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero."""
@@ -232,15 +246,10 @@ class ScoreAllPairs(torch.autograd.Function):
     def forward(ctx, Z, H, t: float):
         Z, H = _f32c(Z), _f32c(H)
         N = Z.shape[0]
-        idx = torch.arange(N, device=Z.device, dtype=torch.int32)
-        pu = idx.repeat_interleave(N)
-        pv = idx.repeat(N)
-        if N * N >= 2 ** 31:
-            raise ValueError("dense [N,N] scoring needs N*N < 2^31; use forward_pairs for large graphs")
-        starts = torch.arange(0, N, 64, device=Z.device, dtype=torch.int32)        # runs of <= 64 pairs sharing u
-        run_ptr = torch.cat([(idx.unsqueeze(1) * N + starts.unsqueeze(0)).reshape(-1),
-                             torch.tensor([N * N], device=Z.device, dtype=torch.int32)])
-        prob = score_pairs_fwd(Z, H, pu, pv, t, run_ptr).view(N, N)
+        if N * N >= 2 ** 30:
+            raise ValueError("dense [N,N] scoring needs 2*N*N < 2^31; use forward_pairs for large graphs")
+        allp = _all_pairs(N, Z.device)
+        prob = score_pairs_fwd(Z, H, allp.pu, allp.pv, t, allp).view(N, N)
         ctx.t = t
         ctx.save_for_backward(Z, H, prob)
         return prob

@@ -44,7 +44,13 @@ extern "C" {
 
 /* A CSR over (a shard of) the nodes plus the segment plan that balances skewed rows: every row is
  * cut into >= 1 segments of <= seg_len consecutive entries; one wavefront owns one segment.  Rows
- * with several segments reduce through per-segment partial slots in the workspace. */
+ * with several segments reduce through per-segment partial slots in the workspace.
+ *
+ * XCD-aware slicing (optional, n_slices = 8 on MI355X): the column space is cut into n_slices
+ * equal node ranges and no segment spans two of them; segments are stored slice-major and
+ * workgroup b serves slice b % n_slices.  Workgroups b and b+8 are observed to share an XCD, so
+ * each XCD's 4 MiB L2 only ever gathers rows of "its" 1/8 of the node table.  Placement is a
+ * speed matter only: results do not depend on it. */
 typedef struct dl_csr_plan {
     int32_t n_rows;             /* rows of this plan */
     int32_t row_offset;         /* global node id of row 0 */
@@ -56,7 +62,11 @@ typedef struct dl_csr_plan {
     int32_t n_seg;
     const int32_t* seg_row;     /* [n_seg] local row of the segment */
     const int32_t* seg_beg;     /* [n_seg] first entry of the segment */
+    const int32_t* seg_end;     /* [n_seg] one past its last entry */
     const int32_t* seg_slot;    /* [n_seg] partial slot, -1 if the row has a single segment */
+    int32_t n_slices;           /* >= 1 */
+    int32_t slice_max_seg;      /* largest number of segments in one slice (sizes the launch grid) */
+    const int32_t* slice_seg0;  /* [n_slices+1] first segment of each column slice */
     int32_t n_multi;            /* rows with more than one segment */
     int32_t n_slots;            /* segments belonging to such rows */
     const int32_t* multi_row;   /* [n_multi] local row */
@@ -69,8 +79,10 @@ typedef struct dl_graph {
     dl_csr_plan csr;
 } dl_graph;
 
-/* Node-incidence list of a scored pair list: row u lists, for every pair slot u occupies, the
- * other endpoint (csr.col) and the pair id (inc_pair); a pair (u,u) appears twice. */
+/* A CSR over pair slots: row u lists other endpoints (csr.col) and pair ids (inc_pair).
+ *   - as the backward's node-incidence list, every pair occupies two slots (one per endpoint;
+ *     a pair (u,u) appears twice in row u);
+ *   - as the forward's "pairs by first endpoint" list, every pair occupies one slot in row pu. */
 typedef struct dl_pair_incidence {
     dl_csr_plan csr;
     const int32_t* inc_pair;    /* [csr.n_entries] */
@@ -105,11 +117,12 @@ int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta
 
 /* Pair-list link scorer: replaces model.py:109-113 evaluated at the listed (u,v) only.
  *   prob[q] = sigmoid( sum_k (h_k[u].h_k[v]) * exp(z_k[u].z_k[v] / t) )    (raw exp, not softmax)
- * run_ptr (optional, may be NULL): [n_runs+1] boundaries of consecutive pairs that share pu (long
- * runs cut into chunks); lets a wavefront keep the u rows in LDS for the whole run. */
+ * by_u (optional, may be NULL): the same pairs as a CSR by first endpoint (each pair once, inc_pair =
+ * position in pu/pv/prob); lets a wavefront keep the u rows in LDS for a whole segment and, when
+ * sliced, keeps the gathered v rows inside one XCD's L2. */
 int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t,
                        const int32_t* pu, const int32_t* pv, int n_pairs,
-                       const int32_t* run_ptr, int n_runs,
+                       const dl_pair_incidence* by_u,
                        float* prob, void* stream);
 
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at

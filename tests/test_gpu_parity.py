@@ -165,17 +165,14 @@ def test_forward_and_backward_match_oracle_on_random_graphs(K, d, N, deg, force_
         pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
         pu[:5] = pv[:5]
         pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N)
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)            # LDS-staged, XCD-sliced plan
         prob_o = sparse_ref.score_pairs(Zh, H_o, pu, pv, t)
         np.testing.assert_allclose(prob.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
-        # pairs sorted by u give long runs (the LDS-staged path); no runs at all takes the per-pair path
-        order = np.argsort(pu, kind="stable")
-        spairs = PairList.build(torch.from_numpy(pu[order]).to(DEV), torch.from_numpy(pv[order]).to(DEV), N)
-        assert spairs.n_runs < pairs.n_runs
-        prob_s = ops.score_pairs_fwd(Z, H, spairs.pu, spairs.pv, t, spairs.run_ptr)
-        np.testing.assert_allclose(prob_s.cpu().numpy(), prob_o[order], rtol=1e-5, atol=1e-5)
-        prob_n = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, None)
+        prob_n = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, None)             # per-pair kernel, no plan
         np.testing.assert_allclose(prob_n.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
+        unsliced = PairList.build(pairs.pu, pairs.pv, N, n_slices=1, run_len=16)
+        prob_u = ops.score_pairs_fwd(Z, H, unsliced.pu, unsliced.pv, t, unsliced)
+        np.testing.assert_allclose(prob_u.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
         # backward
         gp = (rng.standard_normal(P) * 0.1).astype(np.float32)
         dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, torch.from_numpy(gp).to(DEV))
@@ -257,7 +254,7 @@ def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic):
         pu, pv = np.sort(rng.integers(0, N, P)), rng.integers(0, N, P)
         tpu, tpv = torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV)
         pairs = PairList.build(tpu, tpv, N)
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs.run_ptr)
+        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
         gp = torch.from_numpy((rng.standard_normal(P) * 0.1).astype(np.float32)).to(DEV)
         dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp)
         dZ = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH, dZ_accum=dZs.clone())

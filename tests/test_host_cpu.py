@@ -57,26 +57,41 @@ def test_ops_fail_loudly_on_cpu_tensors():
 
 
 def _check_plan(plan, rowptr, seg_len):
-    """segment plan: every row covered exactly once, in order, by segments of <= seg_len entries;
-    multi-segment rows own consecutive partial slots"""
+    """segment plan: every row covered exactly once, in order, by segments of <= seg_len entries that
+    never span two column slices; multi-segment rows own consecutive partial slots in entry order;
+    segments are stored slice-major"""
     deg = np.diff(rowptr)
-    seg_row, seg_beg, seg_slot = plan.seg_row.numpy(), plan.seg_beg.numpy(), plan.seg_slot.numpy()
-    row_seg0 = plan.row_seg0.numpy()
-    assert row_seg0[0] == 0 and row_seg0[-1] == plan.n_seg
+    col = plan.col.numpy()
+    seg_row, seg_beg, seg_end = plan.seg_row.numpy(), plan.seg_beg.numpy(), plan.seg_end.numpy()
+    seg_slot, sl0 = plan.seg_slot.numpy(), plan.slice_seg0.numpy()
+    width = max(1, -(-plan.n_total // plan.n_slices))
+    assert sl0[0] == 0 and sl0[-1] == plan.n_seg and plan.slice_max_seg == np.diff(sl0).max()
+    by_row = {i: [] for i in range(plan.n_rows)}
+    for x in range(plan.n_slices):
+        for sgi in range(sl0[x], sl0[x + 1]):
+            b, e = seg_beg[sgi], seg_end[sgi]
+            assert 0 <= e - b <= seg_len
+            if e > b and plan.n_slices > 1:
+                assert (col[b:e] // width == x).all()
+            by_row[seg_row[sgi]].append((b, e, seg_slot[sgi]))
+    multi = []
     for i in range(plan.n_rows):
-        segs = range(row_seg0[i], row_seg0[i + 1])
-        assert len(segs) == max(1, -(-deg[i] // seg_len))
-        assert all(seg_row[s] == i for s in segs)
-        assert [seg_beg[s] for s in segs] == [rowptr[i] + q * seg_len for q in range(len(segs))]
-    multi = np.flatnonzero(deg > seg_len)
-    assert np.array_equal(plan.multi_row.numpy(), multi)
+        segs = sorted(by_row[i])
+        assert len(segs) >= 1 and segs[0][0] == rowptr[i] and segs[-1][1] == rowptr[i + 1]
+        assert all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:]))          # contiguous cover
+        if plan.n_slices == 1:
+            assert len(segs) == max(1, -(-deg[i] // seg_len))
+        if len(segs) > 1:
+            multi.append(i)
+            slots = [sg[2] for sg in segs]
+            assert slots == list(range(slots[0], slots[0] + len(segs)))
+        else:
+            assert segs[0][2] == -1
+    assert np.array_equal(plan.multi_row.numpy(), np.array(multi, dtype=np.int32))
     slot0 = plan.multi_slot0.numpy()
     assert slot0[0] == 0 and slot0[-1] == plan.n_slots
     for m, i in enumerate(multi):
-        segs = list(range(row_seg0[i], row_seg0[i + 1]))
-        assert [seg_slot[s] for s in segs] == list(range(slot0[m], slot0[m + 1]))
-    single = np.setdiff1d(np.arange(plan.n_rows), multi)
-    assert all(seg_slot[row_seg0[i]] == -1 for i in single)
+        assert sorted(by_row[i])[0][2] == slot0[m] and slot0[m + 1] - slot0[m] == len(by_row[i])
 
 
 @pytest.mark.parametrize("name", golden_case_names())
@@ -99,6 +114,9 @@ def test_graph_builder_matches_oracle_csr(name):
         assert np.array_equal(S.rowptr.numpy(), rowptr[lo:hi + 1] - rowptr[lo])
         assert np.array_equal(S.col.numpy(), col[rowptr[lo]:rowptr[hi]])
         _check_plan(S.plan, S.rowptr.numpy(), seg_len)
+        from disenlink_amd.graph import CsrPlan
+        sliced = CsrPlan.build(G.rowptr, G.col, G.n_nodes, seg_len=seg_len, n_slices=8)
+        _check_plan(sliced, rowptr, seg_len)
 
 
 def test_graph_from_edge_rows_symmetrises_and_collapses_duplicates():
@@ -127,29 +145,34 @@ def test_pair_incidence_lists_every_slot_once():
     n, P = 11, 60
     pu, pv = rng.integers(0, n, P), rng.integers(0, n, P)
     pu[:3] = pv[:3]                                   # self pairs
-    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, run_len=4)
+    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=4, run_len=4)
     ptr, other, pair = pl.inc.rowptr.numpy(), pl.inc.col.numpy(), pl.inc_pair.numpy()
-    # runs: consecutive pairs sharing pu, at most run_len long, covering the list exactly
-    rp = pl.run_ptr.numpy()
-    assert rp[0] == 0 and rp[-1] == P and (np.diff(rp) > 0).all() and (np.diff(rp) <= 4).all()
-    for b, e in zip(rp[:-1], rp[1:]):
-        assert (pu[b:e] == pu[b]).all()
-    sorted_pl = PairList.build(torch.from_numpy(np.sort(pu)), torch.from_numpy(pv), n, run_len=4)
-    assert sorted_pl.n_runs < pl.n_runs
-    # a shard lists only its own nodes' slots
-    sh = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, row_range=(3, 8))
-    assert sh.inc.n_rows == 5 and sh.inc.row_offset == 3
-    assert np.array_equal(sh.inc.rowptr.numpy(), ptr[3:9] - ptr[3])
-    assert np.array_equal(sh.inc.col.numpy(), other[ptr[3]:ptr[8]])
     assert ptr[-1] == 2 * P
     seen = np.zeros(P, int)
     for u in range(n):
         ids = pair[ptr[u]:ptr[u + 1]]
         oth = other[ptr[u]:ptr[u + 1]]
+        assert (np.diff(oth) >= 0).all()                                  # sorted by the other endpoint
         for q, o in zip(ids, oth):
             assert (pu[q] == u and pv[q] == o) or (pv[q] == u and pu[q] == o)
             seen[q] += 1
     assert (seen == 2).all()
+    _check_plan(pl.inc, ptr, 4)
+    # forward plan: every pair exactly once, in the row of its first endpoint
+    uptr, ucol, uid = pl.by_u.rowptr.numpy(), pl.by_u.col.numpy(), pl.by_u_pair.numpy()
+    assert uptr[-1] == P and sorted(uid.tolist()) == list(range(P))
+    for u in range(n):
+        for q, v in zip(uid[uptr[u]:uptr[u + 1]], ucol[uptr[u]:uptr[u + 1]]):
+            assert pu[q] == u and pv[q] == v
+    _check_plan(pl.by_u, uptr, 4)
+    assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 8
+    # a shard lists only its own nodes' slots
+    sh = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, row_range=(3, 8))
+    assert sh.inc.n_rows == 5 and sh.inc.row_offset == 3
+    assert np.array_equal(sh.inc.rowptr.numpy(), ptr[3:9] - ptr[3])
+    assert np.array_equal(sh.inc.col.numpy(), other[ptr[3]:ptr[8]])
+    with pytest.raises(ValueError, match="by_u_range"):
+        PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, by_u_range=(0, 3))
 
 
 @pytest.mark.parametrize("name", golden_case_names())
