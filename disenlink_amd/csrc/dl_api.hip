@@ -76,7 +76,7 @@ static int check_workspace(const dl_csr_plan* c, int K, int d, void* ws, size_t 
 }
 
 static bool has_seg_plan(const dl_csr_plan* c) {
-    return c->seg_len > 0 && c->n_seg > 0 && c->seg_row && c->seg_beg && c->seg_end && c->seg_slot &&
+    return c->seg_len > 0 && c->seg_len <= DL_WAVE && c->n_seg > 0 && c->seg_row && c->seg_beg && c->seg_end && c->seg_slot &&
            c->n_slices >= 1 && c->slice_seg0 && c->slice_max_seg > 0 &&
            (c->n_multi == 0 || (c->multi_row && c->multi_slot0));
 }

@@ -63,39 +63,56 @@ __global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const f
     const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
     const size_t rs = (size_t)K * G;    // float4 per node row
 
+    using FL = FactorLanes<G, K>;
+    constexpr int KP = FL::KP, VPL = FL::VPL;
+    const int kb = FL::factor_base(c);
+    const bool prim = FL::primary(c);
+
     float4 zi[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) zi[k] = Z4[(size_t)si.grow * rs + k * G + c];
-    float sacc[K];
+    float sacc[VPL];
 #pragma unroll
-    for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+    for (int i = 0; i < VPL; ++i) sacc[i] = 0.0f;
 
+    // lane l pre-loads entry l of the segment (seg_len <= 64): one coalesced load instead of a
+    // dependent load per iteration; groups pick their entry up with a shuffle.
+    const int my_col = (si.beg + lane < si.end) ? g.col[si.beg + lane] : si.grow;
     for (int base = si.beg; base < si.end; base += EPW) {
         const int e = base + grp;
         const bool live = e < si.end;
-        const int j = live ? g.col[e] : si.grow;
-        float4 zj[K];
+        const int j = __shfl(my_col, e - si.beg, DL_WAVE);
+        float part[KP];
 #pragma unroll
-        for (int k = 0; k < K; ++k) zj[k] = Z4[(size_t)j * rs + k * G + c];
-        float ex[K];
-        const float S = edge_exps<K, G>(zi, zj, t, ex);
-        float best = ex[0] / S;
-        int win = 0;
+        for (int k = 0; k < KP; ++k) part[k] = k < K ? dot4(zi[k < K ? k : 0], Z4[(size_t)j * rs + (k < K ? k : 0) * G + c]) : 0.0f;
+        TransposedReduce<KP, G / 2>::run(part, c);         // this lane now owns factors kb .. kb+VPL-1
+        float ex[VPL];
+        float mine = 0.0f;
 #pragma unroll
-        for (int k = 1; k < K; ++k) {
-            const float al = ex[k] / S;
-            if (beats(al, best)) { best = al; win = k; }
+        for (int i = 0; i < VPL; ++i) {
+            ex[i] = expf(div_t(part[i], t));
+            if (prim && kb + i < K) mine += ex[i];
         }
+        const float S = group_allreduce_sum<G>(mine);
+        float best = 0.0f;
+        int win = 255;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float al = ex[i] / S;
+            if (kb + i < K && (win == 255 || beats(al, best))) { best = al; win = kb + i; }
+        }
+        group_argmax_first<G>(best, win);
         if (live && c == 0) { p[e] = (uint8_t)win; a[e] = best; }
 #pragma unroll
-        for (int k = 0; k < K; ++k) sacc[k] += (live && win == k) ? best : 0.0f;
+        for (int i = 0; i < VPL; ++i) sacc[i] += (live && prim && win == kb + i) ? best : 0.0f;
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) sacc[k] = across_groups_sum<G>(sacc[k]);
-    if (lane == 0) {
+    for (int i = 0; i < VPL; ++i) sacc[i] = across_groups_sum<G>(sacc[i]);
+    if (grp == 0 && prim) {
         float* dst = si.slot < 0 ? s + (size_t)si.grow * K : s_part + (size_t)si.slot * K;
 #pragma unroll
-        for (int k = 0; k < K; ++k) dst[k] = sacc[k];
+        for (int i = 0; i < VPL; ++i)
+            if (kb + i < K) dst[kb + i] = sacc[i];
     }
 }
 
@@ -142,12 +159,19 @@ __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, con
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = zero4();
 
+    // per-entry scalars are computed once by the entry's own lane, then shuffled to its group
+    int my_col = si.grow, my_k = 0;
+    float my_w = 0.0f;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        my_k = p[si.beg + lane];
+        my_w = a[si.beg + lane] / one_if_zero(s[(size_t)my_col * K + my_k]);
+    }
     for (int base = si.beg; base < si.end; base += EPW) {
-        const int e = base + grp;
-        const bool live = e < si.end;
-        const int j = live ? g.col[e] : si.grow;
-        const int k = live ? (int)p[e] : 0;
-        const float w = live ? a[e] / one_if_zero(s[(size_t)j * K + k]) : 0.0f;
+        const int idx = base + grp - si.beg;
+        const int j = __shfl(my_col, idx, DL_WAVE);
+        const int k = __shfl(my_k, idx, DL_WAVE);
+        const float w = __shfl(my_w, idx, DL_WAVE);
         const float4 v = Z4[(size_t)j * rs + k * G + c];
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) fma4(acc[kk], (kk == k) ? w : 0.0f, v);
@@ -257,16 +281,24 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, co
     float acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+    int my_col = si.grow, my_k = 0;
+    float my_a = 0.0f;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        my_k = p[si.beg + lane];
+        my_a = a[si.beg + lane];
+    }
     for (int base = si.beg; base < si.end; base += EPW) {
         const int e = base + grp;
         const bool live = e < si.end;
-        const int j = live ? g.col[e] : si.grow;
-        const int k = live ? (int)p[e] : 0;
+        const int j = __shfl(my_col, e - si.beg, DL_WAVE);
+        const int k = __shfl(my_k, e - si.beg, DL_WAVE);
+        const float ae = __shfl(my_a, e - si.beg, DL_WAVE);
         const size_t oi = (size_t)si.grow * rs + k * G + c, oj = (size_t)j * rs + k * G + c;
         const float v = omb * group_allreduce_sum<G>(dot4(D4[oi], Z4[oj]));
         const float vr = omb * group_allreduce_sum<G>(dot4(D4[oj], Z4[oi]));
         if (live && c == 0) { dw[e] = v; dwr[e] = vr; }
-        const float contrib = live ? vr * a[e] : 0.0f;
+        const float contrib = live ? vr * ae : 0.0f;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) acc[kk] += (kk == k) ? contrib : 0.0f;
     }
@@ -311,27 +343,35 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
         zi[k] = Z4[(size_t)si.grow * rs + k * G + c];
         acc[k] = zero4();
     }
+    // per-entry scalars (routing factor, softmax-gradient scale cc, aggregation weight w2) are
+    // computed once by the entry's own lane and shuffled to its group inside the loop
+    int my_col = si.grow, my_k = 0;
+    float my_cc = 0.0f, my_w2 = 0.0f;
+    if (si.beg + lane < si.end) {
+        const int e = si.beg + lane;
+        my_col = g.col[e];
+        my_k = p[e];
+        const float ae = a[e];
+        const float s_i = one_if_zero(s[(size_t)si.grow * K + my_k]);
+        const float s_j = one_if_zero(s[(size_t)my_col * K + my_k]);
+        const float da = dw[e] / s_j + ds[(size_t)si.grow * K + my_k];
+        const float dar = dwr[e] / s_i + ds[(size_t)my_col * K + my_k];
+        my_cc = (da + dar) * ae;
+        my_w2 = omb * ae / s_i;
+    }
     for (int base = si.beg; base < si.end; base += EPW) {
         const int e = base + grp;
         const bool live = e < si.end;
-        const int j = live ? g.col[e] : si.grow;
-        const int k = live ? (int)p[e] : 0;
+        const int j = __shfl(my_col, e - si.beg, DL_WAVE);
+        const int k = __shfl(my_k, e - si.beg, DL_WAVE);
+        const float cc = __shfl(my_cc, e - si.beg, DL_WAVE);
+        const float w2 = __shfl(my_w2, e - si.beg, DL_WAVE);
         float4 zj[K];
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) zj[kk] = Z4[(size_t)j * rs + kk * G + c];
         const float4 dhj = D4[(size_t)j * rs + k * G + c];
         float ex[K];
         const float S = edge_exps<K, G>(zi, zj, t, ex);
-        float cc = 0.0f, w2 = 0.0f;
-        if (live) {
-            const float ae = a[e];
-            const float s_i = one_if_zero(s[(size_t)si.grow * K + k]);
-            const float s_j = one_if_zero(s[(size_t)j * K + k]);
-            const float da = dw[e] / s_j + ds[(size_t)si.grow * K + k];
-            const float dar = dwr[e] / s_i + ds[(size_t)j * K + k];
-            cc = (da + dar) * ae;
-            w2 = omb * ae / s_i;
-        }
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             const bool hit = kk == k;
@@ -392,24 +432,39 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
+    int my_col = si.grow, my_pair = 0;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        my_pair = pair_id[si.beg + lane];
+    }
     for (int base = si.beg; base < si.end; base += EPW) {
         const int it = base + grp;
         const bool live = it < si.end;
-        const size_t v = (size_t)(live ? g.col[it] : si.grow);
+        const size_t v = (size_t)__shfl(my_col, it - si.beg, DL_WAVE);
+        const int q = __shfl(my_pair, it - si.beg, DL_WAVE);
         float4 zv[K], hv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             zv[k] = Z4[v * RS + k * G + c];
             hv[k] = H4[v * RS + k * G + c];
         }
-        float logit = 0.0f;
+        using FL = FactorLanes<G, K>;
+        constexpr int KP = FL::KP, VPL = FL::VPL;
+        float pq[KP], ps[KP];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float qk = group_allreduce_sum<G>(dot4(urow[wave][RS + k * G + c], hv[k]));
-            const float ek = expf(group_allreduce_sum<G>(dot4(urow[wave][k * G + c], zv[k])) / t);
-            logit += qk * ek;
+        for (int k = 0; k < KP; ++k) {
+            pq[k] = k < K ? dot4(urow[wave][RS + (k < K ? k : 0) * G + c], hv[k < K ? k : 0]) : 0.0f;
+            ps[k] = k < K ? dot4(urow[wave][(k < K ? k : 0) * G + c], zv[k < K ? k : 0]) : 0.0f;
         }
-        if (live && c == 0) prob[pair_id[it]] = sigmoid_ref(logit);
+        TransposedReduce<KP, G / 2>::run(pq, c);
+        TransposedReduce<KP, G / 2>::run(ps, c);
+        const int kb = FL::factor_base(c);
+        float term = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            if (FL::primary(c) && kb + i < K) term += pq[i] * expf(div_t(ps[i], t));
+        const float logit = group_allreduce_sum<G>(term);
+        if (live && c == 0) prob[q] = sigmoid_ref(logit);
     }
 }
 
@@ -446,16 +501,19 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     float4 accZ[K], accH[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { accZ[k] = zero4(); accH[k] = zero4(); }
+    int my_col = si.grow;
+    float my_gl = 0.0f;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        const int q = inc_pair[si.beg + lane];
+        const float pr = prob[q];
+        my_gl = g_prob[q] * pr * (1.0f - pr);           // sigmoid backward p(1-p)
+    }
     for (int base = si.beg; base < si.end; base += EPW) {
         const int it = base + grp;
         const bool live = it < si.end;
-        const size_t v = (size_t)(live ? g.col[it] : si.grow);
-        float gl = 0.0f;
-        if (live) {
-            const int q = inc_pair[it];
-            const float pr = prob[q];
-            gl = g_prob[q] * pr * (1.0f - pr);          // sigmoid backward p(1-p)
-        }
+        const size_t v = (size_t)__shfl(my_col, it - si.beg, DL_WAVE);
+        const float gl = __shfl(my_gl, it - si.beg, DL_WAVE);
         float4 zv[K], hv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
