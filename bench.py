@@ -178,8 +178,10 @@ def main():
     # extra: forward+backward of the same path (what one training epoch adds on top), not the headline
     gp = torch.full((P,), 1.0 / P, device=device)
     def train_step():
-        p, a, s, H, prob = step()
-        dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp)
+        p, a, s = ops.route_fwd(graph, Z, t)
+        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+        prob, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+        dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp, coef=coef)
         return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
     for _ in range(3):
         train_step()

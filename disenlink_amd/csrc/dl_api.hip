@@ -97,7 +97,7 @@ int dl_has_fast_path(int K, int d) { return fast_supported(K, d) ? 1 : 0; }
 
 int dl_set_force_generic(int on) {
     int old = g_force_generic;
-    g_force_generic = on ? 1 : 0;
+    if (on >= 0) g_force_generic = on ? 1 : 0;
     return old;
 }
 
@@ -142,7 +142,8 @@ int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta
 }
 
 int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, const int32_t* pu,
-                       const int32_t* pv, int n_pairs, const dl_pair_incidence* by_u, float* prob, void* stream) {
+                       const int32_t* pv, int n_pairs, const dl_pair_incidence* by_u, float* prob, float* coef,
+                       void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(N >= 0 && n_pairs >= 0, "negative size");
     DL_REQUIRE(t != 0.0f, "temperature is 0");
@@ -154,14 +155,15 @@ int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, floa
                    "by_u must list each of the %d pairs exactly once", n_pairs);
         DL_REQUIRE(by_u->csr.n_total == N, "by_u.n_total=%d != N=%d", by_u->csr.n_total, N);
         if (use_fast(&by_u->csr, K, d))
-            return fast_score_pairs_fwd(by_u, Z, H, K, d, t, prob, (hipStream_t)stream);
+            return fast_score_pairs_fwd(by_u, Z, H, K, d, t, prob, coef, (hipStream_t)stream);
     }
+    DL_REQUIRE(coef == nullptr, "coef output needs the tuned scorer (a (K,d) with a fast path and a by_u plan)");
     return generic_score_pairs_fwd(Z, H, K, d, t, pu, pv, n_pairs, prob, (hipStream_t)stream);
 }
 
 int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t, const dl_pair_incidence* inc,
-                       const float* prob, const float* g_prob, float* dZ, float* dH, void* ws, size_t ws_bytes,
-                       void* stream) {
+                       const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH, void* ws,
+                       size_t ws_bytes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(inc != nullptr, "incidence is NULL");
     const dl_csr_plan* c = &inc->csr;
@@ -173,6 +175,9 @@ int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t, co
     if (use_fast(c, K, d)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+        if (coef)
+            return fast_score_pairs_bwd_coef(inc, Z, H, K, d, t, prob, g_prob, coef, dZ, dH, w.row_part,
+                                             (hipStream_t)stream);
         return fast_score_pairs_bwd(inc, Z, H, K, d, t, prob, g_prob, dZ, dH, w.row_part, (hipStream_t)stream);
     }
     return generic_score_pairs_bwd(inc, Z, H, K, d, t, prob, g_prob, dZ, dH, (hipStream_t)stream);

@@ -407,11 +407,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
 // ---------------------------------------------------------------------------- pair scorer
 // One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
 // in LDS, every lane group then scores one pair per iteration from the gathered v rows.
-template <int K, int D>
+template <int K, int D, bool COEF>
 __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
                                                               const float* __restrict__ Z,
                                                               const float* __restrict__ H, float t,
-                                                              float* __restrict__ prob) {
+                                                              float* __restrict__ prob, float* __restrict__ coef_e,
+                                                              float* __restrict__ coef_q) {
     constexpr int G = D / 4;
     constexpr int EPW = DL_WAVE / G;
     constexpr int RS = K * G;                       // float4 per node row
@@ -461,8 +462,17 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
         const int kb = FL::factor_base(c);
         float term = 0.0f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i)
-            if (FL::primary(c) && kb + i < K) term += pq[i] * expf(div_t(ps[i], t));
+        for (int i = 0; i < VPL; ++i) {
+            if (FL::primary(c) && kb + i < K) {
+                const float ek = expf(div_t(ps[i], t));
+                const float qe = pq[i] * ek;
+                term += qe;
+                if (COEF && live) {                             // per-factor logit terms for the backward
+                    coef_e[(size_t)q * K + kb + i] = ek;
+                    coef_q[(size_t)q * K + kb + i] = qe;
+                }
+            }
+        }
         const float logit = group_allreduce_sum<G>(term);
         if (live && c == 0) prob[q] = sigmoid_ref(logit);
     }
@@ -603,11 +613,102 @@ int bwd_phase2_t(const dl_csr_plan* g, const float* Z, float beta, float t, cons
 }
 
 template <int K, int D>
-int score_fwd_t(const dl_pair_incidence* by_u, const float* Z, const float* H, float t, float* prob, hipStream_t st) {
+int score_fwd_t(const dl_pair_incidence* by_u, const float* Z, const float* H, float t, float* prob, float* coef,
+                hipStream_t st) {
     const dl_csr_plan* g = &by_u->csr;
-    hipLaunchKernelGGL((score_fwd_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, by_u->inc_pair, Z, H,
-                       t, prob);
+    float* coef_q = coef ? coef + (size_t)by_u->n_pairs * K : nullptr;
+    if (coef)
+        hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
+                           by_u->inc_pair, Z, H, t, prob, coef, coef_q);
+    else
+        hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, false>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
+                           by_u->inc_pair, Z, H, t, prob, coef, coef_q);
     return check_launch("score_pairs_fwd(fast)");
+}
+
+// Scorer backward from stored per-factor terms: a weighted row gather, one launch per output.
+//   PASS 0: dZ[u] = sum_inc gl * (q_k e_k) / t * Z[v][k]      PASS 1: dH[u] = sum_inc gl * e_k * H[v][k]
+template <int K, int D, int PASS>
+__global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
+                                                                   const float* __restrict__ X, float t,
+                                                                   const float* __restrict__ prob,
+                                                                   const float* __restrict__ g_prob,
+                                                                   const float* __restrict__ coef,
+                                                                   float* __restrict__ out, float* __restrict__ part) {
+    constexpr int G = D / 4;
+    constexpr int EPW = DL_WAVE / G;
+    constexpr int RS = K * G;
+    constexpr int K4 = (K + 3) / 4;
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
+    const int lane = lane_id();
+    const int c = lane % G, grp = lane / G;
+    const SegInfo si = load_seg(g, seg);
+    const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X);
+    float4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = zero4();
+    int my_col = si.grow, my_pair = 0;
+    float my_gl = 0.0f;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        my_pair = inc_pair[si.beg + lane];
+        const float pr = prob[my_pair];
+        my_gl = g_prob[my_pair] * pr * (1.0f - pr);      // sigmoid backward p(1-p)
+        if (PASS == 0) my_gl = div_t(my_gl, t);          // NOTE: (gl/t)*qe instead of gl*qe/t (rounding-level)
+    }
+    for (int base = si.beg; base < si.end; base += EPW) {
+        const int idx = base + grp - si.beg;
+        const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
+        const int q = __shfl(my_pair, idx, DL_WAVE);
+        const float gl = __shfl(my_gl, idx, DL_WAVE);     // 0 for lanes past the segment end
+        float4 xv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[k] = X4[v * RS + k * G + c];
+        float ck[K4 * 4];
+        if constexpr (K % 4 == 0) {
+            const float4* __restrict__ C4 = reinterpret_cast<const float4*>(coef + (size_t)q * K);
+#pragma unroll
+            for (int i = 0; i < K4; ++i) {
+                const float4 t4 = C4[i];
+                ck[4 * i] = t4.x; ck[4 * i + 1] = t4.y; ck[4 * i + 2] = t4.z; ck[4 * i + 3] = t4.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) ck[k] = coef[(size_t)q * K + k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) fma4(acc[k], gl * ck[k], xv[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) across_groups_sum4<G>(acc[k]);
+    if (grp == 0) {
+        float4* __restrict__ O4 = reinterpret_cast<float4*>(si.slot < 0 ? out : part);
+        const size_t o = si.slot < 0 ? (size_t)si.grow * RS : (size_t)si.slot * RS;
+#pragma unroll
+        for (int k = 0; k < K; ++k) O4[o + k * G + c] = acc[k];
+    }
+}
+
+template <int K, int D>
+int score_bwd_coef_t(const dl_pair_incidence* inc, const float* Z, const float* H, float t, const float* prob,
+                     const float* g_prob, const float* coef, float* dZ, float* dH, float* part, hipStream_t st) {
+    constexpr int TOT4 = K * D / 4;
+    const dl_csr_plan* g = &inc->csr;
+    const float* coef_e = coef;
+    const float* coef_q = coef + (size_t)inc->n_pairs * K;
+    float* part_h = part + (size_t)g->n_slots * K * D;
+    hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, 0>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
+                       Z, t, prob, g_prob, coef_q, dZ, part);
+    hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, 1>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
+                       H, t, prob, g_prob, coef_e, dH, part_h);
+    if (g->n_multi > 0) {
+        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part, TOT4, 0, Z, 0.0f,
+                           1.0f, dZ, 0);
+        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part_h, TOT4, 0, Z,
+                           0.0f, 1.0f, dH, 0);
+    }
+    return check_launch("score_pairs_bwd(fast, stored terms)");
 }
 
 template <int K, int D>
@@ -679,8 +780,8 @@ int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float be
 }
 
 int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const float* Z, const float* H, int K, int d, float t,
-                         float* prob, hipStream_t st) {
-#define X(KK, DD) if (K == KK && d == DD) return fast::score_fwd_t<KK, DD>(by_u, Z, H, t, prob, st);
+                         float* prob, float* coef, hipStream_t st) {
+#define X(KK, DD) if (K == KK && d == DD) return fast::score_fwd_t<KK, DD>(by_u, Z, H, t, prob, coef, st);
     DL_DISPATCH(X)
 #undef X
 }
@@ -689,6 +790,15 @@ int fast_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const flo
                          const float* prob, const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st) {
 #define X(KK, DD) \
     if (K == KK && d == DD) return fast::score_bwd_t<KK, DD>(inc, Z, H, t, prob, g_prob, dZ, dH, part, st);
+    DL_DISPATCH(X)
+#undef X
+}
+
+int fast_score_pairs_bwd_coef(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
+                              const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
+                              float* part, hipStream_t st) {
+#define X(KK, DD) \
+    if (K == KK && d == DD) return fast::score_bwd_coef_t<KK, DD>(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
     DL_DISPATCH(X)
 #undef X
 }

@@ -34,7 +34,10 @@ int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float be
                     const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
                     const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
 int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const float* Z, const float* H, int K, int d, float t,
-                         float* prob, hipStream_t st);
+                         float* prob, float* coef, hipStream_t st);
+int fast_score_pairs_bwd_coef(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
+                              const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
+                              float* part, hipStream_t st);
 int fast_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
                          const float* prob, const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st);
 

@@ -99,7 +99,7 @@ def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s, H_out: torch.
     return H
 
 
-def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None) -> torch.Tensor:
+def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_coef: bool = False):
     """-> prob f32[P].  model.py:109-113 at the listed pairs.  ``pairs`` (the PairList the index arrays
     belong to) enables the LDS-staged, XCD-sliced kernel; without it every pair is scored on its own."""
     lib = _lib.load()
@@ -113,12 +113,17 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None) -> to
     P = int(pu.numel())
     prob = torch.empty(P, dtype=torch.float32, device=Z.device)
     by_u = pairs.c_struct_by_u() if pairs is not None else None
+    # per-factor logit terms for the backward: only the tuned scorer produces them
+    coef = None
+    if want_coef and pairs is not None and lib.dl_has_fast_path(K, d) and not lib.dl_set_force_generic(-1):
+        coef = torch.empty((2, P, K), dtype=torch.float32, device=Z.device)
     _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pu.data_ptr(), pv.data_ptr(),
-                                      P, by_u, prob.data_ptr(), _stream()), "dl_score_pairs_fwd")
-    return prob
+                                      P, by_u, prob.data_ptr(), coef.data_ptr() if coef is not None else None,
+                                      _stream()), "dl_score_pairs_fwd")
+    return (prob, coef) if want_coef else prob
 
 
-def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, dH_out=None):
+def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, dH_out=None, coef=None):
     """-> dZ, dH f32[N,K,d] (rows of the incidence plan are written)."""
     lib = _lib.load()
     Z, H, prob, g_prob = _f32c(Z), _f32c(H), _f32c(prob), _f32c(g_prob)
@@ -130,8 +135,11 @@ def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, 
     dH = torch.empty_like(Z) if dH_out is None else dH_out
     inc = pairs.c_struct(int(prob.numel()))
     ws = _workspace(pairs.c_plan(), Z.device, K, d)
+    if coef is not None and tuple(coef.shape) != (2, prob.numel(), K):
+        raise ValueError("coef must be the [2, P, K] array of score_pairs_fwd for the same pair list")
     _lib.check(lib.dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), K, d, float(t), inc, prob.data_ptr(),
-                                      g_prob.data_ptr(), dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      g_prob.data_ptr(), coef.data_ptr() if coef is not None else None,
+                                      dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(), ws.numel(),
                                       _stream()), "dl_score_pairs_bwd")
     return dZ, dH
 
@@ -213,15 +221,17 @@ class ScorePairs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Z, H, pairs: PairList, t: float):
         Z, H = _f32c(Z), _f32c(H)
-        prob = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
-        ctx.pairs, ctx.t = pairs, t
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        prob, coef = score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True) if need else \
+            (score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs), None)
+        ctx.pairs, ctx.t, ctx.coef = pairs, t, coef
         ctx.save_for_backward(Z, H, prob)
         return prob
 
     @staticmethod
     def backward(ctx, g_prob):
         Z, H, prob = ctx.saved_tensors
-        dZ, dH = score_pairs_bwd(Z, H, ctx.pairs, ctx.t, prob, g_prob.contiguous())
+        dZ, dH = score_pairs_bwd(Z, H, ctx.pairs, ctx.t, prob, g_prob.contiguous(), coef=ctx.coef)
         return dZ, dH, None, None
 
 

@@ -94,7 +94,8 @@ const char* dl_last_error(void);
 
 /* 1 if (K,d) runs on the tuned wavefront-tiled kernels, 0 if it falls back to the generic ones. */
 int dl_has_fast_path(int K, int d);
-/* Force the generic kernels (parity cross-check of the two implementations).  Returns old value. */
+/* Force the generic kernels (parity cross-check of the two implementations): 1 = on, 0 = off,
+ * negative = query only.  Returns the previous value. */
 int dl_set_force_generic(int on);
 
 /* Scratch needed by the calls below for this plan and shape. */
@@ -119,17 +120,22 @@ int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta
  *   prob[q] = sigmoid( sum_k (h_k[u].h_k[v]) * exp(z_k[u].z_k[v] / t) )    (raw exp, not softmax)
  * by_u (optional, may be NULL): the same pairs as a CSR by first endpoint (each pair once, inc_pair =
  * position in pu/pv/prob); lets a wavefront keep the u rows in LDS for a whole segment and, when
- * sliced, keeps the gathered v rows inside one XCD's L2. */
+ * sliced, keeps the gathered v rows inside one XCD's L2.
+ * coef (optional, may be NULL; training only): [2][n_pairs][K] — coef[0][q][k] = e_k = exp(z_k[u].z_k[v]/t)
+ * and coef[1][q][k] = (h_k[u].h_k[v]) * e_k, the per-factor terms of the logit.  Handing them to
+ * dl_score_pairs_bwd turns the backward into two plain weighted row gathers (no dot products). */
 int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t,
                        const int32_t* pu, const int32_t* pv, int n_pairs,
                        const dl_pair_incidence* by_u,
-                       float* prob, void* stream);
+                       float* prob, float* coef, void* stream);
 
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
- * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows. */
+ * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:
+ *   gl = g_prob * prob * (1 - prob);  dH[u] += gl e_k H[v][k];  dZ[u] += gl (q_k e_k)/t Z[v][k]
+ * coef: the array dl_score_pairs_fwd filled (n_pairs = inc->n_pairs), or NULL to recompute e and q. */
 int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t,
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob,
-                       float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream);
+                       const float* coef, float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of aggregate + normaliser + routing softmax (autograd of model.py:56-75; argmax and
  * masks carry no gradient), SURVEY.md Appendix A.3, split at its one global dependency:

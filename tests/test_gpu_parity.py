@@ -180,6 +180,18 @@ def test_forward_and_backward_match_oracle_on_random_graphs(K, d, N, deg, force_
         tol = lambda ref: 1e-4 * max(np.abs(ref).max(), 1e-6)
         assert np.abs(dH.cpu().numpy() - dH_o).max() <= tol(dH_o)
         assert np.abs(dZs.cpu().numpy() - dZs_o).max() <= tol(dZs_o)
+        # the stored-terms backward (tuned path only): per-factor logit terms from the forward
+        prob_c, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+        assert torch.equal(prob_c, prob)
+        if coef is not None:
+            _pr, q_o, e_o = sparse_ref.score_pairs(Zh, H_o, pu, pv, t, return_parts=True)
+            np.testing.assert_allclose(coef[0].cpu().numpy(), e_o, rtol=1e-5)
+            np.testing.assert_allclose(coef[1].cpu().numpy(), q_o * e_o, rtol=1e-4, atol=1e-5)
+            dZc, dHc = ops.score_pairs_bwd(Z, H, pairs, t, prob, torch.from_numpy(gp).to(DEV), coef=coef)
+            assert np.abs(dHc.cpu().numpy() - dH_o).max() <= tol(dH_o)
+            assert np.abs(dZc.cpu().numpy() - dZs_o).max() <= tol(dZs_o)
+        else:
+            assert force_generic or not _lib.load().dl_has_fast_path(K, d)
         dZ = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH)
         dZ_o = sparse_ref.route_aggregate_bwd(Zh, rowptr, col, rev, p_h, a_h, s_h, beta, t, dH_o)
         assert np.abs(dZ.cpu().numpy() - dZ_o).max() <= tol(dZ_o)
