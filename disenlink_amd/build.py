@@ -25,7 +25,7 @@ def _newest(paths):
 
 
 def _compile(src, obj, verbose):
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *os.environ.get("DL_CXXFLAGS", "").split(), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

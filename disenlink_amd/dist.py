@@ -92,11 +92,10 @@ class HipBackend:
         self.ops.route_aggregate_bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ_out, accumulate)
 
 
-def _incidence_only(pu, pv, n_nodes, seg_len, lo, hi) -> PairList:
+def _incidence_only(pu, pv, n_nodes, lo, hi) -> PairList:
     """PairList over the WHOLE pair list whose incidence rows are this shard's nodes; its forward
     plan is left empty (the forward scores a slice through another PairList)."""
-    full = PairList.build(pu, pv, n_nodes, seg_len=seg_len, row_range=(lo, hi), by_u_range=(0, n_nodes),
-                          build_by_u=False)
+    full = PairList.build(pu, pv, n_nodes, row_range=(lo, hi), by_u_range=(0, n_nodes), build_by_u=False)
     return full
 
 
@@ -134,8 +133,8 @@ class Shard:
         cuts = pair_slices(pu, n_nodes, world)
         q0, q1 = int(cuts[rank]), int(cuts[rank + 1])
         tpu, tpv = torch.as_tensor(pu, device=device), torch.as_tensor(pv, device=device)
-        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, seg_len=seg_len, row_range=(lo, lo), by_u_range=(lo, hi))
-        inc = _incidence_only(tpu, tpv, n_pad, seg_len, lo, hi)
+        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, row_range=(lo, lo), by_u_range=(lo, hi))
+        inc = _incidence_only(tpu, tpv, n_pad, lo, hi)
         block = int(np.max(np.diff(cuts))) if pu.size else 0
         return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts)
 

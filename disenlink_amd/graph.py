@@ -18,9 +18,17 @@ import torch
 
 from . import _lib
 
-DEFAULT_SEG_LEN = 32
-DEFAULT_RUN_LEN = 64
+DEFAULT_SEG_LEN = 32        # adjacency rows
+DEFAULT_INC_SEG_LEN = 64    # pair-incidence rows (backward of the scorer)
+DEFAULT_RUN_LEN = 64        # pairs-by-first-endpoint rows (forward scorer)
 DEFAULT_SLICES = 8          # XCDs of an MI355X
+L2_BYTES_PER_XCD = 4 << 20
+
+
+def auto_slices(n_nodes: int, row_bytes: int, n_tables: int = 2) -> int:
+    """XCD-aware slicing pays only while one slice of the gathered tables (Z and H rows of n_nodes/8
+    nodes) stays resident in an XCD's 4 MiB L2; beyond that it only multiplies the segment count."""
+    return DEFAULT_SLICES if n_nodes * row_bytes * n_tables <= 2 * DEFAULT_SLICES * L2_BYTES_PER_XCD else 1
 
 
 def _i32(t: torch.Tensor) -> torch.Tensor:
@@ -238,10 +246,10 @@ class PairList:
         return int(self.pu.numel())
 
     @staticmethod
-    def build(pu: torch.Tensor, pv: torch.Tensor, n_nodes: int, seg_len: int = DEFAULT_SEG_LEN,
+    def build(pu: torch.Tensor, pv: torch.Tensor, n_nodes: int, seg_len: int = DEFAULT_INC_SEG_LEN,
               run_len: int = DEFAULT_RUN_LEN, row_range: tuple[int, int] | None = None,
-              n_slices: int = DEFAULT_SLICES, by_u_range: tuple[int, int] | None = None,
-              build_by_u: bool = True) -> "PairList":
+              n_slices: int | None = None, by_u_range: tuple[int, int] | None = None,
+              build_by_u: bool = True, row_bytes: int = 2048) -> "PairList":
         """``row_range`` restricts the incidence rows to one shard's nodes (the pair ids in ``inc_pair``
         then index prob / g_prob arrays covering the whole pair list); ``by_u_range`` restricts the rows
         of the forward plan (every pu must lie inside it)."""
@@ -249,6 +257,8 @@ class PairList:
         pv = pv.reshape(-1).to(torch.int64)
         if pu.numel() != pv.numel():
             raise ValueError("pu and pv differ in length")
+        if n_slices is None:
+            n_slices = auto_slices(n_nodes, row_bytes)
         P = pu.numel()
         if 2 * P >= 2 ** 31:
             raise ValueError("too many pairs for int32 incidence")

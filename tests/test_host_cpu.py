@@ -166,6 +166,8 @@ def test_pair_incidence_lists_every_slot_once():
             assert pu[q] == u and pv[q] == v
     _check_plan(pl.by_u, uptr, 4)
     assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 8
+    from disenlink_amd.graph import auto_slices
+    assert auto_slices(5201, 2048) == 8 and auto_slices(41554, 8192) == 1 and auto_slices(2_900_000, 2048) == 1
     # a shard lists only its own nodes' slots
     sh = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, row_range=(3, 8))
     assert sh.inc.n_rows == 5 and sh.inc.row_offset == 3
