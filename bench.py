@@ -26,6 +26,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# kernel behind each timed phase (the name rocprofv3 reports) -> PMC summary of tools/pmc_traffic.py
+PHASE_KERNEL = {"route": "dl::fast::route_seg_kernel<8, 64>", "aggregate": "dl::fast::aggregate_seg_kernel<8, 64>",
+                "score": "dl::fast::score_fwd_seg_kernel<8, 64, false>"}
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+
+
+def pmc_traffic(phase):
+    """HBM-side bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; same command, same workload), or None."""
+    try:
+        table = json.load(open(PMC_SUMMARY))
+        return float(table[PHASE_KERNEL[phase]]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def algorithmic_bytes(K, d, n_nodes, n_edges, n_pairs, w=4):
@@ -208,7 +222,11 @@ def main():
                    "K": K, "d": d, "n_nodes": N, "E_sym": E, "P": P, "fast_path": bool(lib.dl_has_fast_path(K, d))
                    and not args.force_generic},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None},
+                     "unit": "GB/s", "frac": kernels[dom]["frac"],
+                     "traffic": pmc_traffic(dom) if (args.workload == "squirrel" and K == 8 and d == 64) else None,
+                     "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                       "separate passes of this command; bytes leaving the XCD L2s per launch)",
+                     "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "avg_us": kernels[dom]["avg_us"]},
         "edge_scatter": {"kernels": "route+aggregate", "avg_us": scatter_t * 1e6, "algorithmic_bytes": scatter_b,
                          "achieved_GBs": scatter_b / scatter_t / 1e9, "frac": scatter_b / scatter_t / 1e9 / HBM_PEAK_GBS,
                          "edges_per_s": E / scatter_t},

@@ -38,16 +38,19 @@ EXPORTS = {
     "dl_version": (C.c_char_p, []),
     "dl_last_error": (C.c_char_p, []),
     "dl_has_fast_path": (_i, [_i, _i]),
+    "dl_has_fast_path_dtype": (_i, [_i, _i, _i]),
     "dl_set_force_generic": (_i, [_i]),
     "dl_workspace_bytes": (_z, [C.POINTER(DlCsrPlan), _i, _i]),
-    "dl_route_fwd": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
-    "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
-    "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P, _P]),
-    "dl_score_pairs_bwd": (_i, [_P, _P, _i, _i, _f, _I, _P, _P, _P, _P, _P, _P, _z, _P]),
-    "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
-    "dl_route_aggregate_bwd_phase2": (_i, [_G, _P, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
-    "dl_route_aggregate_bwd": (_i, [_G, _P, _i, _i, _f, _f, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
+    "dl_route_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
+    "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P, _P]),
+    "dl_score_pairs_bwd": (_i, [_P, _P, _i, _i, _i, _f, _I, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_route_aggregate_bwd_phase2": (_i, [_G, _P, _i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
+    "dl_route_aggregate_bwd": (_i, [_G, _P, _i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
 }
+
+DL_F32, DL_BF16 = 0, 1
 
 _lib = None
 

@@ -81,8 +81,17 @@ static bool has_seg_plan(const dl_csr_plan* c) {
            (c->n_multi == 0 || (c->multi_row && c->multi_slot0));
 }
 
-static bool use_fast(const dl_csr_plan* c, int K, int d) {
-    return !g_force_generic && fast_supported(K, d) && has_seg_plan(c);
+static bool use_fast(const dl_csr_plan* c, int K, int d, int dtype) {
+    return !g_force_generic && fast_supported(K, d, dtype) && has_seg_plan(c);
+}
+
+// bf16 tables exist only on the tuned path
+static int check_dtype(const dl_csr_plan* c, int K, int d, int dtype) {
+    DL_REQUIRE(dtype == DL_F32 || dtype == DL_BF16, "unknown dtype %d", dtype);
+    if (dtype == DL_BF16)
+        DL_REQUIRE(c && use_fast(c, K, d, dtype),
+                   "bf16 tables need a tuned kernel for K=%d d=%d and a segment plan (no generic bf16 path)", K, d);
+    return DL_OK;
 }
 
 }  // namespace dl
@@ -91,9 +100,10 @@ using namespace dl;
 
 extern "C" {
 
-const char* dl_version(void) { return "disenlink_hip 0.2 (gfx950)"; }
+const char* dl_version(void) { return "disenlink_hip 0.3 (gfx950)"; }
 const char* dl_last_error(void) { return g_err; }
-int dl_has_fast_path(int K, int d) { return fast_supported(K, d) ? 1 : 0; }
+int dl_has_fast_path(int K, int d) { return fast_supported(K, d, DL_F32) ? 1 : 0; }
+int dl_has_fast_path_dtype(int K, int d, dl_dtype dtype) { return fast_supported(K, d, (int)dtype) ? 1 : 0; }
 
 int dl_set_force_generic(int on) {
     int old = g_force_generic;
@@ -106,45 +116,48 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d) {
     return carve(plan, K, d, nullptr).bytes;
 }
 
-int dl_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
-                 void* ws, size_t ws_bytes, void* stream) {
+int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float t, uint8_t* p, float* a,
+                 float* s, void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
     const dl_csr_plan* c = &g->csr;
     if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
+    if (int rc = check_dtype(c, K, d, dtype)) return rc;
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && s, "Z or s is NULL");
     if (c->n_entries > 0) DL_REQUIRE(p && a, "p or a is NULL");
-    if (use_fast(c, K, d)) {
+    if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_route_fwd(c, Z, K, d, t, p, a, s, w.vec_part, (hipStream_t)stream);
+        return fast_route_fwd(c, Z, K, d, dtype, t, p, a, s, w.vec_part, (hipStream_t)stream);
     }
-    return generic_route_fwd(c, Z, K, d, t, p, a, s, (hipStream_t)stream);
+    return generic_route_fwd(c, (const float*)Z, K, d, t, p, a, s, (hipStream_t)stream);
 }
 
-int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
-                     const float* a, const float* s, float* H, void* ws, size_t ws_bytes, void* stream) {
+int dl_aggregate_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, const uint8_t* p,
+                     const float* a, const float* s, void* H, void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
     const dl_csr_plan* c = &g->csr;
     if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
+    if (int rc = check_dtype(c, K, d, dtype)) return rc;
     if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && s && H, "Z, s or H is NULL");
     if (c->n_entries > 0) DL_REQUIRE(p && a, "p or a is NULL");
-    if (use_fast(c, K, d)) {
+    if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_aggregate_fwd(c, Z, K, d, beta, p, a, s, H, w.row_part, (hipStream_t)stream);
+        return fast_aggregate_fwd(c, Z, K, d, dtype, beta, p, a, s, H, w.row_part, (hipStream_t)stream);
     }
-    return generic_aggregate_fwd(c, Z, K, d, beta, p, a, s, H, (hipStream_t)stream);
+    return generic_aggregate_fwd(c, (const float*)Z, K, d, beta, p, a, s, (float*)H, (hipStream_t)stream);
 }
 
-int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, const int32_t* pu,
-                       const int32_t* pv, int n_pairs, const dl_pair_incidence* by_u, float* prob, float* coef,
-                       void* stream) {
+int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
+                       const int32_t* pu, const int32_t* pv, int n_pairs, const dl_pair_incidence* by_u,
+                       float* prob, float* coef, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
+    if (int rc = check_dtype(by_u ? &by_u->csr : nullptr, K, d, dtype)) return rc;
     DL_REQUIRE(N >= 0 && n_pairs >= 0, "negative size");
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (n_pairs == 0) return DL_OK;
@@ -154,75 +167,79 @@ int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, floa
         DL_REQUIRE(by_u->csr.n_entries == n_pairs && by_u->n_pairs == n_pairs && by_u->inc_pair,
                    "by_u must list each of the %d pairs exactly once", n_pairs);
         DL_REQUIRE(by_u->csr.n_total == N, "by_u.n_total=%d != N=%d", by_u->csr.n_total, N);
-        if (use_fast(&by_u->csr, K, d))
-            return fast_score_pairs_fwd(by_u, Z, H, K, d, t, prob, coef, (hipStream_t)stream);
+        if (use_fast(&by_u->csr, K, d, dtype))
+            return fast_score_pairs_fwd(by_u, Z, H, K, d, dtype, t, prob, coef, (hipStream_t)stream);
     }
     DL_REQUIRE(coef == nullptr, "coef output needs the tuned scorer (a (K,d) with a fast path and a by_u plan)");
-    return generic_score_pairs_fwd(Z, H, K, d, t, pu, pv, n_pairs, prob, (hipStream_t)stream);
+    return generic_score_pairs_fwd((const float*)Z, (const float*)H, K, d, t, pu, pv, n_pairs, prob,
+                                   (hipStream_t)stream);
 }
 
-int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t, const dl_pair_incidence* inc,
-                       const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH, void* ws,
-                       size_t ws_bytes, void* stream) {
+int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
+                       const dl_pair_incidence* inc, const float* prob, const float* g_prob, const float* coef,
+                       float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(inc != nullptr, "incidence is NULL");
     const dl_csr_plan* c = &inc->csr;
     if (int rc = check_plan(c, "incidence")) return rc;
+    if (int rc = check_dtype(c, K, d, dtype)) return rc;
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && H && dZ && dH, "NULL argument");
     if (c->n_entries > 0) DL_REQUIRE(inc->inc_pair && prob && g_prob, "NULL pair argument");
-    if (use_fast(c, K, d)) {
+    if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        if (coef)
-            return fast_score_pairs_bwd_coef(inc, Z, H, K, d, t, prob, g_prob, coef, dZ, dH, w.row_part,
-                                             (hipStream_t)stream);
-        return fast_score_pairs_bwd(inc, Z, H, K, d, t, prob, g_prob, dZ, dH, w.row_part, (hipStream_t)stream);
+        return fast_score_pairs_bwd(inc, Z, H, K, d, dtype, t, prob, g_prob, coef, dZ, dH, w.row_part,
+                                    (hipStream_t)stream);
     }
-    return generic_score_pairs_bwd(inc, Z, H, K, d, t, prob, g_prob, dZ, dH, (hipStream_t)stream);
+    return generic_score_pairs_bwd(inc, (const float*)Z, (const float*)H, K, d, t, prob, g_prob, dZ, dH,
+                                   (hipStream_t)stream);
 }
 
-int dl_route_aggregate_bwd_phase1(const dl_graph* g, const float* Z, int K, int d, float beta, const uint8_t* p,
-                                  const float* a, const float* s, const float* dH, float* dw, float* dwr,
-                                  float* ds, void* ws, size_t ws_bytes, void* stream) {
+int dl_route_aggregate_bwd_phase1(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
+                                  const uint8_t* p, const float* a, const float* s, const float* dH, float* dw,
+                                  float* dwr, float* ds, void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
     const dl_csr_plan* c = &g->csr;
     if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
+    if (int rc = check_dtype(c, K, d, dtype)) return rc;
     if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && s && dH && ds, "NULL argument");
     if (c->n_entries > 0) DL_REQUIRE(p && a && dw && dwr, "NULL per-edge argument");
-    if (use_fast(c, K, d)) {
+    if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_bwd_phase1(c, Z, K, d, beta, p, a, s, dH, dw, dwr, ds, w.vec_part, (hipStream_t)stream);
+        return fast_bwd_phase1(c, Z, K, d, dtype, beta, p, a, s, dH, dw, dwr, ds, w.vec_part, (hipStream_t)stream);
     }
-    return generic_bwd_phase1(c, Z, K, d, beta, p, a, s, dH, dw, dwr, ds, (hipStream_t)stream);
+    return generic_bwd_phase1(c, (const float*)Z, K, d, beta, p, a, s, dH, dw, dwr, ds, (hipStream_t)stream);
 }
 
-int dl_route_aggregate_bwd_phase2(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
-                                  const uint8_t* p, const float* a, const float* s, const float* dH,
+int dl_route_aggregate_bwd_phase2(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
+                                  float t, const uint8_t* p, const float* a, const float* s, const float* dH,
                                   const float* dw, const float* dwr, const float* ds, float* dZ, int accumulate,
                                   void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
     const dl_csr_plan* c = &g->csr;
     if (int rc = check_plan(c, "graph")) return rc;
     if (int rc = check_shape(K, d)) return rc;
+    if (int rc = check_dtype(c, K, d, dtype)) return rc;
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (c->n_rows == 0) return DL_OK;
     DL_REQUIRE(Z && s && dH && ds && dZ, "NULL argument");
     if (c->n_entries > 0) DL_REQUIRE(p && a && dw && dwr, "NULL per-edge argument");
-    if (use_fast(c, K, d)) {
+    if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_bwd_phase2(c, Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, w.row_part,
+        return fast_bwd_phase2(c, Z, K, d, dtype, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, w.row_part,
                                (hipStream_t)stream);
     }
-    return generic_bwd_phase2(c, Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, (hipStream_t)stream);
+    return generic_bwd_phase2(c, (const float*)Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate,
+                              (hipStream_t)stream);
 }
 
-int dl_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
+int dl_route_aggregate_bwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
                            const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
                            int accumulate, void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
@@ -233,10 +250,11 @@ int dl_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, floa
                "dl_route_aggregate_bwd needs an unsharded plan; call the two phases with an all-gather of ds between");
     Workspace w;
     if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-    if (int rc = dl_route_aggregate_bwd_phase1(g, Z, K, d, beta, p, a, s, dH, w.dw, w.dwr, w.ds, ws, ws_bytes, stream))
+    if (int rc = dl_route_aggregate_bwd_phase1(g, Z, K, d, dtype, beta, p, a, s, dH, w.dw, w.dwr, w.ds, ws, ws_bytes,
+                                               stream))
         return rc;
-    return dl_route_aggregate_bwd_phase2(g, Z, K, d, beta, t, p, a, s, dH, w.dw, w.dwr, w.ds, dZ, accumulate, ws,
-                                         ws_bytes, stream);
+    return dl_route_aggregate_bwd_phase2(g, Z, K, d, dtype, beta, t, p, a, s, dH, w.dw, w.dwr, w.ds, dZ, accumulate,
+                                         ws, ws_bytes, stream);
 }
 
 }  // extern "C"

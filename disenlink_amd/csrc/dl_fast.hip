@@ -1,82 +1,171 @@
-// Tuned kernels for gfx950, instantiated per (K, D).
+// Tuned kernels for gfx950, instantiated per (K, D, table type).
 //
-// Work decomposition: the plan cuts every CSR row into segments of <= seg_len consecutive
+// Work decomposition: the plan cuts every CSR row into segments of <= seg_len (<= 64) consecutive
 // entries; ONE 64-lane wave owns one segment, so a hub row of thousands of edges is spread over
 // many waves and CUs while a median row (tens of edges) is a single wave.  Inside a wave, a group
-// of G = D/4 lanes owns one entry: lane c of the group holds the float4 chunk c of every factor
-// slice, i.e. one neighbour row Z[j] (K*D*4 bytes, contiguous) is fetched by K coalesced
-// 16-byte-per-lane loads and 64/G entries are in flight per wave iteration.  The K dot products
-// are reduced with log2(G) cross-lane butterflies; the K-way softmax / arg-max is then computed
-// redundantly by every lane of the group, so no further exchange is needed.
+// of G = D/VEC lanes owns one entry: lane c of the group holds the 16-byte chunk c (VEC = 4 fp32 or
+// 8 bf16 elements) of every factor slice, i.e. one neighbour row Z[j] (contiguous in HBM) is fetched
+// by K coalesced 16-byte-per-lane loads and 64/G entries are in flight per wave iteration.
+//
+// Per-entry scalars (column, routing factor, weights) are loaded once per segment, one entry per
+// lane, and handed to the groups by shuffles: no dependent index load inside the loop.
+//
+// The K per-factor dot products are reduced with a TRANSPOSED butterfly (dl_common.h): after
+// log2(G) exchange steps every lane owns the complete dot product of one factor, so exp, softmax
+// weight and the per-factor terms are computed once per factor, not once per lane.
 //
 // Rows with one segment write their outputs directly; segments of multi-segment rows write
-// per-segment partials (in the caller's workspace) that a combine kernel sums in segment order.
-// No float atomics anywhere: results are bitwise reproducible.
+// per-segment partials (fp32, in the caller's workspace) that a combine kernel sums in segment
+// order.  No float atomics anywhere: results are bitwise reproducible.
+//
+// Tables Z and H may be stored as fp32 or bf16 (dl_dtype); all arithmetic and all gradients are fp32.
 #include "dl_common.h"
 #include "dl_kernels.h"
 
 namespace dl {
 namespace fast {
 
-__device__ __forceinline__ float dot4(const float4& x, const float4& y) {
-    return fmaf(x.w, y.w, fmaf(x.z, y.z, fmaf(x.y, y.y, x.x * y.x)));
-}
-__device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
-    acc.x = fmaf(w, v.x, acc.x);
-    acc.y = fmaf(w, v.y, acc.y);
-    acc.z = fmaf(w, v.z, acc.z);
-    acc.w = fmaf(w, v.w, acc.w);
-}
-template <int G>
-__device__ __forceinline__ void across_groups_sum4(float4& v) {
-    v.x = across_groups_sum<G>(v.x);
-    v.y = across_groups_sum<G>(v.y);
-    v.z = across_groups_sum<G>(v.z);
-    v.w = across_groups_sum<G>(v.w);
-}
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// ---------------------------------------------------------------------------- typed 16-byte chunks
+typedef unsigned short bf16_t;      // raw bf16 bits
 
-// e_k = exp(z_k[i].z_k[j] / t) for all K factors and their sum S (sequential in k).
-template <int K, int G>
-__device__ __forceinline__ float edge_exps(const float4 (&zi)[K], const float4 (&zj)[K], float t, float (&ex)[K]) {
-    float S = 0.0f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        ex[k] = expf(group_allreduce_sum<G>(dot4(zi[k], zj[k])) / t);
-        S += ex[k];
+template <int VEC>
+struct Chunk {
+    float v[VEC];
+};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned int hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ unsigned int f32_to_bf16(float f) {   // round to nearest even; NaN stays NaN
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <typename T>
+struct Tab;
+template <>
+struct Tab<float> {
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ Chunk<4> load(const float* p) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        return Chunk<4>{{q.x, q.y, q.z, q.w}};
     }
-    return S;
+    static __device__ __forceinline__ void store(float* p, const Chunk<4>& c) {
+        *reinterpret_cast<float4*>(p) = make_float4(c.v[0], c.v[1], c.v[2], c.v[3]);
+    }
+};
+template <>
+struct Tab<bf16_t> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ Chunk<8> load(const bf16_t* p) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        Chunk<8> c;
+        c.v[0] = bf16_to_f32(q.x & 0xffffu); c.v[1] = bf16_to_f32(q.x >> 16);
+        c.v[2] = bf16_to_f32(q.y & 0xffffu); c.v[3] = bf16_to_f32(q.y >> 16);
+        c.v[4] = bf16_to_f32(q.z & 0xffffu); c.v[5] = bf16_to_f32(q.z >> 16);
+        c.v[6] = bf16_to_f32(q.w & 0xffffu); c.v[7] = bf16_to_f32(q.w >> 16);
+        return c;
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const Chunk<8>& c) {
+        uint4 q;
+        q.x = f32_to_bf16(c.v[0]) | (f32_to_bf16(c.v[1]) << 16);
+        q.y = f32_to_bf16(c.v[2]) | (f32_to_bf16(c.v[3]) << 16);
+        q.z = f32_to_bf16(c.v[4]) | (f32_to_bf16(c.v[5]) << 16);
+        q.w = f32_to_bf16(c.v[6]) | (f32_to_bf16(c.v[7]) << 16);
+        *reinterpret_cast<uint4*>(p) = q;
+    }
+};
+
+// fp32 arrays (gradients, partials, LDS) accessed VEC elements at a time
+template <int VEC>
+__device__ __forceinline__ Chunk<VEC> load_f32(const float* p) {
+    Chunk<VEC> c;
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p + i);
+        c.v[i] = q.x; c.v[i + 1] = q.y; c.v[i + 2] = q.z; c.v[i + 3] = q.w;
+    }
+    return c;
+}
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* p, const Chunk<VEC>& c) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4)
+        *reinterpret_cast<float4*>(p + i) = make_float4(c.v[i], c.v[i + 1], c.v[i + 2], c.v[i + 3]);
+}
+template <int VEC>
+__device__ __forceinline__ Chunk<VEC> zero_chunk() {
+    Chunk<VEC> c;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) c.v[i] = 0.0f;
+    return c;
+}
+template <int VEC>
+__device__ __forceinline__ float dot(const Chunk<VEC>& x, const Chunk<VEC>& y) {
+    float r = x.v[0] * y.v[0];
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) r = fmaf(x.v[i], y.v[i], r);
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void fma_chunk(Chunk<VEC>& acc, float w, const Chunk<VEC>& x) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(w, x.v[i], acc.v[i]);
+}
+template <int G, int VEC>
+__device__ __forceinline__ void across_groups_sum_chunk(Chunk<VEC>& c) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) c.v[i] = across_groups_sum<G>(c.v[i]);
+}
+
+template <int K, int D, typename T>
+struct Geo {
+    static constexpr int VEC = Tab<T>::VEC;
+    static constexpr int G = D / VEC;             // lanes per entry
+    static constexpr int EPW = DL_WAVE / G;       // entries per wave iteration
+    static constexpr int ROW = K * D;             // elements per node row
+    using FL = FactorLanes<G, K>;
+    static_assert(D % VEC == 0 && (G & (G - 1)) == 0 && G <= DL_WAVE, "D must be VEC * a power of two <= 64");
+};
+
+// Per-lane softmax pieces of one entry after the transposed reduce: this lane owns factors
+// kb .. kb+VPL-1; ex[i] = exp(sigma/t); S = sum over all K factors (group-wide).
+template <int K, int G>
+__device__ __forceinline__ float lane_exps(float* part, int c, float t, float (&ex)[FactorLanes<G, K>::VPL]) {
+    using FL = FactorLanes<G, K>;
+    TransposedReduce<FL::KP, G / 2>::run(part, c);
+    const int kb = FL::factor_base(c);
+    float mine = 0.0f;
+#pragma unroll
+    for (int i = 0; i < FL::VPL; ++i) {
+        ex[i] = expf(div_t(part[i], t));
+        if (FL::primary(c) && kb + i < K) mine += ex[i];
+    }
+    return group_allreduce_sum<G>(mine);
 }
 
 // ---------------------------------------------------------------------------- route
-template <int K, int D>
-__global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const float* __restrict__ Z, float t,
+template <int K, int D, typename T>
+__global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float t,
                                                           uint8_t* __restrict__ p, float* __restrict__ a,
                                                           float* __restrict__ s, float* __restrict__ s_part) {
-    constexpr int G = D / 4;            // lanes per edge
-    constexpr int EPW = DL_WAVE / G;    // edges per wave iteration
+    using GE = Geo<K, D, T>;
+    using FL = typename GE::FL;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL;
     const int seg = wave_segment(g);
     if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
-    const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
-    const size_t rs = (size_t)K * G;    // float4 per node row
-
-    using FL = FactorLanes<G, K>;
-    constexpr int KP = FL::KP, VPL = FL::VPL;
     const int kb = FL::factor_base(c);
     const bool prim = FL::primary(c);
 
-    float4 zi[K];
+    Chunk<VEC> zi[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) zi[k] = Z4[(size_t)si.grow * rs + k * G + c];
+    for (int k = 0; k < K; ++k) zi[k] = Tab<T>::load(Z + (size_t)si.grow * GE::ROW + k * D + c * VEC);
     float sacc[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) sacc[i] = 0.0f;
 
-    // lane l pre-loads entry l of the segment (seg_len <= 64): one coalesced load instead of a
-    // dependent load per iteration; groups pick their entry up with a shuffle.
     const int my_col = (si.beg + lane < si.end) ? g.col[si.beg + lane] : si.grow;
     for (int base = si.beg; base < si.end; base += EPW) {
         const int e = base + grp;
@@ -84,16 +173,11 @@ __global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const f
         const int j = __shfl(my_col, e - si.beg, DL_WAVE);
         float part[KP];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) part[k] = k < K ? dot4(zi[k < K ? k : 0], Z4[(size_t)j * rs + (k < K ? k : 0) * G + c]) : 0.0f;
-        TransposedReduce<KP, G / 2>::run(part, c);         // this lane now owns factors kb .. kb+VPL-1
+        for (int k = 0; k < KP; ++k)
+            part[k] = k < K ? dot(zi[k < K ? k : 0], Tab<T>::load(Z + (size_t)j * GE::ROW + (k < K ? k : 0) * D + c * VEC))
+                            : 0.0f;
         float ex[VPL];
-        float mine = 0.0f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            ex[i] = expf(div_t(part[i], t));
-            if (prim && kb + i < K) mine += ex[i];
-        }
-        const float S = group_allreduce_sum<G>(mine);
+        const float S = lane_exps<K, G>(part, c, t, ex);
         float best = 0.0f;
         int win = 255;
 #pragma unroll
@@ -139,26 +223,23 @@ __global__ __launch_bounds__(BLOCK) void vec_combine_kernel(dl_csr_plan g, int K
 }
 
 // ---------------------------------------------------------------------------- aggregate
-template <int K, int D>
-__global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, const float* __restrict__ Z, float beta,
+template <int K, int D, typename T>
+__global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
                                                               const uint8_t* __restrict__ p,
                                                               const float* __restrict__ a,
-                                                              const float* __restrict__ s, float* __restrict__ H,
+                                                              const float* __restrict__ s, T* __restrict__ H,
                                                               float* __restrict__ h_part) {
-    constexpr int G = D / 4;
-    constexpr int EPW = DL_WAVE / G;
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW;
     const int seg = wave_segment(g);
     if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
-    const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
-    const size_t rs = (size_t)K * G;
 
-    float4 acc[K];
+    Chunk<VEC> acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = zero4();
-
+    for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
     // per-entry scalars are computed once by the entry's own lane, then shuffled to its group
     int my_col = si.grow, my_k = 0;
     float my_w = 0.0f;
@@ -171,52 +252,66 @@ __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, con
         const int idx = base + grp - si.beg;
         const int j = __shfl(my_col, idx, DL_WAVE);
         const int k = __shfl(my_k, idx, DL_WAVE);
-        const float w = __shfl(my_w, idx, DL_WAVE);
-        const float4 v = Z4[(size_t)j * rs + k * G + c];
+        const float w = __shfl(my_w, idx, DL_WAVE);           // 0 past the segment end
+        const Chunk<VEC> v = Tab<T>::load(Z + (size_t)j * GE::ROW + k * D + c * VEC);
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) fma4(acc[kk], (kk == k) ? w : 0.0f, v);
+        for (int kk = 0; kk < K; ++kk) fma_chunk(acc[kk], (kk == k) ? w : 0.0f, v);
     }
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) across_groups_sum4<G>(acc[kk]);
+    for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
     if (grp == 0) {
         if (si.slot < 0) {
             const float omb = 1.0f - beta;
-            float4* __restrict__ H4 = reinterpret_cast<float4*>(H);
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                const float4 z = Z4[(size_t)si.grow * rs + kk * G + c];
-                float4 h;
-                h.x = beta * z.x + omb * acc[kk].x;
-                h.y = beta * z.y + omb * acc[kk].y;
-                h.z = beta * z.z + omb * acc[kk].z;
-                h.w = beta * z.w + omb * acc[kk].w;
-                H4[(size_t)si.grow * rs + kk * G + c] = h;
+                const size_t o = (size_t)si.grow * GE::ROW + kk * D + c * VEC;
+                const Chunk<VEC> z = Tab<T>::load(Z + o);
+                Chunk<VEC> h;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) h.v[i] = beta * z.v[i] + omb * acc[kk].v[i];
+                Tab<T>::store(H + o, h);
             }
         } else {
-            float4* __restrict__ P4 = reinterpret_cast<float4*>(h_part);
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) P4[(size_t)si.slot * rs + kk * G + c] = acc[kk];
+            for (int kk = 0; kk < K; ++kk)
+                store_f32<VEC>(h_part + (size_t)si.slot * GE::ROW + kk * D + c * VEC, acc[kk]);
         }
     }
 }
 
 // Per multi-segment row:  out[grow] = (accumulate ? out[grow] : 0) + cx * X[grow] + cp * sum_slots part[slot].
-// One 256-thread block per row: each of the 4 waves sums every 4th slot, LDS combines them in
-// wave order.  `part` rows are `pstride4` float4 apart, starting at `poff4` (so the dZ and dH
-// halves of the scorer backward's partials can be combined separately).
-template <int TOT4>
-__global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const float* __restrict__ part,
-                                                            int pstride4, int poff4, const float* __restrict__ X,
-                                                            float cx, float cp, float* __restrict__ out,
-                                                            int accumulate) {
+// One 256-thread block per row: each of the 4 waves sums every 4th slot, LDS combines them in wave
+// order.  Partials are fp32 rows `pstride` floats apart; X and out are tables of type TX / TO.
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu),
+                       bf16_to_f32(q.y >> 16));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
+    uint2 q;
+    q.x = f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16);
+    q.y = f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+
+template <int TOT, typename TX, typename TO>
+__global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const float* __restrict__ part, int pstride,
+                                                            const TX* __restrict__ X, float cx, float cp,
+                                                            TO* __restrict__ out, int accumulate) {
+    constexpr int TOT4 = TOT / 4;
     constexpr int NQ = (TOT4 + DL_WAVE - 1) / DL_WAVE;
     __shared__ float4 red[WAVES_PER_BLOCK][NQ * DL_WAVE];
     const int m = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const float4* __restrict__ P4 = reinterpret_cast<const float4*>(part);
     float4 acc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = zero4();
+    for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int s0 = g.multi_slot0[m], s1 = g.multi_slot0[m + 1];
 #pragma unroll 2
     for (int slot = s0 + wave; slot < s1; slot += WAVES_PER_BLOCK) {
@@ -224,7 +319,7 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
         for (int q = 0; q < NQ; ++q) {
             const int x = q * DL_WAVE + lane;
             if (x < TOT4) {
-                const float4 v = P4[(size_t)slot * pstride4 + poff4 + x];
+                const float4 v = load4<float>(part + (size_t)slot * pstride + 4 * x);
                 acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
             }
         }
@@ -234,8 +329,6 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
     __syncthreads();
     if (wave != 0) return;
     const size_t grow = (size_t)g.multi_row[m] + g.row_offset;
-    const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X);
-    float4* __restrict__ O4 = reinterpret_cast<float4*>(out);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int x = q * DL_WAVE + lane;
@@ -246,37 +339,35 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
                 const float4 v = red[w][x];
                 t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
             }
-            const float4 xv = X4[grow * TOT4 + x];
-            float4 o = accumulate ? O4[grow * TOT4 + x] : zero4();
-            o.x += cx * xv.x + cp * t.x;
-            o.y += cx * xv.y + cp * t.y;
-            o.z += cx * xv.z + cp * t.z;
-            o.w += cx * xv.w + cp * t.w;
-            O4[grow * TOT4 + x] = o;
+            const size_t o = grow * TOT + 4 * x;
+            float4 r = accumulate ? load4<TO>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cx != 0.0f) {
+                const float4 xv = load4<TX>(X + o);
+                r.x += cx * xv.x; r.y += cx * xv.y; r.z += cx * xv.z; r.w += cx * xv.w;
+            }
+            r.x += cp * t.x; r.y += cp * t.y; r.z += cp * t.z; r.w += cp * t.w;
+            store4(out + o, r);
         }
     }
 }
 
 // ---------------------------------------------------------------------------- backward, phase 1
 // dw[e] = (1-b) dH[i][p].Z[j][p] ; dwr[e] = (1-b) dH[j][p].Z[i][p] ; ds[i][k] = -(sum [p=k] dwr a)/s~^2
-template <int K, int D>
-__global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, const float* __restrict__ Z,
+template <int K, int D, typename T>
+__global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, const T* __restrict__ Z,
                                                                const float* __restrict__ dH, float beta,
                                                                const uint8_t* __restrict__ p,
                                                                const float* __restrict__ a,
                                                                const float* __restrict__ s,
                                                                float* __restrict__ dw, float* __restrict__ dwr,
                                                                float* __restrict__ ds, float* __restrict__ ds_part) {
-    constexpr int G = D / 4;
-    constexpr int EPW = DL_WAVE / G;
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW;
     const int seg = wave_segment(g);
     if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
-    const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
-    const float4* __restrict__ D4 = reinterpret_cast<const float4*>(dH);
-    const size_t rs = (size_t)K * G;
     const float omb = 1.0f - beta;
     float acc[K];
 #pragma unroll
@@ -294,9 +385,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, co
         const int j = __shfl(my_col, e - si.beg, DL_WAVE);
         const int k = __shfl(my_k, e - si.beg, DL_WAVE);
         const float ae = __shfl(my_a, e - si.beg, DL_WAVE);
-        const size_t oi = (size_t)si.grow * rs + k * G + c, oj = (size_t)j * rs + k * G + c;
-        const float v = omb * group_allreduce_sum<G>(dot4(D4[oi], Z4[oj]));
-        const float vr = omb * group_allreduce_sum<G>(dot4(D4[oj], Z4[oi]));
+        const size_t oi = (size_t)si.grow * GE::ROW + k * D + c * VEC, oj = (size_t)j * GE::ROW + k * D + c * VEC;
+        const float v = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oi), Tab<T>::load(Z + oj)));
+        const float vr = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oj), Tab<T>::load(Z + oi)));
         if (live && c == 0) { dw[e] = v; dwr[e] = vr; }
         const float contrib = live ? vr * ae : 0.0f;
 #pragma unroll
@@ -319,29 +410,28 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, co
 }
 
 // ---------------------------------------------------------------------------- backward, phase 2
-template <int K, int D>
+template <int K, int D, typename T>
 __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
-    dl_csr_plan g, const float* __restrict__ Z, const float* __restrict__ dH, float beta, float t,
+    dl_csr_plan g, const T* __restrict__ Z, const float* __restrict__ dH, float beta, float t,
     const uint8_t* __restrict__ p, const float* __restrict__ a, const float* __restrict__ s,
     const float* __restrict__ dw, const float* __restrict__ dwr, const float* __restrict__ ds,
     float* __restrict__ dZ, int accumulate, float* __restrict__ dz_part) {
-    constexpr int G = D / 4;
-    constexpr int EPW = DL_WAVE / G;
+    using GE = Geo<K, D, T>;
+    using FL = typename GE::FL;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL;
     const int seg = wave_segment(g);
     if (seg < 0) return;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
-    const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
-    const float4* __restrict__ D4 = reinterpret_cast<const float4*>(dH);
-    const size_t rs = (size_t)K * G;
     const float omb = 1.0f - beta;
+    const int kb = FL::factor_base(c);
 
-    float4 zi[K], acc[K];
+    Chunk<VEC> zi[K], acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        zi[k] = Z4[(size_t)si.grow * rs + k * G + c];
-        acc[k] = zero4();
+        zi[k] = Tab<T>::load(Z + (size_t)si.grow * GE::ROW + k * D + c * VEC);
+        acc[k] = zero_chunk<VEC>();
     }
     // per-entry scalars (routing factor, softmax-gradient scale cc, aggregation weight w2) are
     // computed once by the entry's own lane and shuffled to its group inside the loop
@@ -360,79 +450,89 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
         my_w2 = omb * ae / s_i;
     }
     for (int base = si.beg; base < si.end; base += EPW) {
-        const int e = base + grp;
-        const bool live = e < si.end;
-        const int j = __shfl(my_col, e - si.beg, DL_WAVE);
-        const int k = __shfl(my_k, e - si.beg, DL_WAVE);
-        const float cc = __shfl(my_cc, e - si.beg, DL_WAVE);
-        const float w2 = __shfl(my_w2, e - si.beg, DL_WAVE);
-        float4 zj[K];
+        const int idx = base + grp - si.beg;
+        const int j = __shfl(my_col, idx, DL_WAVE);
+        const int k = __shfl(my_k, idx, DL_WAVE);
+        const float cc = __shfl(my_cc, idx, DL_WAVE);          // 0 past the segment end
+        const float w2 = __shfl(my_w2, idx, DL_WAVE);
+        Chunk<VEC> zj[K];
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) zj[kk] = Z4[(size_t)j * rs + kk * G + c];
-        const float4 dhj = D4[(size_t)j * rs + k * G + c];
-        float ex[K];
-        const float S = edge_exps<K, G>(zi, zj, t, ex);
+        for (int kk = 0; kk < K; ++kk) zj[kk] = Tab<T>::load(Z + (size_t)j * GE::ROW + kk * D + c * VEC);
+        const Chunk<VEC> dhj = load_f32<VEC>(dH + (size_t)j * GE::ROW + k * D + c * VEC);
+        float part[KP];
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) part[kk] = kk < K ? dot(zi[kk < K ? kk : 0], zj[kk < K ? kk : 0]) : 0.0f;
+        float ex[VPL];
+        const float S = lane_exps<K, G>(part, c, t, ex);
+        float ck_lane[VPL];                                     // coefficient of the factors this lane owns
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            ck_lane[i] = cc == 0.0f ? 0.0f : cc * ((kb + i == k ? 1.0f : 0.0f) - ex[i] / S) / t;
+        const int gbase = lane & ~(G - 1);
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
-            const bool hit = kk == k;
-            const float ck = live ? cc * ((hit ? 1.0f : 0.0f) - ex[kk] / S) / t : 0.0f;
-            fma4(acc[kk], ck, zj[kk]);
-            fma4(acc[kk], hit ? w2 : 0.0f, dhj);
+            const float ck = __shfl(ck_lane[FL::src_slot(kk)], gbase + FL::src_lane(kk), DL_WAVE);
+            fma_chunk(acc[kk], ck, zj[kk]);
+            fma_chunk(acc[kk], kk == k ? w2 : 0.0f, dhj);
         }
     }
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) across_groups_sum4<G>(acc[kk]);
+    for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
     if (grp == 0) {
         if (si.slot < 0) {
-            float4* __restrict__ O4 = reinterpret_cast<float4*>(dZ);
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                const size_t o = (size_t)si.grow * rs + kk * G + c;
-                const float4 dh = D4[o];
-                float4 r = accumulate ? O4[o] : zero4();
-                r.x += beta * dh.x + acc[kk].x;
-                r.y += beta * dh.y + acc[kk].y;
-                r.z += beta * dh.z + acc[kk].z;
-                r.w += beta * dh.w + acc[kk].w;
-                O4[o] = r;
+                const size_t o = (size_t)si.grow * GE::ROW + kk * D + c * VEC;
+                const Chunk<VEC> dh = load_f32<VEC>(dH + o);
+                Chunk<VEC> r = accumulate ? load_f32<VEC>(dZ + o) : zero_chunk<VEC>();
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r.v[i] += beta * dh.v[i] + acc[kk].v[i];
+                store_f32<VEC>(dZ + o, r);
             }
         } else {
-            float4* __restrict__ P4 = reinterpret_cast<float4*>(dz_part);
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) P4[(size_t)si.slot * rs + kk * G + c] = acc[kk];
+            for (int kk = 0; kk < K; ++kk)
+                store_f32<VEC>(dz_part + (size_t)si.slot * GE::ROW + kk * D + c * VEC, acc[kk]);
         }
     }
 }
 
 // ---------------------------------------------------------------------------- pair scorer
+// Stage the u rows of Z and H (as fp32) in this wave's LDS region.
+template <int K, int D, typename T>
+__device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ Z, const T* __restrict__ H, size_t u) {
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC;
+    for (int x = lane_id(); x < GE::ROW / VEC; x += DL_WAVE) {
+        store_f32<VEC>(urow + x * VEC, Tab<T>::load(Z + u * GE::ROW + x * VEC));
+        store_f32<VEC>(urow + GE::ROW + x * VEC, Tab<T>::load(H + u * GE::ROW + x * VEC));
+    }
+}
+
 // One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
 // in LDS, every lane group then scores one pair per iteration from the gathered v rows.
-template <int K, int D, bool COEF>
+template <int K, int D, typename T, bool COEF>
 __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
-                                                              const float* __restrict__ Z,
-                                                              const float* __restrict__ H, float t,
-                                                              float* __restrict__ prob, float* __restrict__ coef_e,
+                                                              const T* __restrict__ Z, const T* __restrict__ H,
+                                                              float t, float* __restrict__ prob,
+                                                              float* __restrict__ coef_e,
                                                               float* __restrict__ coef_q) {
-    constexpr int G = D / 4;
-    constexpr int EPW = DL_WAVE / G;
-    constexpr int RS = K * G;                       // float4 per node row
-    __shared__ float4 urow[WAVES_PER_BLOCK][2 * RS];
+    using GE = Geo<K, D, T>;
+    using FL = typename GE::FL;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
+    __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int seg = wave_segment(g);
     const bool active = seg >= 0;
-    const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
-    const float4* __restrict__ H4 = reinterpret_cast<const float4*>(H);
     SegInfo si{0, 0, 0, 0, -1};
     if (active) {
         si = load_seg(g, seg);
-        for (int x = lane; x < RS; x += DL_WAVE) {
-            urow[wave][x] = Z4[(size_t)si.grow * RS + x];
-            urow[wave][RS + x] = H4[(size_t)si.grow * RS + x];
-        }
+        stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
     }
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
+    const int kb = FL::factor_base(c);
     int my_col = si.grow, my_pair = 0;
     if (si.beg + lane < si.end) {
         my_col = g.col[si.beg + lane];
@@ -443,23 +543,21 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
         const bool live = it < si.end;
         const size_t v = (size_t)__shfl(my_col, it - si.beg, DL_WAVE);
         const int q = __shfl(my_pair, it - si.beg, DL_WAVE);
-        float4 zv[K], hv[K];
+        Chunk<VEC> zv[K], hv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            zv[k] = Z4[v * RS + k * G + c];
-            hv[k] = H4[v * RS + k * G + c];
+            zv[k] = Tab<T>::load(Z + v * ROW + k * D + c * VEC);
+            hv[k] = Tab<T>::load(H + v * ROW + k * D + c * VEC);
         }
-        using FL = FactorLanes<G, K>;
-        constexpr int KP = FL::KP, VPL = FL::VPL;
         float pq[KP], ps[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            pq[k] = k < K ? dot4(urow[wave][RS + (k < K ? k : 0) * G + c], hv[k < K ? k : 0]) : 0.0f;
-            ps[k] = k < K ? dot4(urow[wave][(k < K ? k : 0) * G + c], zv[k < K ? k : 0]) : 0.0f;
+            const int kk = k < K ? k : 0;
+            pq[k] = k < K ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
+            ps[k] = k < K ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zv[kk]) : 0.0f;
         }
         TransposedReduce<KP, G / 2>::run(pq, c);
         TransposedReduce<KP, G / 2>::run(ps, c);
-        const int kb = FL::factor_base(c);
         float term = 0.0f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
@@ -478,39 +576,34 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
     }
 }
 
-// Scorer backward over the node-incidence plan: one wave per segment of node u's pair slots.
-// Partials (multi-segment rows) hold [dZ row | dH row] per slot.
-template <int K, int D>
+// Scorer backward, recomputing e_k and q_k (used when the forward did not store them): one wave per
+// segment of node u's pair slots.  Partials (multi-segment rows) hold [dZ row | dH row] per slot.
+template <int K, int D, typename T>
 __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
-                                                              const float* __restrict__ Z,
-                                                              const float* __restrict__ H, float t,
-                                                              const float* __restrict__ prob,
+                                                              const T* __restrict__ Z, const T* __restrict__ H,
+                                                              float t, const float* __restrict__ prob,
                                                               const float* __restrict__ g_prob,
                                                               float* __restrict__ dZ, float* __restrict__ dH,
                                                               float* __restrict__ part) {
-    constexpr int G = D / 4;
-    constexpr int EPW = DL_WAVE / G;
-    constexpr int RS = K * G;
-    __shared__ float4 urow[WAVES_PER_BLOCK][2 * RS];
+    using GE = Geo<K, D, T>;
+    using FL = typename GE::FL;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
+    __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int seg = wave_segment(g);
     const bool active = seg >= 0;
-    const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(Z);
-    const float4* __restrict__ H4 = reinterpret_cast<const float4*>(H);
     SegInfo si{0, 0, 0, 0, -1};
     if (active) {
         si = load_seg(g, seg);
-        for (int x = lane; x < RS; x += DL_WAVE) {
-            urow[wave][x] = Z4[(size_t)si.grow * RS + x];
-            urow[wave][RS + x] = H4[(size_t)si.grow * RS + x];
-        }
+        stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
     }
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
-    float4 accZ[K], accH[K];
+    const int kb = FL::factor_base(c);
+    Chunk<VEC> accZ[K], accH[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { accZ[k] = zero4(); accH[k] = zero4(); }
+    for (int k = 0; k < K; ++k) { accZ[k] = zero_chunk<VEC>(); accH[k] = zero_chunk<VEC>(); }
     int my_col = si.grow;
     float my_gl = 0.0f;
     if (si.beg + lane < si.end) {
@@ -520,38 +613,109 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
         my_gl = g_prob[q] * pr * (1.0f - pr);           // sigmoid backward p(1-p)
     }
     for (int base = si.beg; base < si.end; base += EPW) {
-        const int it = base + grp;
-        const bool live = it < si.end;
-        const size_t v = (size_t)__shfl(my_col, it - si.beg, DL_WAVE);
-        const float gl = __shfl(my_gl, it - si.beg, DL_WAVE);
-        float4 zv[K], hv[K];
+        const int idx = base + grp - si.beg;
+        const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
+        const float gl = __shfl(my_gl, idx, DL_WAVE);    // 0 past the segment end
+        Chunk<VEC> zv[K], hv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            zv[k] = Z4[v * RS + k * G + c];
-            hv[k] = H4[v * RS + k * G + c];
+            zv[k] = Tab<T>::load(Z + v * ROW + k * D + c * VEC);
+            hv[k] = Tab<T>::load(H + v * ROW + k * D + c * VEC);
         }
+        float pq[KP], ps[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int kk = k < K ? k : 0;
+            pq[k] = k < K ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
+            ps[k] = k < K ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zv[kk]) : 0.0f;
+        }
+        TransposedReduce<KP, G / 2>::run(pq, c);
+        TransposedReduce<KP, G / 2>::run(ps, c);
+        float ch_lane[VPL], cz_lane[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float ek = expf(div_t(ps[i], t));
+            ch_lane[i] = gl == 0.0f ? 0.0f : gl * ek;
+            cz_lane[i] = gl == 0.0f ? 0.0f : gl * pq[i] * ek / t;
+        }
+        const int gbase = lane & ~(G - 1);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float qk = group_allreduce_sum<G>(dot4(urow[wave][RS + k * G + c], hv[k]));
-            const float ek = expf(group_allreduce_sum<G>(dot4(urow[wave][k * G + c], zv[k])) / t);
-            const float ch = live ? gl * ek : 0.0f;
-            const float cz = live ? gl * qk * ek / t : 0.0f;
-            fma4(accH[k], ch, hv[k]);
-            fma4(accZ[k], cz, zv[k]);
+            const float ch = __shfl(ch_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
+            const float cz = __shfl(cz_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
+            fma_chunk(accH[k], ch, hv[k]);
+            fma_chunk(accZ[k], cz, zv[k]);
         }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) { across_groups_sum4<G>(accZ[k]); across_groups_sum4<G>(accH[k]); }
+    for (int k = 0; k < K; ++k) { across_groups_sum_chunk<G>(accZ[k]); across_groups_sum_chunk<G>(accH[k]); }
     if (grp == 0) {
-        float4* __restrict__ OZ = reinterpret_cast<float4*>(si.slot < 0 ? dZ : part);
-        float4* __restrict__ OH = reinterpret_cast<float4*>(si.slot < 0 ? dH : part);
-        const size_t oz = si.slot < 0 ? (size_t)si.grow * RS : (size_t)si.slot * 2 * RS;
-        const size_t oh = si.slot < 0 ? (size_t)si.grow * RS : (size_t)si.slot * 2 * RS + RS;
+        float* oz = si.slot < 0 ? dZ + (size_t)si.grow * ROW : part + (size_t)si.slot * 2 * ROW;
+        float* oh = si.slot < 0 ? dH + (size_t)si.grow * ROW : part + (size_t)si.slot * 2 * ROW + ROW;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            OZ[oz + k * G + c] = accZ[k];
-            OH[oh + k * G + c] = accH[k];
+            store_f32<VEC>(oz + k * D + c * VEC, accZ[k]);
+            store_f32<VEC>(oh + k * D + c * VEC, accH[k]);
         }
+    }
+}
+
+// Scorer backward from stored per-factor terms: a weighted row gather, one launch per output.
+//   PASS 0: dZ[u] = sum_inc (gl/t) * (q_k e_k) * Z[v][k]      PASS 1: dH[u] = sum_inc gl * e_k * H[v][k]
+template <int K, int D, typename T, int PASS>
+__global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
+                                                                   const T* __restrict__ X, float t,
+                                                                   const float* __restrict__ prob,
+                                                                   const float* __restrict__ g_prob,
+                                                                   const float* __restrict__ coef,
+                                                                   float* __restrict__ out, float* __restrict__ part) {
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
+    const int lane = lane_id();
+    const int c = lane % G, grp = lane / G;
+    const SegInfo si = load_seg(g, seg);
+    Chunk<VEC> acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
+    int my_col = si.grow, my_pair = 0;
+    float my_gl = 0.0f;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        my_pair = inc_pair[si.beg + lane];
+        const float pr = prob[my_pair];
+        my_gl = g_prob[my_pair] * pr * (1.0f - pr);      // sigmoid backward p(1-p)
+        if (PASS == 0) my_gl = div_t(my_gl, t);
+    }
+    for (int base = si.beg; base < si.end; base += EPW) {
+        const int idx = base + grp - si.beg;
+        const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
+        const int q = __shfl(my_pair, idx, DL_WAVE);
+        const float gl = __shfl(my_gl, idx, DL_WAVE);     // 0 past the segment end
+        Chunk<VEC> xv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[k] = Tab<T>::load(X + v * ROW + k * D + c * VEC);
+        float ck[K];
+        if constexpr (K % 4 == 0) {
+#pragma unroll
+            for (int k = 0; k < K; k += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(coef + (size_t)q * K + k);
+                ck[k] = t4.x; ck[k + 1] = t4.y; ck[k + 2] = t4.z; ck[k + 3] = t4.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) ck[k] = coef[(size_t)q * K + k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) fma_chunk(acc[k], gl * ck[k], xv[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) across_groups_sum_chunk<G>(acc[k]);
+    if (grp == 0) {
+        float* o = si.slot < 0 ? out + (size_t)si.grow * ROW : part + (size_t)si.slot * ROW;
+#pragma unroll
+        for (int k = 0; k < K; ++k) store_f32<VEC>(o + k * D + c * VEC, acc[k]);
     }
 }
 
@@ -569,238 +733,172 @@ static void launch_vec_combine(const dl_csr_plan* g, int K, const float* part, i
                        part, mode, s_raw, out);
 }
 
-template <int K, int D>
-int route_fwd_t(const dl_csr_plan* g, const float* Z, float t, uint8_t* p, float* a, float* s, float* s_part,
-                hipStream_t st) {
-    hipLaunchKernelGGL((route_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, t, p, a, s,
-                       s_part);
-    launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
-    return check_launch("route_fwd(fast)");
-}
+template <int K, int D, typename T>
+struct Ops {
+    static constexpr int ROW = K * D;
 
-template <int K, int D>
-int aggregate_fwd_t(const dl_csr_plan* g, const float* Z, float beta, const uint8_t* p, const float* a,
-                    const float* s, float* H, float* h_part, hipStream_t st) {
-    constexpr int TOT4 = K * D / 4;
-    hipLaunchKernelGGL((aggregate_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, beta, p,
-                       a, s, H, h_part);
-    if (g->n_multi > 0)
-        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, TOT4, 0, Z,
-                           beta, 1.0f - beta, H, 0);
-    return check_launch("aggregate_fwd(fast)");
-}
-
-template <int K, int D>
-int bwd_phase1_t(const dl_csr_plan* g, const float* Z, float beta, const uint8_t* p, const float* a, const float* s,
-                 const float* dH, float* dw, float* dwr, float* ds, float* ds_part, hipStream_t st) {
-    hipLaunchKernelGGL((bwd_phase1_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, dH, beta,
-                       p, a, s, dw, dwr, ds, ds_part);
-    launch_vec_combine(g, K, ds_part, 1, s, ds, st);
-    return check_launch("route_aggregate_bwd_phase1(fast)");
-}
-
-template <int K, int D>
-int bwd_phase2_t(const dl_csr_plan* g, const float* Z, float beta, float t, const uint8_t* p, const float* a,
-                 const float* s, const float* dH, const float* dw, const float* dwr, const float* ds, float* dZ,
-                 int accumulate, float* dz_part, hipStream_t st) {
-    constexpr int TOT4 = K * D / 4;
-    hipLaunchKernelGGL((bwd_phase2_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, Z, dH, beta,
-                       t, p, a, s, dw, dwr, ds, dZ, accumulate, dz_part);
-    if (g->n_multi > 0)
-        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, dz_part, TOT4, 0, dH,
-                           beta, 1.0f, dZ, accumulate);
-    return check_launch("route_aggregate_bwd_phase2(fast)");
-}
-
-template <int K, int D>
-int score_fwd_t(const dl_pair_incidence* by_u, const float* Z, const float* H, float t, float* prob, float* coef,
-                hipStream_t st) {
-    const dl_csr_plan* g = &by_u->csr;
-    float* coef_q = coef ? coef + (size_t)by_u->n_pairs * K : nullptr;
-    if (coef)
-        hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
-                           by_u->inc_pair, Z, H, t, prob, coef, coef_q);
-    else
-        hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, false>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
-                           by_u->inc_pair, Z, H, t, prob, coef, coef_q);
-    return check_launch("score_pairs_fwd(fast)");
-}
-
-// Scorer backward from stored per-factor terms: a weighted row gather, one launch per output.
-//   PASS 0: dZ[u] = sum_inc gl * (q_k e_k) / t * Z[v][k]      PASS 1: dH[u] = sum_inc gl * e_k * H[v][k]
-template <int K, int D, int PASS>
-__global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
-                                                                   const float* __restrict__ X, float t,
-                                                                   const float* __restrict__ prob,
-                                                                   const float* __restrict__ g_prob,
-                                                                   const float* __restrict__ coef,
-                                                                   float* __restrict__ out, float* __restrict__ part) {
-    constexpr int G = D / 4;
-    constexpr int EPW = DL_WAVE / G;
-    constexpr int RS = K * G;
-    constexpr int K4 = (K + 3) / 4;
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
-    const int lane = lane_id();
-    const int c = lane % G, grp = lane / G;
-    const SegInfo si = load_seg(g, seg);
-    const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X);
-    float4 acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = zero4();
-    int my_col = si.grow, my_pair = 0;
-    float my_gl = 0.0f;
-    if (si.beg + lane < si.end) {
-        my_col = g.col[si.beg + lane];
-        my_pair = inc_pair[si.beg + lane];
-        const float pr = prob[my_pair];
-        my_gl = g_prob[my_pair] * pr * (1.0f - pr);      // sigmoid backward p(1-p)
-        if (PASS == 0) my_gl = div_t(my_gl, t);          // NOTE: (gl/t)*qe instead of gl*qe/t (rounding-level)
+    static int route_fwd(const dl_csr_plan* g, const void* Z, float t, uint8_t* p, float* a, float* s, float* s_part,
+                         hipStream_t st) {
+        hipLaunchKernelGGL((route_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z, t, p,
+                           a, s, s_part);
+        launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
+        return check_launch("route_fwd(fast)");
     }
-    for (int base = si.beg; base < si.end; base += EPW) {
-        const int idx = base + grp - si.beg;
-        const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
-        const int q = __shfl(my_pair, idx, DL_WAVE);
-        const float gl = __shfl(my_gl, idx, DL_WAVE);     // 0 for lanes past the segment end
-        float4 xv[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) xv[k] = X4[v * RS + k * G + c];
-        float ck[K4 * 4];
-        if constexpr (K % 4 == 0) {
-            const float4* __restrict__ C4 = reinterpret_cast<const float4*>(coef + (size_t)q * K);
-#pragma unroll
-            for (int i = 0; i < K4; ++i) {
-                const float4 t4 = C4[i];
-                ck[4 * i] = t4.x; ck[4 * i + 1] = t4.y; ck[4 * i + 2] = t4.z; ck[4 * i + 3] = t4.w;
+
+    static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
+                             const float* s, void* H, float* h_part, hipStream_t st) {
+        hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                           beta, p, a, s, (T*)H, h_part);
+        if (g->n_multi > 0)
+            hipLaunchKernelGGL((row_combine_kernel<ROW, T, T>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, ROW,
+                               (const T*)Z, beta, 1.0f - beta, (T*)H, 0);
+        return check_launch("aggregate_fwd(fast)");
+    }
+
+    static int bwd_phase1(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
+                          const float* s, const float* dH, float* dw, float* dwr, float* ds, float* ds_part,
+                          hipStream_t st) {
+        hipLaunchKernelGGL((bwd_phase1_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                           dH, beta, p, a, s, dw, dwr, ds, ds_part);
+        launch_vec_combine(g, K, ds_part, 1, s, ds, st);
+        return check_launch("route_aggregate_bwd_phase1(fast)");
+    }
+
+    static int bwd_phase2(const dl_csr_plan* g, const void* Z, float beta, float t, const uint8_t* p, const float* a,
+                          const float* s, const float* dH, const float* dw, const float* dwr, const float* ds,
+                          float* dZ, int accumulate, float* dz_part, hipStream_t st) {
+        hipLaunchKernelGGL((bwd_phase2_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                           dH, beta, t, p, a, s, dw, dwr, ds, dZ, accumulate, dz_part);
+        if (g->n_multi > 0)
+            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
+                               dz_part, ROW, dH, beta, 1.0f, dZ, accumulate);
+        return check_launch("route_aggregate_bwd_phase2(fast)");
+    }
+
+    static int score_fwd(const dl_pair_incidence* by_u, const void* Z, const void* H, float t, float* prob,
+                         float* coef, hipStream_t st) {
+        const dl_csr_plan* g = &by_u->csr;
+        float* coef_q = coef ? coef + (size_t)by_u->n_pairs * K : nullptr;
+        if (coef)
+            hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, T, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
+                               by_u->inc_pair, (const T*)Z, (const T*)H, t, prob, coef, coef_q);
+        else
+            hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, T, false>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
+                               by_u->inc_pair, (const T*)Z, (const T*)H, t, prob, coef, coef_q);
+        return check_launch("score_pairs_fwd(fast)");
+    }
+
+    static int score_bwd(const dl_pair_incidence* inc, const void* Z, const void* H, float t, const float* prob,
+                         const float* g_prob, const float* coef, float* dZ, float* dH, float* part, hipStream_t st) {
+        const dl_csr_plan* g = &inc->csr;
+        const float* no_x = nullptr;
+        if (coef) {
+            const float* coef_q = coef + (size_t)inc->n_pairs * K;
+            float* part_h = part + (size_t)g->n_slots * ROW;
+            hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, T, 0>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
+                               inc->inc_pair, (const T*)Z, t, prob, g_prob, coef_q, dZ, part);
+            hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, T, 1>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
+                               inc->inc_pair, (const T*)H, t, prob, g_prob, coef, dH, part_h);
+            if (g->n_multi > 0) {
+                hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
+                                   part, ROW, no_x, 0.0f, 1.0f, dZ, 0);
+                hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
+                                   part_h, ROW, no_x, 0.0f, 1.0f, dH, 0);
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) ck[k] = coef[(size_t)q * K + k];
+            return check_launch("score_pairs_bwd(fast, stored terms)");
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k) fma4(acc[k], gl * ck[k], xv[k]);
+        hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
+                           (const T*)Z, (const T*)H, t, prob, g_prob, dZ, dH, part);
+        if (g->n_multi > 0) {
+            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part,
+                               2 * ROW, no_x, 0.0f, 1.0f, dZ, 0);
+            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
+                               part + ROW, 2 * ROW, no_x, 0.0f, 1.0f, dH, 0);
+        }
+        return check_launch("score_pairs_bwd(fast)");
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) across_groups_sum4<G>(acc[k]);
-    if (grp == 0) {
-        float4* __restrict__ O4 = reinterpret_cast<float4*>(si.slot < 0 ? out : part);
-        const size_t o = si.slot < 0 ? (size_t)si.grow * RS : (size_t)si.slot * RS;
-#pragma unroll
-        for (int k = 0; k < K; ++k) O4[o + k * G + c] = acc[k];
-    }
-}
-
-template <int K, int D>
-int score_bwd_coef_t(const dl_pair_incidence* inc, const float* Z, const float* H, float t, const float* prob,
-                     const float* g_prob, const float* coef, float* dZ, float* dH, float* part, hipStream_t st) {
-    constexpr int TOT4 = K * D / 4;
-    const dl_csr_plan* g = &inc->csr;
-    const float* coef_e = coef;
-    const float* coef_q = coef + (size_t)inc->n_pairs * K;
-    float* part_h = part + (size_t)g->n_slots * K * D;
-    hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, 0>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
-                       Z, t, prob, g_prob, coef_q, dZ, part);
-    hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, 1>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
-                       H, t, prob, g_prob, coef_e, dH, part_h);
-    if (g->n_multi > 0) {
-        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part, TOT4, 0, Z, 0.0f,
-                           1.0f, dZ, 0);
-        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part_h, TOT4, 0, Z,
-                           0.0f, 1.0f, dH, 0);
-    }
-    return check_launch("score_pairs_bwd(fast, stored terms)");
-}
-
-template <int K, int D>
-int score_bwd_t(const dl_pair_incidence* inc, const float* Z, const float* H, float t, const float* prob,
-                const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st) {
-    constexpr int TOT4 = K * D / 4;
-    const dl_csr_plan* g = &inc->csr;
-    hipLaunchKernelGGL((score_bwd_seg_kernel<K, D>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
-                       inc->inc_pair, Z, H, t, prob, g_prob, dZ, dH, part);
-    if (g->n_multi > 0) {
-        // X is unused (cx = 0) but must be a valid row pointer: pass Z
-        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part, 2 * TOT4, 0, Z,
-                           0.0f, 1.0f, dZ, 0);
-        hipLaunchKernelGGL((row_combine_kernel<TOT4>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part, 2 * TOT4, TOT4,
-                           Z, 0.0f, 1.0f, dH, 0);
-    }
-    return check_launch("score_pairs_bwd(fast)");
-}
+};
 
 }  // namespace fast
 
-// (K, D) pairs with a tuned instantiation.  D must be 4 * a power of two <= 256.
-#define DL_FAST_SHAPES(X) \
+// (K, D) pairs with a tuned instantiation.  D must be VEC * a power of two (VEC = 4 fp32 / 8 bf16).
+#define DL_FAST_SHAPES_F32(X) \
     X(4, 32) X(8, 64) X(16, 128) X(5, 32) X(5, 64) X(10, 32) X(10, 64) X(20, 32) X(8, 32) X(4, 64) X(4, 8) X(8, 8) X(3, 8)
+#define DL_FAST_SHAPES_BF16(X) X(4, 32) X(8, 64) X(16, 128) X(5, 64) X(8, 32)
 
-#define DL_DISPATCH(CALL)                                     \
-    DL_FAST_SHAPES(CALL)                                      \
-    set_error("no tuned kernel for K=%d d=%d", K, d);         \
-    return DL_E_ARG;
-
-bool fast_supported(int K, int d) {
+bool fast_supported(int K, int d, int dtype) {
 #define X(KK, DD) if (K == KK && d == DD) return true;
-    DL_FAST_SHAPES(X)
+    if (dtype == DL_F32) { DL_FAST_SHAPES_F32(X) }
+    if (dtype == DL_BF16) { DL_FAST_SHAPES_BF16(X) }
 #undef X
     return false;
 }
 
-int fast_route_fwd(const dl_csr_plan* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
-                   float* s_part, hipStream_t st) {
-#define X(KK, DD) if (K == KK && d == DD) return fast::route_fwd_t<KK, DD>(g, Z, t, p, a, s, s_part, st);
+// CALL(OPS) is expanded with OPS = fast::Ops<K, D, T> of the matching instantiation
+#define DL_DISPATCH(CALL)                                                                         \
+    if (dtype == DL_F32) {                                                                        \
+        DL_FAST_SHAPES_F32(CALL##_F32)                                                            \
+    } else if (dtype == DL_BF16) {                                                                \
+        DL_FAST_SHAPES_BF16(CALL##_BF16)                                                          \
+    }                                                                                             \
+    set_error("no tuned kernel for K=%d d=%d dtype=%d", K, d, dtype);                             \
+    return DL_E_ARG;
+
+int fast_route_fwd(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float t, uint8_t* p, float* a,
+                   float* s, float* s_part, hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::route_fwd(g, Z, t, p, a, s, s_part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::route_fwd(g, Z, t, p, a, s, s_part, st);
     DL_DISPATCH(X)
-#undef X
+#undef X_F32
+#undef X_BF16
 }
 
-int fast_aggregate_fwd(const dl_csr_plan* g, const float* Z, int K, int d, float beta, const uint8_t* p,
-                       const float* a, const float* s, float* H, float* h_part, hipStream_t st) {
-#define X(KK, DD) if (K == KK && d == DD) return fast::aggregate_fwd_t<KK, DD>(g, Z, beta, p, a, s, H, h_part, st);
+int fast_aggregate_fwd(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, const uint8_t* p,
+                       const float* a, const float* s, void* H, float* h_part, hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::aggregate_fwd(g, Z, beta, p, a, s, H, h_part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::aggregate_fwd(g, Z, beta, p, a, s, H, h_part, st);
     DL_DISPATCH(X)
-#undef X
+#undef X_F32
+#undef X_BF16
 }
 
-int fast_bwd_phase1(const dl_csr_plan* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+int fast_bwd_phase1(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, const uint8_t* p,
                     const float* a, const float* s, const float* dH, float* dw, float* dwr, float* ds,
                     float* ds_part, hipStream_t st) {
-#define X(KK, DD) \
-    if (K == KK && d == DD) return fast::bwd_phase1_t<KK, DD>(g, Z, beta, p, a, s, dH, dw, dwr, ds, ds_part, st);
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::bwd_phase1(g, Z, beta, p, a, s, dH, dw, dwr, ds, ds_part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::bwd_phase1(g, Z, beta, p, a, s, dH, dw, dwr, ds, ds_part, st);
     DL_DISPATCH(X)
-#undef X
+#undef X_F32
+#undef X_BF16
 }
 
-int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
-                    const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
-                    const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st) {
-#define X(KK, DD)           \
-    if (K == KK && d == DD) \
-        return fast::bwd_phase2_t<KK, DD>(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, dz_part, st);
+int fast_bwd_phase2(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, float t,
+                    const uint8_t* p, const float* a, const float* s, const float* dH, const float* dw,
+                    const float* dwr, const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, dz_part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, dz_part, st);
     DL_DISPATCH(X)
-#undef X
+#undef X_F32
+#undef X_BF16
 }
 
-int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const float* Z, const float* H, int K, int d, float t,
-                         float* prob, float* coef, hipStream_t st) {
-#define X(KK, DD) if (K == KK && d == DD) return fast::score_fwd_t<KK, DD>(by_u, Z, H, t, prob, coef, st);
+int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const void* Z, const void* H, int K, int d, int dtype,
+                         float t, float* prob, float* coef, hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::score_fwd(by_u, Z, H, t, prob, coef, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::score_fwd(by_u, Z, H, t, prob, coef, st);
     DL_DISPATCH(X)
-#undef X
+#undef X_F32
+#undef X_BF16
 }
 
-int fast_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
-                         const float* prob, const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st) {
-#define X(KK, DD) \
-    if (K == KK && d == DD) return fast::score_bwd_t<KK, DD>(inc, Z, H, t, prob, g_prob, dZ, dH, part, st);
+int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype,
+                         float t, const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
+                         float* part, hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::score_bwd(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::score_bwd(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
     DL_DISPATCH(X)
-#undef X
-}
-
-int fast_score_pairs_bwd_coef(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
-                              const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
-                              float* part, hipStream_t st) {
-#define X(KK, DD) \
-    if (K == KK && d == DD) return fast::score_bwd_coef_t<KK, DD>(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
-    DL_DISPATCH(X)
-#undef X
+#undef X_F32
+#undef X_BF16
 }
 
 }  // namespace dl

@@ -21,24 +21,22 @@ int generic_bwd_phase2(const dl_csr_plan* c, const float* Z, int K, int d, float
                        const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
                        const float* ds, float* dZ, int accumulate, hipStream_t st);
 
-// tuned, per-(K,D) instantiations (dl_fast.hip)
-bool fast_supported(int K, int d);
-int fast_route_fwd(const dl_csr_plan* g, const float* Z, int K, int d, float t, uint8_t* p, float* a, float* s,
-                   float* s_part, hipStream_t st);
-int fast_aggregate_fwd(const dl_csr_plan* g, const float* Z, int K, int d, float beta, const uint8_t* p,
-                       const float* a, const float* s, float* H, float* h_part, hipStream_t st);
-int fast_bwd_phase1(const dl_csr_plan* g, const float* Z, int K, int d, float beta, const uint8_t* p,
+// tuned, per-(K, D, table type) instantiations (dl_fast.hip)
+bool fast_supported(int K, int d, int dtype);
+int fast_route_fwd(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float t, uint8_t* p, float* a,
+                   float* s, float* s_part, hipStream_t st);
+int fast_aggregate_fwd(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, const uint8_t* p,
+                       const float* a, const float* s, void* H, float* h_part, hipStream_t st);
+int fast_bwd_phase1(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, const uint8_t* p,
                     const float* a, const float* s, const float* dH, float* dw, float* dwr, float* ds,
                     float* ds_part, hipStream_t st);
-int fast_bwd_phase2(const dl_csr_plan* g, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
-                    const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
-                    const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
-int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const float* Z, const float* H, int K, int d, float t,
-                         float* prob, float* coef, hipStream_t st);
-int fast_score_pairs_bwd_coef(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
-                              const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
-                              float* part, hipStream_t st);
-int fast_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
-                         const float* prob, const float* g_prob, float* dZ, float* dH, float* part, hipStream_t st);
+int fast_bwd_phase2(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, float t,
+                    const uint8_t* p, const float* a, const float* s, const float* dH, const float* dw,
+                    const float* dwr, const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
+int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const void* Z, const void* H, int K, int d, int dtype,
+                         float t, float* prob, float* coef, hipStream_t st);
+int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype,
+                         float t, const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
+                         float* part, hipStream_t st);
 
 }  // namespace dl

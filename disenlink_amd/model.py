@@ -43,8 +43,12 @@ class Factor2(nn.Module):
 
 
 class Disentangle(nn.Module):
-    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1):
+    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1, table_dtype=torch.float32):
+        """``table_dtype`` (extension; the reference has none): storage type of the gathered Z / H tables in
+        ``forward_pairs`` — torch.float32 (reference precision) or torch.bfloat16 (half the gather bytes,
+        fp32 arithmetic and gradients)."""
         super().__init__()
+        self.table_dtype = table_dtype
         # creation order == the reference's (model.py:93-99), so a seeded init draws the same stream
         if nhid == 1:
             factors = [Factor(nfeat, nebed) for _ in range(nfactor)]
@@ -100,6 +104,5 @@ class Disentangle(nn.Module):
     def forward_pairs(self, x, graph: Graph, pairs: PairList):
         """(emb [N,K*d], prob [P]) — the same model evaluated on a pair list only."""
         Z = self.project(x)
-        H = ops.RouteAggregate.apply(Z, graph, float(self.beta), float(self.temperature))
-        prob = ops.ScorePairs.apply(Z, H, pairs, float(self.temperature))
+        H, prob = ops.HotPathPairs.apply(Z, graph, pairs, float(self.beta), float(self.temperature), self.table_dtype)
         return H.view(H.shape[0], -1), prob

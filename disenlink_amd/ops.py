@@ -32,6 +32,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _tab(t: torch.Tensor):
+    """A node table (Z or H): fp32 or bf16 storage -> (contiguous tensor, dl_dtype code)."""
+    if t.dtype == torch.float32:
+        return t.contiguous(), _lib.DL_F32
+    if t.dtype == torch.bfloat16:
+        return t.contiguous(), _lib.DL_BF16
+    raise TypeError(f"node tables must be float32 or bfloat16, got {t.dtype}")
+
+
 def _nkd(Z: torch.Tensor):
     if Z.dim() != 3:
         raise ValueError("Z/H must be [N, K, d]")
@@ -73,14 +82,14 @@ def route_fwd(g: Graph, Z: torch.Tensor, t: float, s_out: torch.Tensor | None = 
     """-> p uint8[E], a f32[E], s f32[N,K] (raw sums; only the graph's rows are written).
     model.py:56-72 on the edges of adj."""
     lib = _lib.load()
-    Z = _f32c(Z)
+    Z, dt = _tab(Z)
     _need_cuda(Z, g.rowptr)
     N, K, d = _check_rows(g, Z)
     p = torch.empty(g.n_edges, dtype=torch.uint8, device=Z.device)
     a = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
     s = torch.empty((N, K), dtype=torch.float32, device=Z.device) if s_out is None else s_out
     ws = _workspace(g.c_plan(), Z.device, K, d)
-    _lib.check(lib.dl_route_fwd(g.c_struct(), Z.data_ptr(), K, d, float(t), p.data_ptr(), a.data_ptr(),
+    _lib.check(lib.dl_route_fwd(g.c_struct(), Z.data_ptr(), K, d, dt, float(t), p.data_ptr(), a.data_ptr(),
                                 s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_route_fwd")
     return p, a, s
 
@@ -88,12 +97,14 @@ def route_fwd(g: Graph, Z: torch.Tensor, t: float, s_out: torch.Tensor | None = 
 def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s, H_out: torch.Tensor | None = None):
     """-> H f32[N,K,d] (only the graph's rows are written).  model.py:73-75."""
     lib = _lib.load()
-    Z = _f32c(Z)
+    Z, dt = _tab(Z)
     _need_cuda(Z, g.rowptr, p, a, s)
     N, K, d = _check_rows(g, Z)
     H = torch.empty_like(Z) if H_out is None else H_out
+    if H.dtype != Z.dtype:
+        raise TypeError("H must have the storage type of Z")
     ws = _workspace(g.c_plan(), Z.device, K, d)
-    _lib.check(lib.dl_aggregate_fwd(g.c_struct(), Z.data_ptr(), K, d, float(beta), p.data_ptr(), a.data_ptr(),
+    _lib.check(lib.dl_aggregate_fwd(g.c_struct(), Z.data_ptr(), K, d, dt, float(beta), p.data_ptr(), a.data_ptr(),
                                     s.data_ptr(), H.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                "dl_aggregate_fwd")
     return H
@@ -103,11 +114,11 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_
     """-> prob f32[P].  model.py:109-113 at the listed pairs.  ``pairs`` (the PairList the index arrays
     belong to) enables the LDS-staged, XCD-sliced kernel; without it every pair is scored on its own."""
     lib = _lib.load()
-    Z, H = _f32c(Z), _f32c(H)
+    (Z, dt), (H, dth) = _tab(Z), _tab(H)
     _need_cuda(Z, H, pu, pv)
     N, K, d = _nkd(Z)
-    if H.shape != Z.shape:
-        raise ValueError("Z and H differ in shape")
+    if H.shape != Z.shape or dt != dth:
+        raise ValueError("Z and H differ in shape or storage type")
     if pu.dtype != torch.int32 or pv.dtype != torch.int32:
         raise TypeError("pair indices must be int32")
     P = int(pu.numel())
@@ -115,9 +126,9 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_
     by_u = pairs.c_struct_by_u() if pairs is not None else None
     # per-factor logit terms for the backward: only the tuned scorer produces them
     coef = None
-    if want_coef and pairs is not None and lib.dl_has_fast_path(K, d) and not lib.dl_set_force_generic(-1):
+    if want_coef and pairs is not None and lib.dl_has_fast_path_dtype(K, d, dt) and not lib.dl_set_force_generic(-1):
         coef = torch.empty((2, P, K), dtype=torch.float32, device=Z.device)
-    _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, float(t), pu.data_ptr(), pv.data_ptr(),
+    _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), pu.data_ptr(), pv.data_ptr(),
                                       P, by_u, prob.data_ptr(), coef.data_ptr() if coef is not None else None,
                                       _stream()), "dl_score_pairs_fwd")
     return (prob, coef) if want_coef else prob
@@ -126,18 +137,18 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_
 def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, dH_out=None, coef=None):
     """-> dZ, dH f32[N,K,d] (rows of the incidence plan are written)."""
     lib = _lib.load()
-    Z, H, prob, g_prob = _f32c(Z), _f32c(H), _f32c(prob), _f32c(g_prob)
+    (Z, dt), (H, _dth), prob, g_prob = _tab(Z), _tab(H), _f32c(prob), _f32c(g_prob)
     _need_cuda(Z, H, prob, g_prob, pairs.inc.rowptr)
     N, K, d = _nkd(Z)
     if prob.numel() != g_prob.numel():
         raise ValueError("prob / g_prob lengths differ")
-    dZ = torch.empty_like(Z) if dZ_out is None else dZ_out
-    dH = torch.empty_like(Z) if dH_out is None else dH_out
+    dZ = torch.empty(Z.shape, dtype=torch.float32, device=Z.device) if dZ_out is None else dZ_out
+    dH = torch.empty(Z.shape, dtype=torch.float32, device=Z.device) if dH_out is None else dH_out
     inc = pairs.c_struct(int(prob.numel()))
     ws = _workspace(pairs.c_plan(), Z.device, K, d)
     if coef is not None and tuple(coef.shape) != (2, prob.numel(), K):
         raise ValueError("coef must be the [2, P, K] array of score_pairs_fwd for the same pair list")
-    _lib.check(lib.dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), K, d, float(t), inc, prob.data_ptr(),
+    _lib.check(lib.dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), K, d, dt, float(t), inc, prob.data_ptr(),
                                       g_prob.data_ptr(), coef.data_ptr() if coef is not None else None,
                                       dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(), ws.numel(),
                                       _stream()), "dl_score_pairs_bwd")
@@ -147,17 +158,17 @@ def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, 
 def route_aggregate_bwd(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_accum=None) -> torch.Tensor:
     """-> dZ f32[N,K,d] (added onto ``dZ_accum`` in place when given).  Unsharded graphs only."""
     lib = _lib.load()
-    Z, dH = _f32c(Z), _f32c(dH)
+    (Z, dt), dH = _tab(Z), _f32c(dH)
     _need_cuda(Z, dH, g.rowptr, p, a, s)
     N, K, d = _check_rows(g, Z)
     if dZ_accum is None:
-        dZ, acc = torch.empty_like(Z), 0
+        dZ, acc = torch.empty(Z.shape, dtype=torch.float32, device=Z.device), 0
     else:
-        if not dZ_accum.is_contiguous() or dZ_accum.shape != Z.shape:
-            raise ValueError("dZ_accum must be a contiguous [N,K,d] tensor")
+        if not dZ_accum.is_contiguous() or dZ_accum.shape != Z.shape or dZ_accum.dtype != torch.float32:
+            raise ValueError("dZ_accum must be a contiguous fp32 [N,K,d] tensor")
         dZ, acc = dZ_accum, 1
     ws = _workspace(g.c_plan(), Z.device, K, d)
-    _lib.check(lib.dl_route_aggregate_bwd(g.c_struct(), Z.data_ptr(), K, d, float(beta), float(t), p.data_ptr(),
+    _lib.check(lib.dl_route_aggregate_bwd(g.c_struct(), Z.data_ptr(), K, d, dt, float(beta), float(t), p.data_ptr(),
                                           a.data_ptr(), s.data_ptr(), dH.data_ptr(), dZ.data_ptr(), acc,
                                           ws.data_ptr(), ws.numel(), _stream()), "dl_route_aggregate_bwd")
     return dZ
@@ -166,13 +177,13 @@ def route_aggregate_bwd(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_accu
 def route_aggregate_bwd_phase1(g: Graph, Z, beta: float, p, a, s, dH, ds_out: torch.Tensor):
     """-> dw, dwr f32[E]; writes ds[N,K] rows of the graph (all-gather ds before phase 2 when sharded)."""
     lib = _lib.load()
-    Z, dH = _f32c(Z), _f32c(dH)
+    (Z, dt), dH = _tab(Z), _f32c(dH)
     _need_cuda(Z, dH, g.rowptr, p, a, s, ds_out)
     N, K, d = _check_rows(g, Z)
     dw = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
     dwr = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
     ws = _workspace(g.c_plan(), Z.device, K, d)
-    _lib.check(lib.dl_route_aggregate_bwd_phase1(g.c_struct(), Z.data_ptr(), K, d, float(beta), p.data_ptr(),
+    _lib.check(lib.dl_route_aggregate_bwd_phase1(g.c_struct(), Z.data_ptr(), K, d, dt, float(beta), p.data_ptr(),
                                                  a.data_ptr(), s.data_ptr(), dH.data_ptr(), dw.data_ptr(),
                                                  dwr.data_ptr(), ds_out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  _stream()), "dl_route_aggregate_bwd_phase1")
@@ -182,11 +193,11 @@ def route_aggregate_bwd_phase1(g: Graph, Z, beta: float, p, a, s, dH, ds_out: to
 def route_aggregate_bwd_phase2(g: Graph, Z, beta: float, t: float, p, a, s, dH, dw, dwr, ds, dZ_out: torch.Tensor,
                                accumulate: bool):
     lib = _lib.load()
-    Z, dH = _f32c(Z), _f32c(dH)
+    (Z, dt), dH = _tab(Z), _f32c(dH)
     _need_cuda(Z, dH, g.rowptr, p, a, s, ds, dZ_out)
     N, K, d = _check_rows(g, Z)
     ws = _workspace(g.c_plan(), Z.device, K, d)
-    _lib.check(lib.dl_route_aggregate_bwd_phase2(g.c_struct(), Z.data_ptr(), K, d, float(beta), float(t),
+    _lib.check(lib.dl_route_aggregate_bwd_phase2(g.c_struct(), Z.data_ptr(), K, d, dt, float(beta), float(t),
                                                  p.data_ptr(), a.data_ptr(), s.data_ptr(), dH.data_ptr(),
                                                  dw.data_ptr(), dwr.data_ptr(), ds.data_ptr(), dZ_out.data_ptr(),
                                                  1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()),
@@ -213,6 +224,35 @@ class RouteAggregate(torch.autograd.Function):
         Z, a, s = ctx.saved_tensors
         dZ = route_aggregate_bwd(ctx.graph, Z, ctx.beta, ctx.t, ctx.p, a, s, dH.contiguous())
         return dZ, None, None, None
+
+
+class HotPathPairs(torch.autograd.Function):
+    """Z [N,K,d] fp32 -> (emb [N,K,d] fp32, prob [P]): route + aggregate + pair scorer as ONE autograd node.
+    ``table_dtype`` (torch.float32 / torch.bfloat16) is the storage type of the gathered Z and H tables;
+    arithmetic and every gradient stay fp32 (the cast of Z happens inside, so dZ comes back in fp32)."""
+
+    @staticmethod
+    def forward(ctx, Z, graph: Graph, pairs: PairList, beta: float, t: float, table_dtype):
+        Zt = _f32c(Z) if table_dtype == torch.float32 else _f32c(Z).to(table_dtype)
+        p, a, s = route_fwd(graph, Zt, t)
+        H = aggregate_fwd(graph, Zt, beta, p, a, s)
+        if ctx.needs_input_grad[0]:
+            prob, coef = score_pairs_fwd(Zt, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+        else:
+            prob, coef = score_pairs_fwd(Zt, H, pairs.pu, pairs.pv, t, pairs), None
+        ctx.graph, ctx.pairs, ctx.beta, ctx.t, ctx.p, ctx.coef = graph, pairs, beta, t, p, coef
+        ctx.save_for_backward(Zt, H, a, s, prob)
+        return H.float(), prob
+
+    @staticmethod
+    def backward(ctx, g_emb, g_prob):
+        Zt, H, a, s, prob = ctx.saved_tensors
+        g_prob = torch.zeros_like(prob) if g_prob is None else g_prob.contiguous()
+        dZ, dH = score_pairs_bwd(Zt, H, ctx.pairs, ctx.t, prob, g_prob, coef=ctx.coef)
+        if g_emb is not None:
+            dH += g_emb
+        route_aggregate_bwd(ctx.graph, Zt, ctx.beta, ctx.t, ctx.p, a, s, dH, dZ_accum=dZ)
+        return dZ, None, None, None, None, None
 
 
 class ScorePairs(torch.autograd.Function):

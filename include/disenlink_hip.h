@@ -16,9 +16,10 @@
  *     so the caller's streams and allocations are valid here.
  *   - return 0 on success, a negative DL_E_* code on error; dl_last_error() returns the
  *     message of the calling thread's last failing call.
- *   - layouts: Z, H, dZ, dH are fp32 [n_total][K][d] row-major (== torch.cat(h_k, dim=1) of
- *     model.py:114); indices int32; factor ids uint8; s is [n_total][K] RAW row sums (the
- *     zero -> 1 substitution of model.py:72 is applied where s is read).
+ *   - layouts: Z, H are [n_total][K][d] row-major (== torch.cat(h_k, dim=1) of model.py:114) in the
+ *     storage type named by the `dtype` argument (fp32 or bf16); dZ, dH are always fp32 of the same
+ *     shape; indices int32; factor ids uint8; s is fp32 [n_total][K] RAW row sums (the zero -> 1
+ *     substitution of model.py:72 is applied where s is read).
  *   - sharding: a plan may cover only rows [row_offset, row_offset + n_rows) of the n_total
  *     nodes (one shard per GPU).  Node-indexed arrays are always indexed by GLOBAL node id and
  *     only the plan's rows are written; per-entry arrays (p, a, ...) are local to the plan.
@@ -41,6 +42,11 @@ extern "C" {
 #define DL_E_WORKSPACE  -3   /* workspace missing or too small */
 
 #define DL_MAX_FACTORS  64   /* K <= 64 */
+
+/* Storage type of the node tables Z and H.  Arithmetic, per-edge values, probabilities and every
+ * gradient are fp32 in both cases; bf16 only halves the bytes of the gathered rows (tuned kernels
+ * only; the reference has no bf16 path — parity is defined against the fp32 restatement). */
+typedef enum dl_dtype { DL_F32 = 0, DL_BF16 = 1 } dl_dtype;
 
 /* A CSR over (a shard of) the nodes plus the segment plan that balances skewed rows: every row is
  * cut into >= 1 segments of <= seg_len consecutive entries; one wavefront owns one segment.  Rows
@@ -94,6 +100,7 @@ const char* dl_last_error(void);
 
 /* 1 if (K,d) runs on the tuned wavefront-tiled kernels, 0 if it falls back to the generic ones. */
 int dl_has_fast_path(int K, int d);
+int dl_has_fast_path_dtype(int K, int d, dl_dtype dtype);
 /* Force the generic kernels (parity cross-check of the two implementations): 1 = on, 0 = off,
  * negative = query only.  Returns the previous value. */
 int dl_set_force_generic(int on);
@@ -105,16 +112,16 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
  *   per edge e=(i,j):  sigma_k = z_k[i].z_k[j] / t ; e_k = exp(sigma_k) ; alpha_k = e_k / sum_k e_k
  *                      p[e] = argmax_k alpha_k (first max; NaN counts as max) ; a[e] = alpha_p
  *   per node:          s[i][k] = sum_{e in row i, p[e]=k} a[e]          (raw; model.py:70-71) */
-int dl_route_fwd(const dl_graph* g, const float* Z, int K, int d, float t,
+int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float t,
                  uint8_t* p, float* a, float* s, void* ws, size_t ws_bytes, void* stream);
 
 /* Aggregation ("K-factor edge scatter"): replaces model.py:73-75.
  *   H[i][k] = beta*Z[i][k] + (1-beta) * sum_{e=(i,j), p[e]=k} a[e] / s~[j][k] * Z[j][k]
  *   with s~ = (s==0 ? 1 : s) and the normaliser taken at the NEIGHBOUR j (model.py:73 broadcast);
  *   s must hold the rows of every neighbour (all-gathered when sharded). */
-int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta,
+int dl_aggregate_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
                      const uint8_t* p, const float* a, const float* s,
-                     float* H, void* ws, size_t ws_bytes, void* stream);
+                     void* H, void* ws, size_t ws_bytes, void* stream);
 
 /* Pair-list link scorer: replaces model.py:109-113 evaluated at the listed (u,v) only.
  *   prob[q] = sigmoid( sum_k (h_k[u].h_k[v]) * exp(z_k[u].z_k[v] / t) )    (raw exp, not softmax)
@@ -124,7 +131,7 @@ int dl_aggregate_fwd(const dl_graph* g, const float* Z, int K, int d, float beta
  * coef (optional, may be NULL; training only): [2][n_pairs][K] — coef[0][q][k] = e_k = exp(z_k[u].z_k[v]/t)
  * and coef[1][q][k] = (h_k[u].h_k[v]) * e_k, the per-factor terms of the logit.  Handing them to
  * dl_score_pairs_bwd turns the backward into two plain weighted row gathers (no dot products). */
-int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, float t,
+int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
                        const int32_t* pu, const int32_t* pv, int n_pairs,
                        const dl_pair_incidence* by_u,
                        float* prob, float* coef, void* stream);
@@ -133,7 +140,7 @@ int dl_score_pairs_fwd(const float* Z, const float* H, int N, int K, int d, floa
  * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:
  *   gl = g_prob * prob * (1 - prob);  dH[u] += gl e_k H[v][k];  dZ[u] += gl (q_k e_k)/t Z[v][k]
  * coef: the array dl_score_pairs_fwd filled (n_pairs = inc->n_pairs), or NULL to recompute e and q. */
-int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t,
+int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob,
                        const float* coef, float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream);
 
@@ -147,14 +154,14 @@ int dl_score_pairs_bwd(const float* Z, const float* H, int K, int d, float t,
  * dH and (for phase 2) ds must hold the rows of every neighbour (all-gathered when sharded).
  * dw, dwr are per-entry scratch of the caller ([n_entries] each).
  * dl_route_aggregate_bwd runs both phases back to back (single GPU). */
-int dl_route_aggregate_bwd_phase1(const dl_graph* g, const float* Z, int K, int d, float beta,
+int dl_route_aggregate_bwd_phase1(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
                                   const uint8_t* p, const float* a, const float* s, const float* dH,
                                   float* dw, float* dwr, float* ds, void* ws, size_t ws_bytes, void* stream);
-int dl_route_aggregate_bwd_phase2(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
+int dl_route_aggregate_bwd_phase2(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
                                   const uint8_t* p, const float* a, const float* s, const float* dH,
                                   const float* dw, const float* dwr, const float* ds,
                                   float* dZ, int accumulate, void* ws, size_t ws_bytes, void* stream);
-int dl_route_aggregate_bwd(const dl_graph* g, const float* Z, int K, int d, float beta, float t,
+int dl_route_aggregate_bwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
                            const uint8_t* p, const float* a, const float* s,
                            const float* dH, float* dZ, int accumulate,
                            void* ws, size_t ws_bytes, void* stream);

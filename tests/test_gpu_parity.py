@@ -352,3 +352,83 @@ def test_training_trajectory_matches_cpu_oracle():
     assert abs(res_gpu.val_aucs[-1] - res_cpu.val_aucs[-1]) <= 5e-3
     assert abs(res_gpu.test_auc - res_cpu.test_auc) <= 5e-3
     assert res_gpu.losses[-1] < res_gpu.losses[0]
+
+
+def _bf16_round(x):
+    return torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("K,d,N,deg", [(8, 64, 600, 12), (16, 128, 300, 10), (4, 32, 400, 8), (8, 32, 300, 8)])
+def test_bf16_tables_match_the_oracle_on_bf16_rounded_inputs(K, d, N, deg):
+    """bf16 storage of the gathered tables (config 5 of BASELINE.json), fp32 arithmetic.  The reference has
+    no bf16 path, so the check is against the fp32 oracle evaluated on the SAME bf16-rounded tables:
+    what remains is fp32 summation order (+ one bf16 rounding of H)."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import Graph, PairList
+    beta, t = 0.6, 1.0
+    src, dst, Zh, rng = _random_problem(K * 77 + d, N, K, d, deg, scale=0.3)
+    Zr = _bf16_round(Zh)
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+    rowptr, col, rev = sparse_ref.csr_from_pairs(src, dst, N, symmetrise=True)
+    Zb = torch.from_numpy(Zh).to(DEV).to(torch.bfloat16)
+    p, a, s = ops.route_fwd(G, Zb, t)
+    p_o, a_o, alpha, _s = sparse_ref.route(Zr, rowptr, col, t)
+    ok = _decisive(alpha)
+    assert (p.cpu().numpy()[ok] == p_o[ok]).all()
+    np.testing.assert_allclose(a.cpu().numpy()[ok], a_o[ok], rtol=1e-5)
+    p_h, a_h, s_h = p.cpu().numpy(), a.cpu().numpy(), s.cpu().numpy()
+    Hb = ops.aggregate_fwd(G, Zb, beta, p, a, s)
+    assert Hb.dtype == torch.bfloat16
+    H_o = sparse_ref.aggregate(Zr, rowptr, col, p_h, a_h, s_h, beta)
+    np.testing.assert_allclose(Hb.float().cpu().numpy(), H_o, rtol=1e-2, atol=1e-3)      # one bf16 rounding
+    Hr = Hb.float().cpu().numpy()
+    P = 3000
+    pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
+    pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N, row_bytes=K * d * 2)
+    prob, coef = ops.score_pairs_fwd(Zb, Hb, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+    prob_o = sparse_ref.score_pairs(Zr, Hr, pu, pv, t)
+    np.testing.assert_allclose(prob.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
+    gp = (rng.standard_normal(P) * 0.1).astype(np.float32)
+    tol = lambda ref: 1e-4 * max(np.abs(ref).max(), 1e-6)
+    dZs_o, dH_o = sparse_ref.score_pairs_bwd(Zr, Hr, pu, pv, t, gp)
+    for cf in (coef, None):
+        dZs, dH = ops.score_pairs_bwd(Zb, Hb, pairs, t, prob, torch.from_numpy(gp).to(DEV), coef=cf)
+        assert dZs.dtype == torch.float32
+        assert np.abs(dH.cpu().numpy() - dH_o).max() <= tol(dH_o)
+        assert np.abs(dZs.cpu().numpy() - dZs_o).max() <= tol(dZs_o)
+    dZ = ops.route_aggregate_bwd(G, Zb, beta, t, p, a, s, dH)
+    dZ_o = sparse_ref.route_aggregate_bwd(Zr, rowptr, col, rev, p_h, a_h, s_h, beta, t, dH_o)
+    assert np.abs(dZ.cpu().numpy() - dZ_o).max() <= tol(dZ_o)
+
+
+def test_bf16_module_auc_close_to_fp32():
+    """ΔAUC of bf16 table storage vs fp32 on the same weights and pairs (reported tolerance 2e-3; the
+    reference defines none) and fp32 gradients through the fused autograd node."""
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.metrics import auc_tie_avg, pair_bce_loss
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run
+    sg = synthetic_graph("chameleon", seed=5, scale=0.3)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=2)
+    run = prepare_run(split, DEV)
+    x = torch.from_numpy(sg.features()[:, :64].copy()).to(DEV)
+    torch.manual_seed(3)
+    m32 = Disentangle(64, 128, 64, nfactor=8, beta=0.7, t=1).to(DEV)
+    m16 = Disentangle(64, 128, 64, nfactor=8, beta=0.7, t=1, table_dtype=torch.bfloat16).to(DEV)
+    m16.load_state_dict(m32.state_dict())
+    out = {}
+    for name, mdl in (("f32", m32), ("bf16", m16)):
+        _emb, prob = mdl.forward_pairs(x, run.graph, run.train_val_pairs)
+        a, b = run.n_pos, run.n_pos + run.n_neg
+        loss = pair_bce_loss(prob[:a], run.label_pos, prob[a:b], run.label_neg, run.m)
+        mdl.zero_grad()
+        loss.backward()
+        out[name] = (float(auc_tie_avg(run.label_val, prob[b:])), float(loss),
+                     torch.cat([p.grad.reshape(-1) for p in mdl.parameters()]))
+    assert abs(out["bf16"][0] - out["f32"][0]) <= 2e-3
+    assert abs(out["bf16"][1] - out["f32"][1]) <= 2e-2 * abs(out["f32"][1])
+    g32, g16 = out["f32"][2], out["bf16"][2]
+    assert g16.dtype == torch.float32 and torch.isfinite(g16).all()
+    cos = torch.dot(g32, g16) / (g32.norm() * g16.norm())
+    assert float(cos) > 0.98

@@ -34,17 +34,23 @@ def test_argument_errors_are_reported_without_a_gpu():
     from disenlink_amd import _lib
     lib = _lib.load()
     g = _lib.DlGraph()
-    rc = lib.dl_route_fwd(None, None, 4, 8, 1.0, None, None, None, None, 0, None)
+    F32, BF16 = _lib.DL_F32, _lib.DL_BF16
+    rc = lib.dl_route_fwd(None, None, 4, 8, F32, 1.0, None, None, None, None, 0, None)
     assert rc == -1 and b"NULL" in lib.dl_last_error()
     import ctypes as C
-    rc = lib.dl_route_fwd(C.byref(g), None, 0, 8, 1.0, None, None, None, None, 0, None)
+    rc = lib.dl_route_fwd(C.byref(g), None, 0, 8, F32, 1.0, None, None, None, None, 0, None)
     assert rc == -1 and b"K=0" in lib.dl_last_error()
-    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, 0.0, None, None, None, None, 0, None)
+    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, F32, 0.0, None, None, None, None, 0, None)
     assert rc == -1 and b"temperature" in lib.dl_last_error()
+    rc = lib.dl_route_fwd(C.byref(g), None, 3, 5, BF16, 1.0, None, None, None, None, 0, None)
+    assert rc == -1 and b"bf16" in lib.dl_last_error()                # no generic bf16 path
+    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, 7, 1.0, None, None, None, None, 0, None)
+    assert rc == -1 and b"dtype" in lib.dl_last_error()
     g.csr.n_rows, g.csr.row_offset, g.csr.n_total = 5, 3, 6          # shard sticking out of the node range
-    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, 1.0, None, None, None, None, 0, None)
+    rc = lib.dl_route_fwd(C.byref(g), None, 4, 8, F32, 1.0, None, None, None, None, 0, None)
     assert rc == -1 and b"exceed n_total" in lib.dl_last_error()
     assert lib.dl_has_fast_path(8, 64) == 1 and lib.dl_has_fast_path(3, 5) == 0
+    assert lib.dl_has_fast_path_dtype(16, 128, BF16) == 1 and lib.dl_has_fast_path_dtype(3, 8, BF16) == 0
 
 
 def test_ops_fail_loudly_on_cpu_tensors():
