@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the gathered Z/H tables (arithmetic is fp32 either way)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +152,9 @@ def main():
 
     sg, split, graph, pairs, model, x, Z = build_workload(args.workload, device, K, d, args.nhidden, scale=args.scale)
     E, P, N = graph.n_edges, pairs.n_pairs, graph.n_nodes
+    wbytes = 4
+    if args.dtype == "bf16":
+        Z, wbytes = Z.to(torch.bfloat16), 2
 
     def step():
         p, a, s = ops.route_fwd(graph, Z, t)
@@ -181,7 +186,7 @@ def main():
     torch.cuda.synchronize()
     ktime = {n: float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(args.steps)])) * 1e-3
              for j, n in enumerate(names)}
-    abytes = algorithmic_bytes(K, d, N, E, P)
+    abytes = algorithmic_bytes(K, d, N, E, P, w=wbytes)
     kernels = {n: dict(avg_us=ktime[n] * 1e6, algorithmic_bytes=abytes[n],
                        achieved_GBs=abytes[n] / ktime[n] / 1e9, frac=abytes[n] / ktime[n] / 1e9 / HBM_PEAK_GBS)
                for n in names}
@@ -215,7 +220,7 @@ def main():
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}-synthetic(seed 0): N={N}, edge rows={sg.src.size}, 85/5/10 split, "
                                f"E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, beta={beta}, t={t}; "
                                "forward route+aggregate+score_pairs",

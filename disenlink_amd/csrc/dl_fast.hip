@@ -3,9 +3,9 @@
 // Work decomposition: the plan cuts every CSR row into segments of <= seg_len (<= 64) consecutive
 // entries; ONE 64-lane wave owns one segment, so a hub row of thousands of edges is spread over
 // many waves and CUs while a median row (tens of edges) is a single wave.  Inside a wave, a group
-// of G = D/VEC lanes owns one entry: lane c of the group holds the 16-byte chunk c (VEC = 4 fp32 or
-// 8 bf16 elements) of every factor slice, i.e. one neighbour row Z[j] (contiguous in HBM) is fetched
-// by K coalesced 16-byte-per-lane loads and 64/G entries are in flight per wave iteration.
+// of G = D/4 lanes owns one entry: lane c of the group holds elements 4c..4c+3 (16 bytes fp32, 8 bytes
+// bf16) of every factor slice, i.e. one neighbour row Z[j] (contiguous in HBM) is fetched by K
+// coalesced loads per lane and 64/G entries are in flight per wave iteration.
 //
 // Per-entry scalars (column, routing factor, weights) are loaded once per segment, one entry per
 // lane, and handed to the groups by shuffles: no dependent index load inside the loop.
@@ -53,25 +53,22 @@ struct Tab<float> {
         *reinterpret_cast<float4*>(p) = make_float4(c.v[0], c.v[1], c.v[2], c.v[3]);
     }
 };
+// bf16 tables keep the fp32 lane geometry (4 elements per lane, 8-byte loads): the same registers
+// per lane as the fp32 kernels, half the bytes per gathered row.  (8 elements per lane was tried:
+// it doubles the fp32 working set per lane and halves the occupancy.)
 template <>
 struct Tab<bf16_t> {
-    static constexpr int VEC = 8;
-    static __device__ __forceinline__ Chunk<8> load(const bf16_t* p) {
-        const uint4 q = *reinterpret_cast<const uint4*>(p);
-        Chunk<8> c;
-        c.v[0] = bf16_to_f32(q.x & 0xffffu); c.v[1] = bf16_to_f32(q.x >> 16);
-        c.v[2] = bf16_to_f32(q.y & 0xffffu); c.v[3] = bf16_to_f32(q.y >> 16);
-        c.v[4] = bf16_to_f32(q.z & 0xffffu); c.v[5] = bf16_to_f32(q.z >> 16);
-        c.v[6] = bf16_to_f32(q.w & 0xffffu); c.v[7] = bf16_to_f32(q.w >> 16);
-        return c;
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ Chunk<4> load(const bf16_t* p) {
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        return Chunk<4>{{bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu),
+                         bf16_to_f32(q.y >> 16)}};
     }
-    static __device__ __forceinline__ void store(bf16_t* p, const Chunk<8>& c) {
-        uint4 q;
+    static __device__ __forceinline__ void store(bf16_t* p, const Chunk<4>& c) {
+        uint2 q;
         q.x = f32_to_bf16(c.v[0]) | (f32_to_bf16(c.v[1]) << 16);
         q.y = f32_to_bf16(c.v[2]) | (f32_to_bf16(c.v[3]) << 16);
-        q.z = f32_to_bf16(c.v[4]) | (f32_to_bf16(c.v[5]) << 16);
-        q.w = f32_to_bf16(c.v[6]) | (f32_to_bf16(c.v[7]) << 16);
-        *reinterpret_cast<uint4*>(p) = q;
+        *reinterpret_cast<uint2*>(p) = q;
     }
 };
 
@@ -821,7 +818,7 @@ struct Ops {
 
 }  // namespace fast
 
-// (K, D) pairs with a tuned instantiation.  D must be VEC * a power of two (VEC = 4 fp32 / 8 bf16).
+// (K, D) pairs with a tuned instantiation.  D must be 4 * a power of two.
 #define DL_FAST_SHAPES_F32(X) \
     X(4, 32) X(8, 64) X(16, 128) X(5, 32) X(5, 64) X(10, 32) X(10, 64) X(20, 32) X(8, 32) X(4, 64) X(4, 8) X(8, 8) X(3, 8)
 #define DL_FAST_SHAPES_BF16(X) X(4, 32) X(8, 64) X(16, 128) X(5, 64) X(8, 32)
