@@ -41,6 +41,8 @@ EXPORTS = {
     "dl_has_fast_path_dtype": (_i, [_i, _i, _i]),
     "dl_set_force_generic": (_i, [_i]),
     "dl_workspace_bytes": (_z, [C.POINTER(DlCsrPlan), _i, _i]),
+    "dl_project_supported": (_i, [_i]),
+    "dl_project_fwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P]),
     "dl_route_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
     "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
     "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P, _P]),

@@ -116,6 +116,20 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d) {
     return carve(plan, K, d, nullptr).bytes;
 }
 
+int dl_project_supported(int d) { return project_supported(d) ? 1 : 0; }
+
+int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                   const float* W2, const float* b2, float* Z, void* stream) {
+    if (int rc = check_shape(K, d)) return rc;
+    DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
+    DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
+    DL_REQUIRE(K <= 65535, "K too large for the launch grid");
+    DL_REQUIRE((W2 == nullptr) == (b2 == nullptr), "W2 and b2 must both be given (two-layer) or both NULL");
+    if (N == 0) return DL_OK;
+    DL_REQUIRE(x && W1 && b1 && Z, "NULL argument");
+    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, (hipStream_t)stream);
+}
+
 int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float t, uint8_t* p, float* a,
                  float* s, void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");

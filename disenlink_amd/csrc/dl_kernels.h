@@ -39,4 +39,9 @@ int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void
                          float t, const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
                          float* part, hipStream_t st);
 
+// factor projection on the matrix cores (dl_project.hip)
+bool project_supported(int d);
+int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                const float* W2, const float* b2, float* Z, hipStream_t st);
+
 }  // namespace dl

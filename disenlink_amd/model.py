@@ -43,12 +43,17 @@ class Factor2(nn.Module):
 
 
 class Disentangle(nn.Module):
-    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1, table_dtype=torch.float32):
-        """``table_dtype`` (extension; the reference has none): storage type of the gathered Z / H tables in
-        ``forward_pairs`` — torch.float32 (reference precision) or torch.bfloat16 (half the gather bytes,
-        fp32 arithmetic and gradients)."""
+    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1, table_dtype=torch.float32, projection="auto"):
+        """Extensions (the reference has neither):
+        ``table_dtype``: storage type of the gathered Z / H tables in ``forward_pairs`` — torch.float32
+        (reference precision) or torch.bfloat16 (half the gather bytes, fp32 arithmetic and gradients).
+        ``projection``: "mfma" = the fused fp32 MFMA kernel of libdisenlink_hip.so, "library" = two library
+        GEMMs (rocBLAS through torch), "auto" = the kernel where it measured faster (d == 128, F <= 128)."""
         super().__init__()
+        if projection not in ("auto", "mfma", "library"):
+            raise ValueError("projection must be 'auto', 'mfma' or 'library'")
         self.table_dtype = table_dtype
+        self.projection = projection
         # creation order == the reference's (model.py:93-99), so a seeded init draws the same stream
         if nhid == 1:
             factors = [Factor(nfeat, nebed) for _ in range(nfactor)]
@@ -69,9 +74,21 @@ class Disentangle(nn.Module):
 
     # ------------------------------------------------------------------ projection (model.py:106)
     def project(self, x: torch.Tensor) -> torch.Tensor:
-        """Z [N,K,d] = K independent MLPs of x, as one wide GEMM + one K-batched GEMM."""
+        """Z [N,K,d] = K independent MLPs of x.  On the GPU (d in {32,64,128}): the fused MFMA kernel of
+        libdisenlink_hip.so.  Otherwise (CPU tests of the host logic, odd d): one wide library GEMM + one
+        K-batched GEMM — plain torch plumbing, the reference's own ops."""
         fs = self.factors
         K, d = self.nfactor, self.nebed
+        use_kernel = x.is_cuda and x.dtype == torch.float32 and self.projection != "library" and ops.project_supported(d)
+        if use_kernel and self.projection == "auto":
+            use_kernel = d == 128 and x.shape[1] <= 128         # measured: tools/project_times.py, DESIGN.md §3
+        if use_kernel:
+            # fused MFMA kernel; the stacks keep the per-factor parameters (and their state_dict keys) intact
+            if self.single_layer:
+                return ops.Project.apply(x, torch.stack([f.mlp.weight for f in fs]),
+                                         torch.stack([f.mlp.bias for f in fs]), None, None)
+            return ops.Project.apply(x, torch.stack([f.mlp1.weight for f in fs]), torch.stack([f.mlp1.bias for f in fs]),
+                                     torch.stack([f.mlp2.weight for f in fs]), torch.stack([f.mlp2.bias for f in fs]))
         if self.single_layer:
             W = torch.cat([f.mlp.weight for f in fs], dim=0)             # [K*d, F]
             b = torch.cat([f.mlp.bias for f in fs], dim=0)

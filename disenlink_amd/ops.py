@@ -205,7 +205,61 @@ def route_aggregate_bwd_phase2(g: Graph, Z, beta: float, t: float, p, a, s, dH, 
     return dZ_out
 
 
+def project_fwd(x, W1, b1, W2=None, b2=None) -> torch.Tensor:
+    """Z [N,K,d] = K MLPs of x on the matrix cores.  Two-layer: W1 [K,nhid,F], b1 [K,nhid], W2 [K,d,nhid],
+    b2 [K,d]; single layer: W1 [K,d,F], b1 [K,d], W2 = b2 = None.  model.py:13-15 / 24-27 / 106."""
+    lib = _lib.load()
+    x, W1, b1 = _f32c(x), _f32c(W1), _f32c(b1)
+    _need_cuda(x, W1, b1)
+    N, F = x.shape
+    K = W1.shape[0]
+    if W2 is None:
+        d, nhid, w2p, b2p = W1.shape[1], 1, None, None
+    else:
+        W2, b2 = _f32c(W2), _f32c(b2)
+        d, nhid, w2p, b2p = W2.shape[1], W1.shape[1], W2.data_ptr(), b2.data_ptr()
+        if W2.shape != (K, d, nhid) or b2.shape != (K, d) or b1.shape != (K, nhid):
+            raise ValueError("inconsistent projection weight shapes")
+    if W1.shape[2] != F:
+        raise ValueError("W1 does not match the feature count of x")
+    Z = torch.empty((N, K, d), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dl_project_fwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(), w2p, b2p,
+                                  Z.data_ptr(), _stream()), "dl_project_fwd")
+    return Z
+
+
+def project_supported(d: int) -> bool:
+    return bool(_lib.load().dl_project_supported(int(d)))
+
+
 # ---------------------------------------------------------------------- autograd
+class Project(torch.autograd.Function):
+    """Z = MLP_k(x) for all k.  Forward: the fused MFMA kernel (hidden activations never leave the
+    register file).  Backward: library GEMMs on the recomputed hidden layer (a native backward is the
+    next step for this row); x is data and gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        ctx.save_for_backward(x, W1, b1, W2 if W2 is not None else x.new_empty(0))
+        ctx.two_layer = W2 is not None
+        return project_fwd(x, W1, b1, W2, b2)
+
+    @staticmethod
+    def backward(ctx, dZ):
+        x, W1, b1, W2 = ctx.saved_tensors
+        dZ = dZ.contiguous()
+        if not ctx.two_layer:                                   # Z[n,k,:] = W1[k] x[n] + b1[k]
+            dW1 = torch.einsum("nkd,nf->kdf", dZ, x)
+            return None, dW1, dZ.sum(dim=0), None, None
+        pre = torch.einsum("nf,khf->nkh", x, W1) + b1           # [N,K,nhid]
+        hid = torch.relu(pre)
+        dW2 = torch.einsum("nkd,nkh->kdh", dZ, hid)
+        db2 = dZ.sum(dim=0)
+        dhid = torch.einsum("nkd,kdh->nkh", dZ, W2) * (pre > 0)
+        dW1 = torch.einsum("nkh,nf->khf", dhid, x)
+        return None, dW1, dhid.sum(dim=0), dW2, db2
+
+
 class RouteAggregate(torch.autograd.Function):
     """Z [N,K,d] -> H [N,K,d]: Disentangle_layer.forward (model.py:55-77) on the CSR of adj."""
 

@@ -108,6 +108,17 @@ int dl_set_force_generic(int on);
 /* Scratch needed by the calls below for this plan and shape. */
 size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
 
+/* Factor projection on the matrix cores: replaces model.py:13-15 / 24-27 fanned out at model.py:106.
+ *   two-layer (Factor2):   Z[n][k][:] = W2[k] . relu(W1[k] . x[n] + b1[k]) + b2[k]
+ *                          W1 [K][nhid][F], b1 [K][nhid], W2 [K][d][nhid], b2 [K][d]
+ *   single layer (Factor): pass W2 = b2 = NULL, nhid = 1:  Z[n][k][:] = W1[k] . x[n] + b1[k],  W1 [K][d][F], b1 [K][d]
+ * x is fp32 [N][F] row-major, Z fp32 [N][K][d].  d must be 32, 64 or 128 (dl_project_supported).
+ * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain). */
+int dl_project_supported(int d);
+int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d,
+                   const float* W1, const float* b1, const float* W2, const float* b2,
+                   float* Z, void* stream);
+
 /* Routing: replaces model.py:56-72 restricted to adj==1 entries.
  *   per edge e=(i,j):  sigma_k = z_k[i].z_k[j] / t ; e_k = exp(sigma_k) ; alpha_k = e_k / sum_k e_k
  *                      p[e] = argmax_k alpha_k (first max; NaN counts as max) ; a[e] = alpha_p
