@@ -27,8 +27,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # kernel behind each timed phase (the name rocprofv3 reports) -> PMC summary of tools/pmc_traffic.py
-PHASE_KERNEL = {"route": "dl::fast::route_seg_kernel<8, 64>", "aggregate": "dl::fast::aggregate_seg_kernel<8, 64>",
-                "score": "dl::fast::score_fwd_seg_kernel<8, 64, false>"}
+PHASE_KERNEL = {"route": "dl::fast::route_seg_kernel<8, 64, float>",
+                "aggregate": "dl::fast::aggregate_seg_kernel<8, 64, float>",
+                "score": "dl::fast::score_fwd_seg_kernel<8, 64, float, false>"}
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 
 
@@ -228,7 +229,8 @@ def main():
                    and not args.force_generic},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": kernels[dom]["frac"],
-                     "traffic": pmc_traffic(dom) if (args.workload == "squirrel" and K == 8 and d == 64) else None,
+                     "traffic": pmc_traffic(dom) if (args.workload == "squirrel" and K == 8 and d == 64
+                                                     and args.dtype == "f32" and args.scale == 1.0) else None,
                      "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                        "separate passes of this command; bytes leaving the XCD L2s per launch)",
                      "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "avg_us": kernels[dom]["avg_us"]},
