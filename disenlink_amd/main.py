@@ -1,0 +1,126 @@
+"""Command-line driver with the flags of the reference's ``main_disentangled.py`` (:21-50), running the
+pair-list pipeline on the MI355X path:
+
+    python -m disenlink_amd.main --dataset chameleon --beta 0.7 --nfactor 5 --nhidden 512 --nembed 32 \\
+        --epochs 2000 --lr 0.0001 --m 5 --run 10 [--data-root /path/to/reference/data | --data-file ds.npz]
+
+Differences from the reference script, on purpose: runs are seeded (``--seed`` + run index; the reference
+seeds nothing on the CPU path, SURVEY.md §0 finding 5); the split / masks / loss / AUC work on pair lists
+(no ``[N,N]`` tensors); flags the reference parses but never uses (``--weight_decay``, ``--nfeat``,
+``--loss_weight``, ``--debug``, ``--layer`` other than 1) are accepted and ignored the same way.
+Without data files a seeded synthetic stand-in of the named dataset is used (``disenlink_amd.data``).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument("--debug", action="store_true", default=False)
+    p.add_argument("--no-cuda", action="store_true", default=False)
+    p.add_argument("--seed", type=int, default=18)
+    p.add_argument("--lr", type=float, default=0.0001)
+    p.add_argument("--beta", type=float, default=0.9)
+    p.add_argument("--nfactor", type=int, default=3)
+    p.add_argument("--weight_decay", type=float, default=5e-4)
+    p.add_argument("--nfeat", type=int, default=128)
+    p.add_argument("--nhidden", type=int, default=512)
+    p.add_argument("--nembed", type=int, default=32)
+    p.add_argument("--epochs", type=int, default=2000)
+    p.add_argument("--temperature", type=int, default=1)
+    p.add_argument("--dataset", type=str, default="chameleon")
+    p.add_argument("--sub_dataset", type=str, default="Amherst41")
+    p.add_argument("--run", type=int, default=10)
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--m", type=int, default=5)
+    p.add_argument("--save", type=int, default=0)
+    p.add_argument("--loss_weight", type=int, default=20)
+    p.add_argument("--layer", type=int, default=1)
+    p.add_argument("--miniid", type=int, default=9)
+    # extensions
+    p.add_argument("--data-root", type=str, default=None, help="directory laid out like the reference's data/")
+    p.add_argument("--data-file", type=str, default=None, help="binary dataset written by datasets.save_binary")
+    p.add_argument("--synthetic", action="store_true", help="seeded synthetic stand-in of --dataset")
+    p.add_argument("--table-dtype", choices=["f32", "bf16"], default="f32")
+    p.add_argument("--quiet", action="store_true")
+    return p
+
+
+def load_dataset(args):
+    from . import datasets
+    from .data import SPECS, synthetic_graph
+    if args.data_file:
+        return datasets.load_binary(args.data_file)
+    root = args.data_root
+    if root and not args.synthetic:
+        name = args.dataset
+        if name in ("chameleon", "squirrel", "crocodile"):          # main_disentangled.py:73-81, 97-108
+            npz = os.path.join(os.path.dirname(root.rstrip("/")), "data_pre_false", name, "raw", f"{name}.npz")
+            if not os.path.exists(npz):
+                npz = os.path.join(root, name, "raw", f"{name}.npz")
+            return datasets.load_npz(npz, name)
+        if name in ("cora", "citeseer", "pubmed"):                  # :117-123
+            return datasets.load_planetoid(os.path.join(root, name, "raw"), name)
+        if name == "fb100":                                         # :62-64, 109-113
+            return datasets.load_fb100(os.path.join(root, "facebook100", args.sub_dataset + ".mat"), args.sub_dataset)
+        if name == "twitch-e":                                      # :62-64, 109-116
+            return datasets.load_twitch(os.path.join(root, "twitch", args.sub_dataset), args.sub_dataset)
+        raise SystemExit(f"no loader for --dataset {name}")
+    key = {"fb100": "penn94", "snap-patents": "snap_patents"}.get(args.dataset, args.dataset)
+    if key not in SPECS:
+        raise SystemExit(f"no data for --dataset {args.dataset}: give --data-root / --data-file")
+    sg = synthetic_graph(key, seed=args.seed)
+    return datasets.LinkDataset(f"{key}-synthetic", sg.features(), sg.src, sg.dst)
+
+
+def main(argv=None):
+    args = build_parser().parse_known_args(argv)[0]                 # unknown tokens ignored, like :50
+    if args.layer != 1:
+        raise SystemExit("only --layer 1 exists in the reference (main_disentangled.py:147-148)")
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("disenlink_amd runs on the GPU only (libdisenlink_hip.so has no CPU fallback)")
+    from .model import Disentangle
+    from .splits import make_link_split
+    from .train import prepare_run, run_link_prediction
+    device = torch.device("cuda", args.gpu)
+    torch.cuda.set_device(device)
+    ds = load_dataset(args)
+    if not args.quiet:
+        print(args)
+        print(f"dataset {ds.name}: N={ds.n_nodes} F={ds.x.shape[1]} edge rows={ds.src.size}")
+    x = torch.from_numpy(ds.x).to(device)
+    tdt = torch.bfloat16 if args.table_dtype == "bf16" else torch.float32
+    result = []
+    for run in range(args.run):
+        if not args.quiet:
+            print("run:", run)
+        split = make_link_split(ds.src, ds.dst, ds.n_nodes, m=args.m, seed=args.seed + run)
+        prepared = prepare_run(split, device)
+        torch.manual_seed(args.seed + run)
+        model = Disentangle(x.shape[1], args.nhidden, args.nembed, nfactor=args.nfactor, beta=args.beta,
+                            t=args.temperature, table_dtype=tdt).to(device)
+        res = run_link_prediction(model, x, prepared, epochs=args.epochs, lr=args.lr,
+                                  log=None if args.quiet else print)
+        if not args.quiet:
+            print("test auc:", res.test_auc)
+        result.append(res.test_auc)
+    result = np.array(result)
+    print("final", result.mean(), result.std())
+    if args.save == 1:                                              # :225-246
+        os.makedirs("performance", exist_ok=True)
+        sub = f"{args.sub_dataset}" if args.dataset in ("twitch-e", "fb100") else ""
+        with open(f"performance/{args.dataset}_{sub}disentangle_nfactor.csv", "a+") as f:
+            f.write(f"{result.mean():.3f} ± {result.std():.3f},{result},beta {args.beta},temperature {args.temperature},"
+                    f"nfactor {args.nfactor},nhidden {args.nhidden},nembed {args.nembed},dataset {args.dataset},"
+                    f"run {args.run},epochs {args.epochs},lr {args.lr},m {args.m}\n")
+    return result
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -457,3 +457,15 @@ def test_mfma_projection_matches_cpu_mlp(N, F, K, nhid, d):
     for (name, pr), (_n, pg) in zip(ref.named_parameters(), gpu.named_parameters()):
         s = max(float(pr.grad.abs().max()), 1e-6)
         assert float((pg.grad.cpu() - pr.grad).abs().max()) <= 1e-4 * s, name
+
+
+def test_cli_runs_the_reference_flag_set():
+    """`python -m disenlink_amd.main` with the flag names of main_disentangled.py:21-50 (incl. a stray token,
+    which parse_known_args ignores like the reference's chameleon recipe) on a synthetic stand-in."""
+    from disenlink_amd import main as cli
+    res = cli.main(["--dataset", "cora", "--synthetic", "--beta", "0.6", "temperature", "1", "--nfactor", "4",
+                    "--nhidden", "64", "--nembed", "32", "--layer", "1", "--epochs", "6", "--lr", "0.001", "--m", "5",
+                    "--run", "2", "--quiet"])
+    assert res.shape == (2,) and np.isfinite(res).all() and (res > 0.4).all() and (res <= 1.0).all()
+    with pytest.raises(SystemExit):
+        cli.main(["--layer", "2", "--quiet"])
