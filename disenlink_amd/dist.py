@@ -232,6 +232,12 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     from .splits import make_link_split
     lib = _lib.load()
     K, d, beta, t = args.K, args.d, 0.5, 1.0
+    # DL_EMULATE_WORLD=8 on one GPU: build rank 0's shard of the 8-GPU problem and time its compute alone
+    # (the collectives degenerate to no-ops) — a rehearsal of the per-rank work, not a scaling number.
+    import os
+    emu = int(os.environ.get("DL_EMULATE_WORLD", "0"))
+    if emu > 1 and world == 1:
+        return _bench_emulated(args, emu, device)
     sg = synthetic_graph(args.workload, seed=0, scale=args.scale * world)
     split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
@@ -287,3 +293,37 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
                    "K": K, "d": d, "n_nodes": sg.n_nodes, "E_sym": E, "P": P,
                    "parallelism": f"row-shard x{world}", "fast_path": bool(lib.dl_has_fast_path(K, d))},
     }
+
+
+def _bench_emulated(args, emu_world: int, device) -> dict:
+    from .data import synthetic_graph
+    from .splits import make_link_split
+    K, d, beta, t = args.K, args.d, 0.5, 1.0
+    sg = synthetic_graph(args.workload, seed=0, scale=args.scale * emu_world)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    order = np.lexsort((pv, pu))
+    shard = Shard.build(0, emu_world, sg.n_nodes, split.train_src, split.train_dst, pu[order], pv[order], device)
+    backend = HipBackend()
+    Z = torch.randn((shard.n_pad, K, d), device=device) * 0.24
+    s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
+    H = torch.empty_like(Z)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = np.zeros(3)
+    for it in range(args.warmup + args.steps):
+        ev[0].record()
+        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        ev[1].record()
+        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+        ev[2].record()
+        backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        ev[3].record()
+        torch.cuda.synchronize()
+        if it >= args.warmup:
+            acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+    acc /= args.steps
+    return {"emulated_world": emu_world, "rank0_edges": shard.graph.n_edges, "rank0_pairs": shard.pairs.n_pairs,
+            "n_nodes": sg.n_nodes, "table_MB": shard.n_pad * K * d * 4 / 1e6,
+            "route_us": acc[0] * 1e3, "aggregate_us": acc[1] * 1e3, "score_us": acc[2] * 1e3,
+            "allgather_bytes_per_rank_per_step": 2 * shard.n_pad * K * d * 4 + shard.n_pad * K * 4}

@@ -469,3 +469,45 @@ def test_cli_runs_the_reference_flag_set():
     assert res.shape == (2,) and np.isfinite(res).all() and (res > 0.4).all() and (res <= 1.0).all()
     with pytest.raises(SystemExit):
         cli.main(["--layer", "2", "--quiet"])
+
+
+def test_full_size_benchmark_workload_matches_c_oracle():
+    """The bench workload at its FULL size (squirrel-synthetic, K=8, d=64: 369k edges, 1.04M pairs) against
+    the multi-threaded C restatement, plus size-independent properties: routing symmetry, normaliser =
+    per-factor row sums, isolated nodes keep beta*z, scorer symmetric in (u, v), bitwise reproducibility."""
+    import bench
+    from disenlink_amd import ops
+    from oracle import c_ref
+    K, d, beta, t = 8, 64, 0.5, 1.0
+    sg, split, graph, pairs, _model, _x, Z = bench.build_workload("squirrel", torch.device(DEV), K, d, 512)
+    p, a, s = ops.route_fwd(graph, Z, t)
+    H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+    prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
+    Zh = Z.cpu().numpy()
+    rowptr, col = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
+    p_o, a_o, s_o = c_ref.route(Zh, rowptr, col, t)
+    p_h, a_h, s_h = p.cpu().numpy(), a.cpu().numpy(), s.cpu().numpy()
+    same = p_h == p_o
+    assert same.mean() > 0.9999                                        # near-ties may flip in fp32
+    np.testing.assert_allclose(a_h[same], a_o[same], rtol=1e-5)
+    H_o = c_ref.aggregate(Zh, rowptr, col, p_h, a_h, s_h, beta)        # from the GPU's own routing
+    np.testing.assert_allclose(H.cpu().numpy(), H_o, rtol=1e-5, atol=1e-5)
+    prob_o = c_ref.score_pairs(Zh, H_o, pairs.pu.cpu().numpy(), pairs.pv.cpu().numpy(), t)
+    np.testing.assert_allclose(prob.cpu().numpy(), prob_o, rtol=1e-5, atol=1e-5)
+    auc_lab = (np.arange(prob_o.size) % 3 == 0).astype(np.float32)      # any fixed labelling: same ranks -> same AUC
+    assert abs(metrics_ref.auc_tie_avg(auc_lab, prob.cpu().numpy()) - metrics_ref.auc_tie_avg(auc_lab, prob_o)) <= 1e-4
+    # properties
+    rev = graph.rev.long()
+    assert torch.equal(p, p[rev]) and torch.equal(a, a[rev])            # (i,j) and (j,i) route identically, bitwise
+    src = torch.repeat_interleave(torch.arange(graph.n_nodes, device=DEV), (graph.rowptr[1:] - graph.rowptr[:-1]).long())
+    s_chk = torch.zeros_like(s).index_put_((src, p.long()), a, accumulate=True)
+    np.testing.assert_allclose(s_h, s_chk.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    iso = (graph.rowptr[1:] == graph.rowptr[:-1])
+    if bool(iso.any()):
+        assert torch.equal(H[iso], beta * Z[iso])
+    swapped = ops.score_pairs_fwd(Z, H, pairs.pv, pairs.pu, t, None)
+    np.testing.assert_allclose(swapped.cpu().numpy(), prob.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    p2, a2, s2 = ops.route_fwd(graph, Z, t)
+    assert torch.equal(p, p2) and torch.equal(a, a2) and torch.equal(s, s2)
+    assert torch.equal(H, ops.aggregate_fwd(graph, Z, beta, p, a, s))
+    assert torch.equal(prob, ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs))

@@ -108,3 +108,22 @@ def test_sparse_backward_matches_reference_grads(golden):
 def test_auc_matches_sklearn_vectors(path):
     g = np.load(path)
     assert abs(metrics_ref.auc_tie_avg(g["y"], g["score"]) - float(g["auc"])) < 1e-12
+
+
+def test_c_restatement_matches_numpy_oracle_and_reference(golden):
+    """oracle/c/sparse_ref.c (OpenMP) against the numpy oracle and the reference's golden vectors."""
+    from oracle import c_ref
+    g, m = golden, golden["meta"]
+    Z = _Z_nkd(g)
+    N, K, d = Z.shape
+    rowptr, col, _rev = sparse_ref.csr_from_dense(g["adj"])
+    p, a, s_raw = c_ref.route(Z, rowptr, col, m["t"])
+    p_n, a_n, _alpha, s_n = sparse_ref.route(Z, rowptr, col, m["t"])
+    assert (p == p_n).all()
+    np.testing.assert_allclose(a, a_n, rtol=2e-6)
+    np.testing.assert_allclose(s_raw, s_n, rtol=1e-5, atol=1e-7)
+    H = c_ref.aggregate(Z, rowptr, col, p, a, s_raw, m["beta"])
+    np.testing.assert_allclose(H.reshape(N, K * d), g["emb"], rtol=1e-5, atol=2e-6)
+    uu, vv = np.divmod(np.arange(N * N), N)
+    prob = c_ref.score_pairs(Z, H, uu, vv, m["t"]).reshape(N, N)
+    np.testing.assert_allclose(prob, g["link_pred"], rtol=1e-5, atol=2e-6)

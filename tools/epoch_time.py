@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Wall time of one training epoch of disenlink_amd.train.run_link_prediction on the bench workload."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from disenlink_amd.data import synthetic_graph
+from disenlink_amd.model import Disentangle
+from disenlink_amd.splits import make_link_split
+from disenlink_amd.train import prepare_run, run_link_prediction
+
+name = sys.argv[1] if len(sys.argv) > 1 else "squirrel"
+dev = torch.device("cuda:0")
+sg = synthetic_graph(name, seed=0)
+split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
+run = prepare_run(split, dev)
+x = torch.from_numpy(sg.features()).to(dev)
+torch.manual_seed(0)
+model = Disentangle(sg.n_feat, 512, 64, nfactor=8, beta=0.5, t=1).to(dev)
+run_link_prediction(model, x, run, epochs=3, lr=1e-4)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+res = run_link_prediction(model, x, run, epochs=30, lr=1e-4)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 31          # 30 epochs + the test forward
+print(f"{name}: {dt * 1e3:.2f} ms per epoch (train pairs {run.n_pos + run.n_neg}, val {run.label_val.numel()}); "
+      f"loss {res.losses[0]:.4f} -> {res.losses[-1]:.4f}, val auc {res.val_aucs[-1]:.4f}")
