@@ -515,8 +515,10 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
                                                               float* __restrict__ coef_e,
                                                               float* __restrict__ coef_q) {
     using GE = Geo<K, D, T>;
-    using FL = typename GE::FL;
-    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
+    constexpr int KB = K > 8 ? 8 : K;                        // factor block
+    using FLB = FactorLanes<G, KB>;
+    constexpr int KBP = FLB::KP;
     __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int seg = wave_segment(g);
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
-    const int kb = FL::factor_base(c);
+    const int kbb = FLB::factor_base(c);
     int my_col = si.grow, my_pair = 0;
     if (si.beg + lane < si.end) {
         my_col = g.col[si.beg + lane];
@@ -540,31 +542,31 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
         const bool live = it < si.end;
         const size_t v = (size_t)__shfl(my_col, it - si.beg, DL_WAVE);
         const int q = __shfl(my_pair, it - si.beg, DL_WAVE);
-        Chunk<VEC> zv[K], hv[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            zv[k] = Tab<T>::load(Z + v * ROW + k * D + c * VEC);
-            hv[k] = Tab<T>::load(H + v * ROW + k * D + c * VEC);
-        }
-        float pq[KP], ps[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int kk = k < K ? k : 0;
-            pq[k] = k < K ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
-            ps[k] = k < K ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zv[kk]) : 0.0f;
-        }
-        TransposedReduce<KP, G / 2>::run(pq, c);
-        TransposedReduce<KP, G / 2>::run(ps, c);
+        // factors are processed in blocks of KB <= 8: at most 2*KB row chunks live at a time, whatever K is
         float term = 0.0f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            if (FL::primary(c) && kb + i < K) {
-                const float ek = expf(div_t(ps[i], t));
-                const float qe = pq[i] * ek;
-                term += qe;
-                if (COEF && live) {                             // per-factor logit terms for the backward
-                    coef_e[(size_t)q * K + kb + i] = ek;
-                    coef_q[(size_t)q * K + kb + i] = qe;
+        for (int b0 = 0; b0 < K; b0 += KB) {
+            float pq[KBP], ps[KBP];
+#pragma unroll
+            for (int k = 0; k < KBP; ++k) {
+                const bool in = k < KB && b0 + k < K;
+                const int kk = in ? b0 + k : 0;
+                pq[k] = in ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), Tab<T>::load(H + v * ROW + kk * D + c * VEC)) : 0.0f;
+                ps[k] = in ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), Tab<T>::load(Z + v * ROW + kk * D + c * VEC)) : 0.0f;
+            }
+            TransposedReduce<KBP, G / 2>::run(pq, c);
+            TransposedReduce<KBP, G / 2>::run(ps, c);
+#pragma unroll
+            for (int i = 0; i < FLB::VPL; ++i) {
+                const int k = b0 + kbb + i;
+                if (FLB::primary(c) && kbb + i < KB && k < K) {
+                    const float ek = expf(div_t(ps[i], t));
+                    const float qe = pq[i] * ek;
+                    term += qe;
+                    if (COEF && live) {                         // per-factor logit terms for the backward
+                        coef_e[(size_t)q * K + k] = ek;
+                        coef_q[(size_t)q * K + k] = qe;
+                    }
                 }
             }
         }
@@ -690,9 +692,6 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g
         const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
         const int q = __shfl(my_pair, idx, DL_WAVE);
         const float gl = __shfl(my_gl, idx, DL_WAVE);     // 0 past the segment end
-        Chunk<VEC> xv[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) xv[k] = Tab<T>::load(X + v * ROW + k * D + c * VEC);
         float ck[K];
         if constexpr (K % 4 == 0) {
 #pragma unroll
@@ -704,8 +703,17 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g
 #pragma unroll
             for (int k = 0; k < K; ++k) ck[k] = coef[(size_t)q * K + k];
         }
+        // gathers in blocks of <= 8 factor slices: bounded live registers for any K
 #pragma unroll
-        for (int k = 0; k < K; ++k) fma_chunk(acc[k], gl * ck[k], xv[k]);
+        for (int b0 = 0; b0 < K; b0 += 8) {
+            Chunk<VEC> xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < K) xv[k] = Tab<T>::load(X + v * ROW + (b0 + k) * D + c * VEC);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < K) fma_chunk(acc[b0 + k], gl * ck[b0 + k], xv[k]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) across_groups_sum_chunk<G>(acc[k]);
