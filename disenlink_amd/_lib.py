@@ -23,7 +23,7 @@ class DlCsrPlan(C.Structure):
 
 
 class DlGraph(C.Structure):
-    _fields_ = [("csr", DlCsrPlan)]
+    _fields_ = [("csr", DlCsrPlan), ("upper", DlCsrPlan), ("rev", C.c_void_p)]
 
 
 class DlPairIncidence(C.Structure):

@@ -141,10 +141,12 @@ __device__ __forceinline__ float lane_exps(float* part, int c, float t, float (&
 }
 
 // ---------------------------------------------------------------------------- route
-template <int K, int D, typename T>
-__global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float t,
-                                                          uint8_t* __restrict__ p, float* __restrict__ a,
-                                                          float* __restrict__ s, float* __restrict__ s_part) {
+// p[e], a[e] for the entries of the plan's segments.  MIRROR: the plan covers col >= row only and
+// every result is also written to the reverse entry (routing is symmetric, bitwise).
+template <int K, int D, typename T, bool MIRROR>
+__global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ rev,
+                                                          const T* __restrict__ Z, float t,
+                                                          uint8_t* __restrict__ p, float* __restrict__ a) {
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL;
@@ -154,16 +156,16 @@ __global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const T
     const int c = lane % G, grp = lane / G;
     const SegInfo si = load_seg(g, seg);
     const int kb = FL::factor_base(c);
-    const bool prim = FL::primary(c);
 
     Chunk<VEC> zi[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) zi[k] = Tab<T>::load(Z + (size_t)si.grow * GE::ROW + k * D + c * VEC);
-    float sacc[VPL];
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) sacc[i] = 0.0f;
 
-    const int my_col = (si.beg + lane < si.end) ? g.col[si.beg + lane] : si.grow;
+    int my_col = si.grow, my_rev = 0;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        if (MIRROR) my_rev = rev[si.beg + lane];
+    }
     for (int base = si.beg; base < si.end; base += EPW) {
         const int e = base + grp;
         const bool live = e < si.end;
@@ -183,17 +185,39 @@ __global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const T
             if (kb + i < K && (win == 255 || beats(al, best))) { best = al; win = kb + i; }
         }
         group_argmax_first<G>(best, win);
-        if (live && c == 0) { p[e] = (uint8_t)win; a[e] = best; }
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) sacc[i] += (live && prim && win == kb + i) ? best : 0.0f;
+        if (MIRROR) {
+            const int r = __shfl(my_rev, e - si.beg, DL_WAVE);
+            if (live && c == 0) { p[e] = (uint8_t)win; a[e] = best; }
+            if (live && c == 1 % G && r != e) { p[r] = (uint8_t)win; a[r] = best; }
+        } else {
+            if (live && c == 0) { p[e] = (uint8_t)win; a[e] = best; }
+        }
     }
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) sacc[i] = across_groups_sum<G>(sacc[i]);
-    if (grp == 0 && prim) {
+}
+
+// s[i][k] = sum_{e in row i, p[e]=k} a[e] (raw; model.py:70-71), one wave per segment of the full plan:
+// lane l holds entry l of the segment; factor k's sum is a wave all-reduce of the lanes routed to k.
+__global__ __launch_bounds__(BLOCK) void s_rowsum_seg_kernel(dl_csr_plan g, int K, const uint8_t* __restrict__ p,
+                                                             const float* __restrict__ a, float* __restrict__ s,
+                                                             float* __restrict__ s_part) {
+    const int seg = wave_segment(g);
+    if (seg < 0) return;
+    const int lane = lane_id();
+    const SegInfo si = load_seg(g, seg);
+    int my_k = 255;
+    float my_a = 0.0f;
+    if (si.beg + lane < si.end) {
+        my_k = p[si.beg + lane];
+        my_a = a[si.beg + lane];
+    }
+    float mine = 0.0f;                                   // lane k ends up with s_k of the segment
+    for (int k = 0; k < K; ++k) {
+        const float v = wave_allreduce_sum(my_k == k ? my_a : 0.0f);
+        if (lane == k) mine = v;
+    }
+    if (lane < K) {
         float* dst = si.slot < 0 ? s + (size_t)si.grow * K : s_part + (size_t)si.slot * K;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i)
-            if (kb + i < K) dst[kb + i] = sacc[i];
+        dst[lane] = mine;
     }
 }
 
@@ -742,10 +766,16 @@ template <int K, int D, typename T>
 struct Ops {
     static constexpr int ROW = K * D;
 
-    static int route_fwd(const dl_csr_plan* g, const void* Z, float t, uint8_t* p, float* a, float* s, float* s_part,
-                         hipStream_t st) {
-        hipLaunchKernelGGL((route_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z, t, p,
-                           a, s, s_part);
+    // `upper` (with `rev`) non-NULL: compute each undirected edge once and mirror it
+    static int route_fwd(const dl_csr_plan* g, const dl_csr_plan* upper, const int32_t* rev, const void* Z, float t,
+                         uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
+        if (upper)
+            hipLaunchKernelGGL((route_seg_kernel<K, D, T, true>), dim3(seg_blocks(upper)), dim3(BLOCK), 0, st, *upper,
+                               rev, (const T*)Z, t, p, a);
+        else
+            hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, rev,
+                               (const T*)Z, t, p, a);
+        hipLaunchKernelGGL(s_rowsum_seg_kernel, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, K, p, a, s, s_part);
         launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
         return check_launch("route_fwd(fast)");
     }
@@ -849,10 +879,12 @@ bool fast_supported(int K, int d, int dtype) {
     set_error("no tuned kernel for K=%d d=%d dtype=%d", K, d, dtype);                             \
     return DL_E_ARG;
 
-int fast_route_fwd(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float t, uint8_t* p, float* a,
-                   float* s, float* s_part, hipStream_t st) {
-#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::route_fwd(g, Z, t, p, a, s, s_part, st);
-#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::route_fwd(g, Z, t, p, a, s, s_part, st);
+int fast_route_fwd(const dl_csr_plan* g, const dl_csr_plan* upper, const int32_t* rev, const void* Z, int K, int d,
+                   int dtype, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
+#define X_F32(KK, DD) \
+    if (K == KK && d == DD) return fast::Ops<KK, DD, float>::route_fwd(g, upper, rev, Z, t, p, a, s, s_part, st);
+#define X_BF16(KK, DD) \
+    if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::route_fwd(g, upper, rev, Z, t, p, a, s, s_part, st);
     DL_DISPATCH(X)
 #undef X_F32
 #undef X_BF16

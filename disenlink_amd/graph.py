@@ -73,7 +73,9 @@ class CsrPlan:
 
     @staticmethod
     def build(rowptr: torch.Tensor, col: torch.Tensor, n_total: int, row_offset: int = 0,
-              seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1) -> "CsrPlan":
+              seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1, keep: torch.Tensor | None = None) -> "CsrPlan":
+        """``keep`` (bool per entry, optional): segments cover only the kept entries, which must form one
+        contiguous run inside every row (e.g. the upper triangle ``col >= row`` of a sorted row)."""
         if seg_len < 1 or n_slices < 1:
             raise ValueError("seg_len and n_slices must be >= 1")
         rowptr = rowptr.to(torch.int64)
@@ -82,21 +84,32 @@ class CsrPlan:
         if row_offset < 0 or row_offset + n_rows > n_total:
             raise ValueError("row block outside [0, n_total)")
         dev = rowptr.device
-        E = int(col.numel())
-        deg = rowptr[1:] - rowptr[:-1]
+        E_all = int(col.numel())
+        deg_all = rowptr[1:] - rowptr[:-1]
         ar = lambda n: torch.arange(n, device=dev)
         # groups = maximal entry ranges with equal (row, column slice); entries are sorted by (row, col)
         width = max(1, (n_total + n_slices - 1) // n_slices)
-        row_of = torch.repeat_interleave(ar(n_rows), deg)
-        gid = row_of * n_slices + (torch.div(col, width, rounding_mode="floor") if n_slices > 1 else 0)
+        row_all = torch.repeat_interleave(ar(n_rows), deg_all)
+        if keep is None:
+            orig, row_of, kcol = ar(E_all), row_all, col
+        else:
+            orig = torch.nonzero(keep.to(dev)).reshape(-1)          # original entry index of every kept entry
+            row_of, kcol = row_all[orig], col[orig]
+        E = int(orig.numel())
+        deg = torch.bincount(row_of, minlength=n_rows) if E else torch.zeros(n_rows, dtype=torch.int64, device=dev)
+        gid = row_of * n_slices + (torch.div(kcol, width, rounding_mode="floor") if n_slices > 1 else 0)
         if E and n_slices > 1 and bool((gid[1:] < gid[:-1]).any()):
             raise ValueError("sliced plans need col ascending inside every row")
         new = torch.ones(E, dtype=torch.bool, device=dev)
         if E:
             new[1:] = gid[1:] != gid[:-1]
-        gstart = torch.nonzero(new).reshape(-1)
-        gend = torch.cat([gstart[1:], torch.tensor([E], device=dev)]) if E else gstart
-        g_id = gid[gstart] if E else gstart
+            if keep is not None and bool(((orig[1:] != orig[:-1] + 1) & ~new[1:]).any()):
+                raise ValueError("kept entries must be contiguous inside every row")
+        gpos = torch.nonzero(new).reshape(-1)                       # positions in the kept list
+        gpos_end = torch.cat([gpos[1:], torch.tensor([E], device=dev)]) if E else gpos
+        gstart = orig[gpos] if E else gpos                          # ... and as original entry indices
+        gend = (orig[gpos_end - 1] + 1) if E else gpos
+        g_id = gid[gpos] if E else gpos
         nch = (gend - gstart + seg_len - 1) // seg_len
         ch0 = torch.cumsum(nch, 0) - nch
         seg_g = torch.repeat_interleave(ar(gstart.numel()), nch)
@@ -111,7 +124,7 @@ class CsrPlan:
         seg_end = torch.cat([seg_end, rowptr[empty]])
         seg_slice = torch.cat([seg_slice, torch.zeros_like(empty)])
         # row order: index of a segment inside its row -> partial slots of multi-segment rows
-        order = torch.argsort(seg_row * (E + 1) + seg_beg, stable=True)
+        order = torch.argsort(seg_row * (E_all + 1) + seg_beg, stable=True)
         seg_row, seg_beg, seg_end, seg_slice = seg_row[order], seg_beg[order], seg_end[order], seg_slice[order]
         nseg_row = torch.bincount(seg_row, minlength=n_rows)
         row_seg0 = torch.cumsum(nseg_row, 0) - nseg_row
@@ -149,7 +162,9 @@ class CsrPlan:
 @dataclass
 class Graph:
     plan: CsrPlan
-    rev: torch.Tensor | None = None      # reverse-edge permutation (unsharded builds only; used by tests/oracle)
+    rev: torch.Tensor | None = None      # reverse-edge permutation (unsharded builds only)
+    upper: CsrPlan | None = None         # segments over the entries with col >= row (unsharded builds only):
+                                         # routing is symmetric, so it is computed once per undirected edge
     _struct: _lib.DlGraph | None = field(default=None, repr=False)
 
     # convenience views
@@ -202,7 +217,11 @@ class Graph:
         full_ptr[1:] = torch.cumsum(counts, dim=0)
         e0, e1 = int(full_ptr[lo]), int(full_ptr[hi])
         plan = CsrPlan.build(full_ptr[lo:hi + 1] - e0, c[e0:e1], n_nodes, row_offset=lo, seg_len=seg_len)
-        return Graph(plan, _i32(rev) if row_range is None else None)
+        if row_range is not None:
+            return Graph(plan, None, None)
+        upper = CsrPlan.build(full_ptr, c, n_nodes, seg_len=seg_len, keep=(c >= r))
+        upper.rowptr, upper.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
+        return Graph(plan, _i32(rev), upper)
 
     @staticmethod
     def from_dense(adj: torch.Tensor, seg_len: int = DEFAULT_SEG_LEN) -> "Graph":
@@ -213,11 +232,16 @@ class Graph:
         return Graph.from_edge_rows(nz[:, 0], nz[:, 1], adj.shape[0], symmetrise=False, seg_len=seg_len)
 
     def to(self, device) -> "Graph":
-        return Graph(self.plan.to(device), None if self.rev is None else self.rev.to(device))
+        plan = self.plan.to(device)
+        upper = None if self.upper is None else self.upper.to(device)
+        if upper is not None:
+            upper.rowptr, upper.col = plan.rowptr, plan.col
+        return Graph(plan, None if self.rev is None else self.rev.to(device), upper)
 
     def c_struct(self):
         if self._struct is None:
-            self._struct = _lib.DlGraph(self.plan.c_value())
+            up = self.upper.c_value() if self.upper is not None else _lib.DlCsrPlan()
+            self._struct = _lib.DlGraph(self.plan.c_value(), up, self.rev.data_ptr() if self.rev is not None else None)
         return C.byref(self._struct)
 
     def c_plan(self):

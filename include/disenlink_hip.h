@@ -83,6 +83,12 @@ typedef struct dl_csr_plan {
  * directed non-zeros of adj_sym, col ascending inside a row, both directions present. */
 typedef struct dl_graph {
     dl_csr_plan csr;
+    /* Optional (unsharded plans only; upper.n_seg == 0 or rev == NULL disables it): a segment plan over
+     * the entries with col >= row of the SAME rowptr/col arrays, and the reverse-entry permutation
+     * rev[e] = index of (col[e], row(e)).  Routing is symmetric — (i,j) and (j,i) evaluate the same
+     * fma chain — so dl_route_fwd computes each undirected edge once and writes both entries. */
+    dl_csr_plan upper;
+    const int32_t* rev;         /* [n_entries] */
 } dl_graph;
 
 /* A CSR over pair slots: row u lists other endpoints (csr.col) and pair ids (inc_pair).

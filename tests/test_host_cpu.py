@@ -111,6 +111,17 @@ def test_graph_builder_matches_oracle_csr(name):
         assert np.array_equal(G.col.numpy(), col)
         assert np.array_equal(G.rev.numpy(), rev)
         _check_plan(G.plan, rowptr, seg_len)
+        # upper plan: exactly the entries with col >= row, each once, in segments of <= seg_len
+        up = G.upper
+        assert up.rowptr.data_ptr() == G.plan.rowptr.data_ptr() and up.col.data_ptr() == G.plan.col.data_ptr()
+        src = np.repeat(np.arange(G.n_nodes), np.diff(rowptr))
+        cover = np.zeros(col.size, int)
+        for r_, b_, e_ in zip(up.seg_row.numpy(), up.seg_beg.numpy(), up.seg_end.numpy()):
+            assert 0 <= e_ - b_ <= seg_len and (src[b_:e_] == r_).all()
+            cover[b_:e_] += 1
+        assert np.array_equal(cover, (col >= src).astype(int))
+        assert sorted(up.seg_row.numpy().tolist()) == sorted(set(up.seg_row.numpy().tolist()) | set(range(G.n_nodes)))[:0] \
+            or set(up.seg_row.numpy().tolist()) == set(range(G.n_nodes))            # every row owns >= 1 segment
         # a shard keeps global column ids and re-bases rowptr
         lo, hi = G.n_nodes // 3, G.n_nodes - 2
         nz = np.nonzero(g["adj"])
