@@ -65,7 +65,8 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0):
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
     order = np.lexsort((pv, pu))                      # pair list laid out by u: long runs share the u rows
     pu, pv = pu[order], pv[order]
-    pairs = PairList.build(torch.from_numpy(pu).to(device), torch.from_numpy(pv).to(device), sg.n_nodes)
+    pairs = PairList.build(torch.from_numpy(pu).to(device), torch.from_numpy(pv).to(device), sg.n_nodes,
+                           row_bytes=K * d * 4)
     torch.manual_seed(seed)
     model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.5, t=1).to(device)
     x = torch.from_numpy(sg.features()).to(device)

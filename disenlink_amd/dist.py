@@ -92,10 +92,11 @@ class HipBackend:
         self.ops.route_aggregate_bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ_out, accumulate)
 
 
-def _incidence_only(pu, pv, n_nodes, lo, hi) -> PairList:
+def _incidence_only(pu, pv, n_nodes, lo, hi, row_bytes=2048) -> PairList:
     """PairList over the WHOLE pair list whose incidence rows are this shard's nodes; its forward
     plan is left empty (the forward scores a slice through another PairList)."""
-    full = PairList.build(pu, pv, n_nodes, row_range=(lo, hi), by_u_range=(0, n_nodes), build_by_u=False)
+    full = PairList.build(pu, pv, n_nodes, row_range=(lo, hi), by_u_range=(0, n_nodes), build_by_u=False,
+                          row_bytes=row_bytes)
     return full
 
 
@@ -119,7 +120,7 @@ class Shard:
 
     @staticmethod
     def build(rank: int, world: int, n_nodes: int, edge_src, edge_dst, pu, pv, device,
-              seg_len: int = 32) -> "Shard":
+              seg_len: int = 32, row_bytes: int = 2048) -> "Shard":
         """edge rows = TRAIN edge rows (directed, duplicates ok); pu/pv = the global pair list, sorted by pu."""
         pu = np.asarray(pu, dtype=np.int64)
         pv = np.asarray(pv, dtype=np.int64)
@@ -133,8 +134,9 @@ class Shard:
         cuts = pair_slices(pu, n_nodes, world)
         q0, q1 = int(cuts[rank]), int(cuts[rank + 1])
         tpu, tpv = torch.as_tensor(pu, device=device), torch.as_tensor(pv, device=device)
-        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, row_range=(lo, lo), by_u_range=(lo, hi))
-        inc = _incidence_only(tpu, tpv, n_pad, lo, hi)
+        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, row_range=(lo, lo), by_u_range=(lo, hi),
+                               row_bytes=row_bytes)
+        inc = _incidence_only(tpu, tpv, n_pad, lo, hi, row_bytes)
         block = int(np.max(np.diff(cuts))) if pu.size else 0
         return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts)
 
@@ -244,7 +246,7 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
     order = np.lexsort((pv, pu))
     pu, pv = pu[order], pv[order]
-    shard = Shard.build(rank, world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device)
+    shard = Shard.build(rank, world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device, row_bytes=K * d * 4)
     torch.manual_seed(0)
     model = Disentangle(sg.n_feat, args.nhidden, d, nfactor=K, beta=beta, t=1).to(device)
     r0, r1 = shard.local_real_rows()
@@ -304,7 +306,8 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
     order = np.lexsort((pv, pu))
-    shard = Shard.build(0, emu_world, sg.n_nodes, split.train_src, split.train_dst, pu[order], pv[order], device)
+    shard = Shard.build(0, emu_world, sg.n_nodes, split.train_src, split.train_dst, pu[order], pv[order], device,
+                        row_bytes=K * d * 4)
     backend = HipBackend()
     Z = torch.randn((shard.n_pad, K, d), device=device) * 0.24
     s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)

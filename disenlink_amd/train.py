@@ -36,13 +36,14 @@ class PreparedRun:
     m: int
 
 
-def prepare_run(split: LinkSplit, device, seg_len: int = 32) -> PreparedRun:
+def prepare_run(split: LinkSplit, device, seg_len: int = 32, row_bytes: int = 2048) -> PreparedRun:
+    """``row_bytes`` = K * d * 4 of the model (sizes the XCD slicing of the pair plans)."""
     t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
     graph = Graph.from_edge_rows(t(split.train_src), t(split.train_dst), split.n_nodes, seg_len=seg_len)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u, split.val.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v, split.val.v])
-    tv = PairList.build(t(pu), t(pv), split.n_nodes, seg_len=seg_len)
-    te = PairList.build(t(split.test.u), t(split.test.v), split.n_nodes, seg_len=seg_len)
+    tv = PairList.build(t(pu), t(pv), split.n_nodes, row_bytes=row_bytes)
+    te = PairList.build(t(split.test.u), t(split.test.v), split.n_nodes, row_bytes=row_bytes)
     return PreparedRun(graph, tv, split.pos_train.u.size, split.neg_train.u.size,
                        t(split.pos_train.label, torch.float32), t(split.neg_train.label, torch.float32),
                        t(split.val.label, torch.float32), te, t(split.test.label, torch.float32), split.m)

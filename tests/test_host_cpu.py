@@ -62,7 +62,7 @@ def test_ops_fail_loudly_on_cpu_tensors():
         ops.route_fwd(g, Z, 1.0)
 
 
-def _check_plan(plan, rowptr, seg_len):
+def _check_plan(plan, rowptr, seg_len, col_slices=None):
     """segment plan: every row covered exactly once, in order, by segments of <= seg_len entries that
     never span two column slices; multi-segment rows own consecutive partial slots in entry order;
     segments are stored slice-major"""
@@ -70,15 +70,20 @@ def _check_plan(plan, rowptr, seg_len):
     col = plan.col.numpy()
     seg_row, seg_beg, seg_end = plan.seg_row.numpy(), plan.seg_beg.numpy(), plan.seg_end.numpy()
     seg_slot, sl0 = plan.seg_slot.numpy(), plan.slice_seg0.numpy()
-    width = max(1, -(-plan.n_total // plan.n_slices))
+    col_slices = col_slices or plan.n_slices          # plan.n_slices = XCD streams; col_slices = column slices
+    width = max(1, -(-plan.n_total // col_slices))
     assert sl0[0] == 0 and sl0[-1] == plan.n_seg and plan.slice_max_seg == np.diff(sl0).max()
     by_row = {i: [] for i in range(plan.n_rows)}
     for x in range(plan.n_slices):
+        last_q = -1
         for sgi in range(sl0[x], sl0[x + 1]):
             b, e = seg_beg[sgi], seg_end[sgi]
             assert 0 <= e - b <= seg_len
-            if e > b and plan.n_slices > 1:
-                assert (col[b:e] // width == x).all()
+            if e > b and col_slices > 1:
+                q = col[b] // width
+                assert (col[b:e] // width == q).all()            # inside one column slice ...
+                assert q % plan.n_slices == x and q >= last_q    # ... of this stream, slices in time order
+                last_q = q
             by_row[seg_row[sgi]].append((b, e, seg_slot[sgi]))
     multi = []
     for i in range(plan.n_rows):
@@ -134,6 +139,9 @@ def test_graph_builder_matches_oracle_csr(name):
         from disenlink_amd.graph import CsrPlan
         sliced = CsrPlan.build(G.rowptr, G.col, G.n_nodes, seg_len=seg_len, n_slices=8)
         _check_plan(sliced, rowptr, seg_len)
+        multi = CsrPlan.build(G.rowptr, G.col, G.n_nodes, seg_len=seg_len, n_slices=24)   # 3 slices per XCD stream
+        assert multi.n_slices == 8
+        _check_plan(multi, rowptr, seg_len, col_slices=24)
 
 
 def test_graph_from_edge_rows_symmetrises_and_collapses_duplicates():
@@ -162,7 +170,7 @@ def test_pair_incidence_lists_every_slot_once():
     n, P = 11, 60
     pu, pv = rng.integers(0, n, P), rng.integers(0, n, P)
     pu[:3] = pv[:3]                                   # self pairs
-    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=4, run_len=4)
+    pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=4, run_len=4, n_slices=8)
     ptr, other, pair = pl.inc.rowptr.numpy(), pl.inc.col.numpy(), pl.inc_pair.numpy()
     assert ptr[-1] == 2 * P
     seen = np.zeros(P, int)
@@ -184,7 +192,8 @@ def test_pair_incidence_lists_every_slot_once():
     _check_plan(pl.by_u, uptr, 4)
     assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 8
     from disenlink_amd.graph import auto_slices
-    assert auto_slices(5201, 2048) == 8 and auto_slices(41554, 8192) == 1 and auto_slices(2_900_000, 2048) == 1
+    assert auto_slices(5201, 2048, 200) == 8 and auto_slices(2_900_000, 2048, 24) == 1
+    assert auto_slices(41608, 2048, 209) == 32 and auto_slices(41608, 2048, 10) == 1
     # a shard lists only its own nodes' slots
     sh = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, row_range=(3, 8))
     assert sh.inc.n_rows == 5 and sh.inc.row_offset == 3
