@@ -60,7 +60,7 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0):
     sg = synthetic_graph(name, seed=seed, scale=scale)
     split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=m, seed=seed)
     graph = Graph.from_edge_rows(torch.from_numpy(split.train_src).to(device),
-                                 torch.from_numpy(split.train_dst).to(device), sg.n_nodes)
+                                 torch.from_numpy(split.train_dst).to(device), sg.n_nodes, row_bytes=K * d * 4)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
     order = np.lexsort((pv, pu))                      # pair list laid out by u: long runs share the u rows

@@ -23,7 +23,7 @@ class DlCsrPlan(C.Structure):
 
 
 class DlGraph(C.Structure):
-    _fields_ = [("csr", DlCsrPlan), ("upper", DlCsrPlan), ("rev", C.c_void_p)]
+    _fields_ = [("csr", DlCsrPlan), ("route", DlCsrPlan), ("rev", C.c_void_p), ("route_mirror", C.c_int32)]
 
 
 class DlPairIncidence(C.Structure):

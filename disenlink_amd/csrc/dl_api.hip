@@ -144,12 +144,15 @@ int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype,
     if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        // symmetric routing: one evaluation per undirected edge when the caller supplied the upper plan
-        const dl_csr_plan* up = &g->upper;
-        const bool mirror = g->rev != nullptr && c->row_offset == 0 && c->n_rows == c->n_total && has_seg_plan(up) &&
-                            up->n_rows == c->n_rows && up->n_total == c->n_total && up->rowptr == c->rowptr &&
-                            up->col == c->col;
-        return fast_route_fwd(c, mirror ? up : nullptr, g->rev, Z, K, d, dtype, t, p, a, s, w.vec_part,
+        // optional routing plan (XCD-sliced and / or upper-triangle with mirrored writes)
+        const dl_csr_plan* rp = &g->route;
+        const bool have = has_seg_plan(rp) && rp->n_rows == c->n_rows && rp->n_total == c->n_total &&
+                          rp->row_offset == c->row_offset && rp->rowptr == c->rowptr && rp->col == c->col;
+        const bool mirror = have && g->route_mirror != 0;
+        if (mirror)
+            DL_REQUIRE((g->rev != nullptr || c->n_entries == 0) && c->row_offset == 0 && c->n_rows == c->n_total,
+                       "route_mirror needs rev and an unsharded plan");
+        return fast_route_fwd(c, have ? rp : nullptr, mirror, g->rev, Z, K, d, dtype, t, p, a, s, w.vec_part,
                               (hipStream_t)stream);
     }
     return generic_route_fwd(c, (const float*)Z, K, d, t, p, a, s, (hipStream_t)stream);

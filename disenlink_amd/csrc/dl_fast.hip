@@ -766,14 +766,16 @@ template <int K, int D, typename T>
 struct Ops {
     static constexpr int ROW = K * D;
 
-    // `upper` (with `rev`) non-NULL: compute each undirected edge once and mirror it
-    static int route_fwd(const dl_csr_plan* g, const dl_csr_plan* upper, const int32_t* rev, const void* Z, float t,
-                         uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
-        if (upper)
-            hipLaunchKernelGGL((route_seg_kernel<K, D, T, true>), dim3(seg_blocks(upper)), dim3(BLOCK), 0, st, *upper,
-                               rev, (const T*)Z, t, p, a);
+    // `route`: the (possibly sliced / upper-triangle) plan the routing kernel walks, NULL = g itself;
+    // mirror: it covers col >= row only and every result is also written through rev
+    static int route_fwd(const dl_csr_plan* g, const dl_csr_plan* route, bool mirror, const int32_t* rev,
+                         const void* Z, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
+        const dl_csr_plan* rp = route ? route : g;
+        if (mirror)
+            hipLaunchKernelGGL((route_seg_kernel<K, D, T, true>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
+                               (const T*)Z, t, p, a);
         else
-            hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, rev,
+            hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
                                (const T*)Z, t, p, a);
         hipLaunchKernelGGL(s_rowsum_seg_kernel, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, K, p, a, s, s_part);
         launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
@@ -879,12 +881,13 @@ bool fast_supported(int K, int d, int dtype) {
     set_error("no tuned kernel for K=%d d=%d dtype=%d", K, d, dtype);                             \
     return DL_E_ARG;
 
-int fast_route_fwd(const dl_csr_plan* g, const dl_csr_plan* upper, const int32_t* rev, const void* Z, int K, int d,
-                   int dtype, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
+int fast_route_fwd(const dl_csr_plan* g, const dl_csr_plan* route, bool mirror, const int32_t* rev, const void* Z,
+                   int K, int d, int dtype, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
 #define X_F32(KK, DD) \
-    if (K == KK && d == DD) return fast::Ops<KK, DD, float>::route_fwd(g, upper, rev, Z, t, p, a, s, s_part, st);
-#define X_BF16(KK, DD) \
-    if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::route_fwd(g, upper, rev, Z, t, p, a, s, s_part, st);
+    if (K == KK && d == DD) return fast::Ops<KK, DD, float>::route_fwd(g, route, mirror, rev, Z, t, p, a, s, s_part, st);
+#define X_BF16(KK, DD)      \
+    if (K == KK && d == DD) \
+        return fast::Ops<KK, DD, fast::bf16_t>::route_fwd(g, route, mirror, rev, Z, t, p, a, s, s_part, st);
     DL_DISPATCH(X)
 #undef X_F32
 #undef X_BF16

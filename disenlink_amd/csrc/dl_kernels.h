@@ -23,8 +23,8 @@ int generic_bwd_phase2(const dl_csr_plan* c, const float* Z, int K, int d, float
 
 // tuned, per-(K, D, table type) instantiations (dl_fast.hip)
 bool fast_supported(int K, int d, int dtype);
-int fast_route_fwd(const dl_csr_plan* g, const dl_csr_plan* upper, const int32_t* rev, const void* Z, int K, int d,
-                   int dtype, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st);
+int fast_route_fwd(const dl_csr_plan* g, const dl_csr_plan* route, bool mirror, const int32_t* rev, const void* Z,
+                   int K, int d, int dtype, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st);
 int fast_aggregate_fwd(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, const uint8_t* p,
                        const float* a, const float* s, void* H, float* h_part, hipStream_t st);
 int fast_bwd_phase1(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, const uint8_t* p,

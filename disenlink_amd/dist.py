@@ -130,7 +130,8 @@ class Shard:
         lo, hi = row_range(n_nodes, world, rank)
         ts = torch.as_tensor(np.asarray(edge_src), device=device)
         td = torch.as_tensor(np.asarray(edge_dst), device=device)
-        graph = Graph.from_edge_rows(ts, td, n_pad, symmetrise=True, seg_len=seg_len, row_range=(lo, hi))
+        graph = Graph.from_edge_rows(ts, td, n_pad, symmetrise=True, seg_len=seg_len, row_range=(lo, hi),
+                                     row_bytes=row_bytes)
         cuts = pair_slices(pu, n_nodes, world)
         q0, q1 = int(cuts[rank]), int(cuts[rank + 1])
         tpu, tpv = torch.as_tensor(pu, device=device), torch.as_tensor(pv, device=device)

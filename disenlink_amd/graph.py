@@ -185,8 +185,9 @@ class CsrPlan:
 class Graph:
     plan: CsrPlan
     rev: torch.Tensor | None = None      # reverse-edge permutation (unsharded builds only)
-    upper: CsrPlan | None = None         # segments over the entries with col >= row (unsharded builds only):
-                                         # routing is symmetric, so it is computed once per undirected edge
+    route: CsrPlan | None = None         # plan walked by the routing kernel: XCD-sliced, and (unsharded builds)
+    route_mirror: bool = False           # covering col >= row only — routing is symmetric, so each undirected
+                                         # edge is computed once and written to both entries through rev
     _struct: _lib.DlGraph | None = field(default=None, repr=False)
 
     # convenience views
@@ -202,7 +203,8 @@ class Graph:
     # ------------------------------------------------------------------ builders
     @staticmethod
     def from_edge_rows(src: torch.Tensor, dst: torch.Tensor, n_nodes: int, symmetrise: bool = True,
-                       seg_len: int = DEFAULT_SEG_LEN, row_range: tuple[int, int] | None = None) -> "Graph":
+                       seg_len: int = DEFAULT_SEG_LEN, row_range: tuple[int, int] | None = None,
+                       row_bytes: int = 2048) -> "Graph":
         """Directed edge rows (duplicates allowed) -> CSR of the binarised adjacency.
 
         ``symmetrise=True`` reproduces ``adj_sym = (adj + adj.T) != 0`` (main_disentangled.py:141-142).
@@ -239,31 +241,37 @@ class Graph:
         full_ptr[1:] = torch.cumsum(counts, dim=0)
         e0, e1 = int(full_ptr[lo]), int(full_ptr[hi])
         plan = CsrPlan.build(full_ptr[lo:hi + 1] - e0, c[e0:e1], n_nodes, row_offset=lo, seg_len=seg_len)
-        if row_range is not None:
-            return Graph(plan, None, None)
-        upper = CsrPlan.build(full_ptr, c, n_nodes, seg_len=seg_len, keep=(c >= r))
-        upper.rowptr, upper.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
-        return Graph(plan, _i32(rev), upper)
+        mirror = row_range is None
+        lc, lr = c[e0:e1], r[e0:e1] - lo
+        # XCD slicing of the routing plan was measured and rejected: hub rows already give the Z gathers a high
+        # L2 hit rate, and the extra segments cost more than they save (squirrel 50 -> 72 us; 41.6k-node shard
+        # 115 -> 107 us).  `row_bytes` is kept for callers that pass the model shape.
+        route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo, seg_len=seg_len, n_slices=1,
+                              keep=(lc >= lr + lo) if mirror else None)
+        route.rowptr, route.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
+        return Graph(plan, _i32(rev) if mirror else None, route, mirror)
 
     @staticmethod
-    def from_dense(adj: torch.Tensor, seg_len: int = DEFAULT_SEG_LEN) -> "Graph":
+    def from_dense(adj: torch.Tensor, seg_len: int = DEFAULT_SEG_LEN, row_bytes: int = 2048) -> "Graph":
         """Dense ``adj_sym`` as the reference passes it to ``model(x, adj_sym)`` (main_disentangled.py:194)."""
         if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
             raise ValueError("adj must be square")
         nz = torch.nonzero(adj)
-        return Graph.from_edge_rows(nz[:, 0], nz[:, 1], adj.shape[0], symmetrise=False, seg_len=seg_len)
+        return Graph.from_edge_rows(nz[:, 0], nz[:, 1], adj.shape[0], symmetrise=False, seg_len=seg_len,
+                                    row_bytes=row_bytes)
 
     def to(self, device) -> "Graph":
         plan = self.plan.to(device)
-        upper = None if self.upper is None else self.upper.to(device)
-        if upper is not None:
-            upper.rowptr, upper.col = plan.rowptr, plan.col
-        return Graph(plan, None if self.rev is None else self.rev.to(device), upper)
+        route = None if self.route is None else self.route.to(device)
+        if route is not None:
+            route.rowptr, route.col = plan.rowptr, plan.col
+        return Graph(plan, None if self.rev is None else self.rev.to(device), route, self.route_mirror)
 
     def c_struct(self):
         if self._struct is None:
-            up = self.upper.c_value() if self.upper is not None else _lib.DlCsrPlan()
-            self._struct = _lib.DlGraph(self.plan.c_value(), up, self.rev.data_ptr() if self.rev is not None else None)
+            rp = self.route.c_value() if self.route is not None else _lib.DlCsrPlan()
+            self._struct = _lib.DlGraph(self.plan.c_value(), rp, self.rev.data_ptr() if self.rev is not None else None,
+                                        1 if self.route_mirror else 0)
         return C.byref(self._struct)
 
     def c_plan(self):

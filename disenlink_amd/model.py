@@ -105,7 +105,7 @@ class Disentangle(nn.Module):
     def _graph_for(self, adj: torch.Tensor) -> Graph:
         key = (adj.data_ptr(), tuple(adj.shape), adj._version, adj.device)
         if self._graph_cache is None or self._graph_cache[0] != key:
-            self._graph_cache = (key, Graph.from_dense(adj))
+            self._graph_cache = (key, Graph.from_dense(adj, row_bytes=self.nfactor * self.nebed * 4))
         return self._graph_cache[1]
 
     # ------------------------------------------------------------------ forward

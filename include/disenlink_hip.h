@@ -83,12 +83,14 @@ typedef struct dl_csr_plan {
  * directed non-zeros of adj_sym, col ascending inside a row, both directions present. */
 typedef struct dl_graph {
     dl_csr_plan csr;
-    /* Optional (unsharded plans only; upper.n_seg == 0 or rev == NULL disables it): a segment plan over
-     * the entries with col >= row of the SAME rowptr/col arrays, and the reverse-entry permutation
-     * rev[e] = index of (col[e], row(e)).  Routing is symmetric — (i,j) and (j,i) evaluate the same
-     * fma chain — so dl_route_fwd computes each undirected edge once and writes both entries. */
-    dl_csr_plan upper;
-    const int32_t* rev;         /* [n_entries] */
+    /* Optional second segment plan over the SAME rowptr/col arrays, used by dl_route_fwd only (route.n_seg == 0
+     * disables it).  It may be XCD-sliced (routing gathers whole Z rows, K*d*4 bytes per edge), and with
+     * route_mirror != 0 it covers only the entries with col >= row: routing is symmetric — (i,j) and (j,i)
+     * evaluate the same fma chain — so each undirected edge is computed once and written to both entries
+     * through rev[e] = index of (col[e], row(e)).  Mirroring needs an unsharded plan. */
+    dl_csr_plan route;
+    const int32_t* rev;         /* [n_entries], needed when route_mirror != 0 */
+    int32_t route_mirror;
 } dl_graph;
 
 /* A CSR over pair slots: row u lists other endpoints (csr.col) and pair ids (inc_pair).

@@ -117,8 +117,8 @@ def test_graph_builder_matches_oracle_csr(name):
         assert np.array_equal(G.rev.numpy(), rev)
         _check_plan(G.plan, rowptr, seg_len)
         # upper plan: exactly the entries with col >= row, each once, in segments of <= seg_len
-        up = G.upper
-        assert up.rowptr.data_ptr() == G.plan.rowptr.data_ptr() and up.col.data_ptr() == G.plan.col.data_ptr()
+        up = G.route
+        assert G.route_mirror and up.rowptr.data_ptr() == G.plan.rowptr.data_ptr() and up.col.data_ptr() == G.plan.col.data_ptr()
         src = np.repeat(np.arange(G.n_nodes), np.diff(rowptr))
         cover = np.zeros(col.size, int)
         for r_, b_, e_ in zip(up.seg_row.numpy(), up.seg_beg.numpy(), up.seg_end.numpy()):
@@ -133,6 +133,7 @@ def test_graph_builder_matches_oracle_csr(name):
         S = Graph.from_edge_rows(torch.from_numpy(nz[0]), torch.from_numpy(nz[1]), G.n_nodes, symmetrise=False,
                                  seg_len=seg_len, row_range=(lo, hi))
         assert S.n_rows == hi - lo and S.row_offset == lo and S.n_nodes == G.n_nodes
+        assert not S.route_mirror and S.rev is None and S.route.n_entries == S.n_edges
         assert np.array_equal(S.rowptr.numpy(), rowptr[lo:hi + 1] - rowptr[lo])
         assert np.array_equal(S.col.numpy(), col[rowptr[lo]:rowptr[hi]])
         _check_plan(S.plan, S.rowptr.numpy(), seg_len)
