@@ -67,6 +67,41 @@ class Disentangle(nn.Module):
         self.nebed = nebed
         self.beta = beta
         self._graph_cache = None
+        self._stacked = {}
+        self._restack()
+
+    # ------------------------------------------------------------------ stacked parameter storage
+    # The K factor modules keep their own Parameters (and state_dict keys), but every group of K same-shaped
+    # parameters shares ONE contiguous [K, ...] buffer: parameter i's .data is the view buf[i].  The projection
+    # kernel reads the buffers directly — no torch.stack copies per call — and Adam / load_state_dict, which
+    # update parameters in place, keep the buffers current.
+    def _param_groups(self):
+        names = ("mlp",) if self.single_layer else ("mlp1", "mlp2")
+        for name in names:
+            for attr in ("weight", "bias"):
+                yield (name, attr), [getattr(getattr(f, name), attr) for f in self.factors]
+
+    def _restack(self):
+        for key, ps in self._param_groups():
+            buf = torch.stack([p.data for p in ps]).contiguous()
+            for i, p in enumerate(ps):
+                p.data = buf[i]
+            self._stacked[key] = buf
+
+    def _apply(self, fn, *args, **kwargs):                     # .to(device) / .float() replace .data: re-stack
+        out = super()._apply(fn, *args, **kwargs)
+        self._restack()
+        return out
+
+    def _stacked_params(self):
+        """(buffers by key, flat parameter list) if every parameter still aliases its buffer, else None."""
+        flat = []
+        for key, ps in self._param_groups():
+            buf = self._stacked.get(key)
+            if buf is None or any(p.data_ptr() != buf[i].data_ptr() or p.shape != buf[i].shape for i, p in enumerate(ps)):
+                return None
+            flat += ps
+        return flat
 
     @property
     def factors(self):
@@ -83,7 +118,13 @@ class Disentangle(nn.Module):
         if use_kernel and self.projection == "auto":
             use_kernel = d == 128 and x.shape[1] <= 128         # measured: tools/project_times.py, DESIGN.md §3
         if use_kernel:
-            # fused MFMA kernel; the stacks keep the per-factor parameters (and their state_dict keys) intact
+            flat = self._stacked_params()
+            if flat is not None:                                # zero-copy: the kernel reads the shared buffers
+                st = self._stacked
+                bufs = ((st[("mlp", "weight")], st[("mlp", "bias")], None, None) if self.single_layer else
+                        (st[("mlp1", "weight")], st[("mlp1", "bias")], st[("mlp2", "weight")], st[("mlp2", "bias")]))
+                return ops.ProjectStacked.apply(x, bufs, K, *flat)
+            # parameters were re-pointed by the caller: stack them (one copy per call)
             if self.single_layer:
                 return ops.Project.apply(x, torch.stack([f.mlp.weight for f in fs]),
                                          torch.stack([f.mlp.bias for f in fs]), None, None)

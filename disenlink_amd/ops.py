@@ -247,17 +247,8 @@ class Project(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dZ):
         x, W1, b1, W2 = ctx.saved_tensors
-        dZ = dZ.contiguous()
-        if not ctx.two_layer:                                   # Z[n,k,:] = W1[k] x[n] + b1[k]
-            dW1 = torch.einsum("nkd,nf->kdf", dZ, x)
-            return None, dW1, dZ.sum(dim=0), None, None
-        pre = torch.einsum("nf,khf->nkh", x, W1) + b1           # [N,K,nhid]
-        hid = torch.relu(pre)
-        dW2 = torch.einsum("nkd,nkh->kdh", dZ, hid)
-        db2 = dZ.sum(dim=0)
-        dhid = torch.einsum("nkd,kdh->nkh", dZ, W2) * (pre > 0)
-        dW1 = torch.einsum("nkh,nf->khf", dhid, x)
-        return None, dW1, dhid.sum(dim=0), dW2, db2
+        dW1, db1, dW2, db2 = _project_grads(x, W1, b1, W2 if ctx.two_layer else None, dZ.contiguous())
+        return None, dW1, db1, dW2, db2
 
 
 class RouteAggregate(torch.autograd.Function):
@@ -278,6 +269,42 @@ class RouteAggregate(torch.autograd.Function):
         Z, a, s = ctx.saved_tensors
         dZ = route_aggregate_bwd(ctx.graph, Z, ctx.beta, ctx.t, ctx.p, a, s, dH.contiguous())
         return dZ, None, None, None
+
+
+def _project_grads(x, W1, b1, W2, dZ):
+    """Library-GEMM backward of the projection on stacked weights -> (dW1, db1, dW2, db2)."""
+    if W2 is None:                                              # Z[n,k,:] = W1[k] x[n] + b1[k]
+        return torch.einsum("nkd,nf->kdf", dZ, x), dZ.sum(dim=0), None, None
+    pre = torch.einsum("nf,khf->nkh", x, W1) + b1               # [N,K,nhid]
+    hid = torch.relu(pre)
+    dW2 = torch.einsum("nkd,nkh->kdh", dZ, hid)
+    dhid = torch.einsum("nkd,kdh->nkh", dZ, W2) * (pre > 0)
+    return torch.einsum("nkh,nf->khf", dhid, x), dhid.sum(dim=0), dW2, dZ.sum(dim=0)
+
+
+class ProjectStacked(torch.autograd.Function):
+    """Projection over the module's shared [K, ...] parameter buffers (see Disentangle._restack): the K
+    per-factor Parameters are the autograd inputs, the kernel reads their common storage — no stacking copy —
+    and each parameter's gradient is a view of the stacked gradient."""
+
+    @staticmethod
+    def forward(ctx, x, bufs, K, *params):
+        W1, b1, W2, b2 = bufs
+        ctx.bufs, ctx.K = bufs, K
+        ctx.save_for_backward(x)
+        return project_fwd(x, W1, b1, W2, b2)
+
+    @staticmethod
+    def backward(ctx, dZ):
+        (x,) = ctx.saved_tensors
+        W1, b1, W2, b2 = ctx.bufs
+        dW1, db1, dW2, db2 = _project_grads(x, W1, b1, W2, dZ.contiguous())
+        K = ctx.K
+        grads = list(dW1.unbind(0)) + list(db1.unbind(0))
+        if W2 is not None:
+            grads += list(dW2.unbind(0)) + list(db2.unbind(0))
+        assert len(grads) == (2 if W2 is None else 4) * K
+        return (None, None, None, *grads)
 
 
 class HotPathPairs(torch.autograd.Function):
