@@ -17,27 +17,23 @@ def pair_bce_loss(prob_pos, label_pos, prob_neg, label_neg, m: int) -> torch.Ten
     return F.binary_cross_entropy(prob_pos, label_pos) + F.binary_cross_entropy(prob_neg, label_neg) / m
 
 
-def auc_tie_avg(label: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
-    """0-dim float64 tensor on score.device.  Raises if only one class is present."""
+def auc_tie_avg(label: torch.Tensor, score: torch.Tensor, check: bool = True) -> torch.Tensor:
+    """0-dim float64 tensor on score.device.  ``check=True`` raises if only one class is present (one
+    device->host sync); with ``check=False`` nothing here synchronises and a one-class input gives nan."""
     label = label.reshape(-1)
     score = score.reshape(-1).detach()
     n = score.numel()
     pos = label > 0.5
-    n_pos = pos.sum()
+    n_pos = pos.sum().to(torch.float64)
     n_neg = n - n_pos
-    if int(n_pos) == 0 or int(n_neg) == 0:
+    if check and (float(n_pos) == 0 or float(n_neg) == 0):
         raise ValueError("AUC undefined with one class")
     order = torch.argsort(score, stable=True)
     ss = score[order]
-    # runs of equal scores -> average 1-based rank (lo+1+hi)/2 with [lo, hi) the run
-    new_run = torch.ones(n, dtype=torch.bool, device=score.device)
-    new_run[1:] = ss[1:] != ss[:-1]
-    run_id = torch.cumsum(new_run, dim=0) - 1
-    starts = torch.nonzero(new_run).reshape(-1)
-    ends = torch.cat([starts[1:], torch.tensor([n], device=score.device)])
-    avg = (starts + 1 + ends).to(torch.float64) / 2.0
-    rank_sorted = avg[run_id]
-    r_pos = rank_sorted[pos[order]].sum()
-    n_pos = n_pos.to(torch.float64)
-    n_neg = n_neg.to(torch.float64)
+    # a run of equal scores occupies sorted positions [first, last]: average 1-based rank (first+last)/2 + 1.
+    # Two binary searches instead of unique / nonzero: no data-dependent shape, hence no host sync.
+    first = torch.searchsorted(ss, ss, right=False)
+    last = torch.searchsorted(ss, ss, right=True) - 1
+    rank_sorted = (first + last).to(torch.float64) / 2.0 + 1.0
+    r_pos = (rank_sorted * pos[order].to(torch.float64)).sum()
     return (r_pos - n_pos * (n_pos + 1.0) / 2.0) / (n_pos * n_neg)

@@ -93,6 +93,19 @@ class Disentangle(nn.Module):
         self._restack()
         return out
 
+    def snapshot_state(self):
+        """deepcopy(state_dict()) (main_disentangled.py:209) with one clone per shared buffer instead of one per
+        parameter; the result loads back with load_state_dict like any state_dict."""
+        if self._stacked_params() is None:
+            from copy import deepcopy
+            return deepcopy(self.state_dict())
+        clones = {key: buf.clone() for key, buf in self._stacked.items()}
+        out = {}
+        for i in range(self.nfactor):
+            for (name, attr), buf in clones.items():
+                out[f"factor_{i}.{name}.{attr}"] = buf[i]
+        return {k: out[k] for k in self.state_dict().keys()}
+
     def _stacked_params(self):
         """(buffers by key, flat parameter list) if every parameter still aliases its buffer, else None."""
         flat = []
@@ -102,6 +115,12 @@ class Disentangle(nn.Module):
                 return None
             flat += ps
         return flat
+
+    def train(self, mode: bool = True):
+        """No layer of this model depends on the mode (main_disentangled.py:193,201 call train()/eval() every
+        epoch as no-ops): set the flag without walking the K factor modules."""
+        self.training = mode
+        return self
 
     @property
     def factors(self):

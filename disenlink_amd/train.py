@@ -62,9 +62,13 @@ class RunResult:
 def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 2000, lr: float = 1e-4,
                         patience: int = 200, weight_decay: float = 5e-4, log=None) -> RunResult:
     opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
-    best_auc, stale, weights = 0.0, 0, deepcopy(model.state_dict())
+    snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
+    best_auc, stale, weights = 0.0, 0, snapshot()
     res = RunResult(float("nan"), 0.0, 0)
     a, b = run.n_pos, run.n_pos + run.n_neg
+    for lab in (run.label_val, run.label_test):                     # validated once: the per-epoch AUC never syncs
+        if not 0 < float(lab.sum()) < lab.numel():
+            raise ValueError("AUC undefined with one class")
     for epoch in range(epochs):
         model.train()
         _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
@@ -73,13 +77,14 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
         loss.backward()
         opt.step()
         model.eval()
-        auc = float(auc_tie_avg(run.label_val, prob[b:]))          # from the pre-step forward, like :202-204
-        res.losses.append(float(loss.detach()))
+        auc_t = auc_tie_avg(run.label_val, prob[b:], check=False)   # from the pre-step forward, like :202-204
+        loss_v, auc = torch.stack([loss.detach().double(), auc_t]).tolist()     # ONE device->host sync per epoch
+        res.losses.append(loss_v)
         res.val_aucs.append(auc)
         res.epochs_run = epoch + 1
         if auc > best_auc:
             stale, best_auc = 0, auc
-            weights = deepcopy(model.state_dict())
+            weights = snapshot()                                    # state AFTER the step, like :209
         else:
             stale += 1
         if stale > patience:
@@ -89,6 +94,6 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
     model.load_state_dict(weights)
     with torch.no_grad():
         _emb, prob = model.forward_pairs(x, run.graph, run.test_pairs)
-    res.test_auc = float(auc_tie_avg(run.label_test, prob))
+    res.test_auc = float(auc_tie_avg(run.label_test, prob, check=False))
     res.best_val_auc = best_auc
     return res
