@@ -198,6 +198,20 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
                                    (hipStream_t)stream);
 }
 
+int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t, float* prob,
+                          void* stream) {
+    if (int rc = check_shape(K, d)) return rc;
+    DL_REQUIRE(dtype == DL_F32 || dtype == DL_BF16, "unknown dtype %d", dtype);
+    DL_REQUIRE(N >= 0 && N <= 46340, "dense [N,N] scoring needs 0 <= N <= 46340, got %d", N);
+    DL_REQUIRE(t != 0.0f, "temperature is 0");
+    if (N == 0) return DL_OK;
+    DL_REQUIRE(Z && H && prob, "NULL argument");
+    if (!g_force_generic && fast_supported(K, d, dtype))
+        return fast_score_allpairs_fwd(Z, H, N, K, d, dtype, t, prob, (hipStream_t)stream);
+    DL_REQUIRE(dtype == DL_F32, "bf16 tables need a tuned kernel for K=%d d=%d", K, d);
+    return generic_score_allpairs_fwd((const float*)Z, (const float*)H, N, K, d, t, prob, (hipStream_t)stream);
+}
+
 int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob, const float* coef,
                        float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream) {

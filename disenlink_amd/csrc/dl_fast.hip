@@ -599,6 +599,58 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
     }
 }
 
+// Dense [N][N] scorer (the reference's link_pred, model.py:109-113): no pair list at all.  One wave = one
+// row u x one chunk of <= VCH consecutive columns; the column space is cut into n_slices XCD slices exactly
+// like the pair plans (workgroup b serves slice b % n_slices), so an XCD's L2 holds the v rows it gathers.
+template <int K, int D, typename T>
+__global__ __launch_bounds__(BLOCK) void score_allpairs_kernel(const T* __restrict__ Z, const T* __restrict__ H, int N,
+                                                               float t, int n_slices, int slice_w, int chunks_per_u,
+                                                               float* __restrict__ prob) {
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
+    constexpr int KB = K > 8 ? 8 : K;
+    using FLB = FactorLanes<G, KB>;
+    constexpr int KBP = FLB::KP;
+    constexpr int VCH = 256;
+    __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int x = blockIdx.x % n_slices;
+    const int item = (blockIdx.x / n_slices) * WAVES_PER_BLOCK + wave;
+    const int u = item / chunks_per_u, ch = item - u * chunks_per_u;
+    const int v0 = x * slice_w + ch * VCH;
+    const int v1 = min(min(v0 + VCH, (x + 1) * slice_w), N);
+    const bool active = u < N && v0 < v1;
+    if (active) stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)u);
+    __syncthreads();
+    if (!active) return;
+    const int c = lane % G, grp = lane / G;
+    const int kbb = FLB::factor_base(c);
+    for (int base = v0; base < v1; base += EPW) {
+        const int vi = base + grp;
+        const bool live = vi < v1;
+        const size_t v = (size_t)(live ? vi : v0);
+        float term = 0.0f;
+#pragma unroll
+        for (int b0 = 0; b0 < K; b0 += KB) {
+            float pq[KBP], ps[KBP];
+#pragma unroll
+            for (int k = 0; k < KBP; ++k) {
+                const bool in = k < KB && b0 + k < K;
+                const int kk = in ? b0 + k : 0;
+                pq[k] = in ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), Tab<T>::load(H + v * ROW + kk * D + c * VEC)) : 0.0f;
+                ps[k] = in ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), Tab<T>::load(Z + v * ROW + kk * D + c * VEC)) : 0.0f;
+            }
+            TransposedReduce<KBP, G / 2>::run(pq, c);
+            TransposedReduce<KBP, G / 2>::run(ps, c);
+#pragma unroll
+            for (int i = 0; i < FLB::VPL; ++i)
+                if (FLB::primary(c) && kbb + i < KB && b0 + kbb + i < K) term += pq[i] * expf(div_t(ps[i], t));
+        }
+        const float logit = group_allreduce_sum<G>(term);
+        if (live && c == 0) prob[(size_t)u * N + vi] = sigmoid_ref(logit);
+    }
+}
+
 // Scorer backward, recomputing e_k and q_k (used when the forward did not store them): one wave per
 // segment of node u's pair slots.  Partials (multi-segment rows) hold [dZ row | dH row] per slot.
 template <int K, int D, typename T>
@@ -825,6 +877,19 @@ struct Ops {
         return check_launch("score_pairs_fwd(fast)");
     }
 
+    static int score_allpairs(const void* Z, const void* H, int N, float t, float* prob, hipStream_t st) {
+        // slice the columns 8 ways only while a slice of Z+H can live in an XCD's L2 (like graph.auto_slices)
+        const double table = 2.0 * N * ROW * sizeof(T);
+        const int n_slices = table <= 8.0 * 8.0 * (4 << 20) && N >= 64 ? 8 : 1;
+        const int slice_w = (N + n_slices - 1) / n_slices;
+        const int chunks_per_u = (slice_w + 255) / 256;
+        const long long items = (long long)N * chunks_per_u;
+        const unsigned blocks = (unsigned)(n_slices * ((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+        hipLaunchKernelGGL((score_allpairs_kernel<K, D, T>), dim3(blocks), dim3(BLOCK), 0, st, (const T*)Z, (const T*)H, N,
+                           t, n_slices, slice_w, chunks_per_u, prob);
+        return check_launch("score_allpairs_fwd(fast)");
+    }
+
     static int score_bwd(const dl_pair_incidence* inc, const void* Z, const void* H, float t, const float* prob,
                          const float* g_prob, const float* coef, float* dZ, float* dH, float* part, hipStream_t st) {
         const dl_csr_plan* g = &inc->csr;
@@ -936,6 +1001,15 @@ int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void
                          float* part, hipStream_t st) {
 #define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::score_bwd(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
 #define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::score_bwd(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
+    DL_DISPATCH(X)
+#undef X_F32
+#undef X_BF16
+}
+
+int fast_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, int dtype, float t, float* prob,
+                            hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::score_allpairs(Z, H, N, t, prob, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::score_allpairs(Z, H, N, t, prob, st);
     DL_DISPATCH(X)
 #undef X_F32
 #undef X_BF16

@@ -111,6 +111,23 @@ __global__ __launch_bounds__(BLOCK) void score_pairs_fwd_kernel(
     if (lane_id() == 0) prob[q] = sigmoid_ref(logit);
 }
 
+// dense [N][N] scorer: one wave per (u, v) entry, row-major
+__global__ __launch_bounds__(BLOCK) void score_allpairs_fwd_kernel(const float* __restrict__ Z,
+                                                                   const float* __restrict__ H, int N, int K, int d,
+                                                                   float t, float* __restrict__ prob) {
+    const long long q = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (q >= (long long)N * N) return;
+    const size_t stride = (size_t)K * d;
+    const size_t u = (size_t)(q / N), v = (size_t)(q % N);
+    float logit = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        float qk = wave_dot(H + u * stride + k * d, H + v * stride + k * d, d);
+        float ek = expf(wave_dot(Z + u * stride + k * d, Z + v * stride + k * d, d) / t);
+        logit += qk * ek;
+    }
+    if (lane_id() == 0) prob[q] = sigmoid_ref(logit);
+}
+
 // dH[u] = sum_inc gl*e_k*h_k[v],  dZ[u] = sum_inc gl*q_k*e_k/t*z_k[v]  over the pair slots of node u.
 __global__ __launch_bounds__(BLOCK) void score_pairs_bwd_kernel(
     dl_csr_plan c, const int32_t* __restrict__ inc_pair, const float* __restrict__ Z, const float* __restrict__ H,
@@ -260,6 +277,14 @@ int generic_score_pairs_fwd(const float* Z, const float* H, int K, int d, float 
     hipLaunchKernelGGL(score_pairs_fwd_kernel, dim3(wave_blocks(P)), dim3(BLOCK), 0, st, Z, H, K, d, t, pu, pv, P,
                        prob);
     return check_launch("score_pairs_fwd(generic)");
+}
+
+int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
+                               hipStream_t st) {
+    const long long n = (long long)N * N;
+    hipLaunchKernelGGL(score_allpairs_fwd_kernel, dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)),
+                       dim3(BLOCK), 0, st, Z, H, N, K, d, t, prob);
+    return check_launch("score_allpairs_fwd(generic)");
 }
 
 int generic_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,

@@ -39,6 +39,11 @@ int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void
                          float t, const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
                          float* part, hipStream_t st);
 
+int fast_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, int dtype, float t, float* prob,
+                            hipStream_t st);
+int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
+                               hipStream_t st);
+
 // factor projection on the matrix cores (dl_project.hip)
 bool project_supported(int d);
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,

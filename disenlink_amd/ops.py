@@ -134,6 +134,20 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_
     return (prob, coef) if want_coef else prob
 
 
+def score_allpairs_fwd(Z, H, t: float) -> torch.Tensor:
+    """-> prob f32[N,N] for all ordered pairs: model.py:109-113 as written, without a pair list."""
+    lib = _lib.load()
+    (Z, dt), (H, dth) = _tab(Z), _tab(H)
+    _need_cuda(Z, H)
+    N, K, d = _nkd(Z)
+    if H.shape != Z.shape or dt != dth:
+        raise ValueError("Z and H differ in shape or storage type")
+    prob = torch.empty((N, N), dtype=torch.float32, device=Z.device)
+    _lib.check(lib.dl_score_allpairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), prob.data_ptr(),
+                                         _stream()), "dl_score_allpairs_fwd")
+    return prob
+
+
 def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, dH_out=None, coef=None):
     """-> dZ, dH f32[N,K,d] (rows of the incidence plan are written)."""
     lib = _lib.load()
@@ -356,19 +370,6 @@ class ScorePairs(torch.autograd.Function):
         return dZ, dH, None, None
 
 
-_all_pairs_cache: dict = {}
-
-
-def _all_pairs(N: int, device) -> PairList:
-    """Pair plan of the dense [N,N] output (row-major pair ids), cached per (N, device)."""
-    key = (N, str(device))
-    if key not in _all_pairs_cache:
-        idx = torch.arange(N, device=device)
-        _all_pairs_cache.clear()
-        _all_pairs_cache[key] = PairList.build(idx.repeat_interleave(N), idx.repeat(N), N, row_range=(0, 0))
-    return _all_pairs_cache[key]
-
-
 class ScoreAllPairs(torch.autograd.Function):
     """(Z, H) -> prob [N,N], the dense output the reference's caller indexes with masks
     (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero."""
@@ -376,11 +377,7 @@ class ScoreAllPairs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Z, H, t: float):
         Z, H = _f32c(Z), _f32c(H)
-        N = Z.shape[0]
-        if N * N >= 2 ** 30:
-            raise ValueError("dense [N,N] scoring needs 2*N*N < 2^31; use forward_pairs for large graphs")
-        allp = _all_pairs(N, Z.device)
-        prob = score_pairs_fwd(Z, H, allp.pu, allp.pv, t, allp).view(N, N)
+        prob = score_allpairs_fwd(Z, H, t)
         ctx.t = t
         ctx.save_for_backward(Z, H, prob)
         return prob

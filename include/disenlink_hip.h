@@ -155,6 +155,13 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
                        const dl_pair_incidence* by_u,
                        float* prob, float* coef, void* stream);
 
+/* Dense scorer: replaces model.py:109-113 as written — prob[u][v] for ALL N*N ordered pairs (row-major
+ * fp32 [N][N]), the link_pred the reference's caller indexes with dense masks (main_disentangled.py:195).
+ * No pair list is materialised.  Its backward is dl_score_pairs_bwd over the entries whose gradient is
+ * non-zero (the masked ones).  N*N must stay below 2^31 waves' worth of work: N <= 46340. */
+int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
+                          float* prob, void* stream);
+
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
  * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:
  *   gl = g_prob * prob * (1 - prob);  dH[u] += gl e_k H[v][k];  dZ[u] += gl (q_k e_k)/t Z[v][k]
