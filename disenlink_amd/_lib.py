@@ -30,11 +30,26 @@ class DlPairIncidence(C.Structure):
     _fields_ = [("csr", DlCsrPlan), ("inc_pair", C.c_void_p), ("n_pairs", C.c_int32)]
 
 
+class DlHostCsr(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_entries", C.c_int32), ("rowptr", C.POINTER(C.c_int32)),
+                ("col", C.POINTER(C.c_int32)), ("rev", C.POINTER(C.c_int32))]
+
+
+class DlHostPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("seg_len", "n_seg", "n_slices", "slice_max_seg", "n_multi", "n_slots")] + \
+               [(n, C.POINTER(C.c_int32)) for n in ("seg_row", "seg_beg", "seg_end", "seg_slot", "slice_seg0",
+                                                    "multi_row", "multi_slot0")]
+
+
 _P = C.c_void_p          # device pointers travel as integers
 _G, _I = C.POINTER(DlGraph), C.POINTER(DlPairIncidence)
 _i, _f, _z = C.c_int, C.c_float, C.c_size_t
 EXPORTS = {
     # name: (restype, argtypes) -- one entry per symbol declared in include/disenlink_hip.h
+    "dl_host_csr_from_edges": (_i, [_P, _P, C.c_int64, C.c_int32, _i, C.POINTER(DlHostCsr)]),
+    "dl_host_csr_free": (None, [C.POINTER(DlHostCsr)]),
+    "dl_host_plan_build": (_i, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.POINTER(DlHostPlan)]),
+    "dl_host_plan_free": (None, [C.POINTER(DlHostPlan)]),
     "dl_version": (C.c_char_p, []),
     "dl_last_error": (C.c_char_p, []),
     "dl_has_fast_path": (_i, [_i, _i]),

@@ -1,0 +1,152 @@
+// Host-side graph preparation behind the C ABI (no GPU work): the counterpart of the reference's
+// dense adjacency construction (main_disentangled.py:137-142) for callers that are not Python.
+// disenlink_amd/graph.py builds the same arrays with torch index ops on the device; tests check the
+// two against each other.  These functions malloc their outputs (freed by the matching *_free);
+// the per-epoch entry points never allocate.
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "dl_common.h"
+
+using namespace dl;
+
+namespace {
+
+template <typename T>
+T* dup(const std::vector<T>& v) {
+    T* p = (T*)malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dl_host_csr_from_edges(const int64_t* src, const int64_t* dst, int64_t n_edge_rows, int32_t n_nodes,
+                           int symmetrise, dl_host_csr* out) {
+    DL_REQUIRE(out != nullptr, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    DL_REQUIRE(n_nodes >= 0 && n_edge_rows >= 0, "negative size");
+    DL_REQUIRE(n_edge_rows == 0 || (src && dst), "src/dst is NULL");
+    std::vector<int64_t> key;
+    key.reserve((size_t)n_edge_rows * (symmetrise ? 2 : 1));
+    for (int64_t r = 0; r < n_edge_rows; ++r) {
+        const int64_t a = src[r], b = dst[r];
+        DL_REQUIRE(a >= 0 && a < n_nodes && b >= 0 && b < n_nodes, "edge row %lld: endpoint outside [0, %d)", (long long)r,
+                   n_nodes);
+        key.push_back(a * n_nodes + b);
+        if (symmetrise) key.push_back(b * n_nodes + a);
+    }
+    std::sort(key.begin(), key.end());                                   // duplicates collapse (binarised adjacency)
+    key.erase(std::unique(key.begin(), key.end()), key.end());
+    DL_REQUIRE(key.size() < (size_t)1 << 31, "more than 2^31-1 edges");
+    const size_t E = key.size();
+    std::vector<int32_t> rowptr((size_t)n_nodes + 1, 0), col(E), rev(E);
+    for (size_t e = 0; e < E; ++e) {
+        rowptr[(size_t)(key[e] / n_nodes) + 1]++;
+        col[e] = (int32_t)(key[e] % n_nodes);
+    }
+    for (int32_t i = 0; i < n_nodes; ++i) rowptr[i + 1] += rowptr[i];
+    for (size_t e = 0; e < E; ++e) {
+        const int64_t r = key[e] / n_nodes, c = key[e] % n_nodes;
+        const auto it = std::lower_bound(key.begin(), key.end(), c * n_nodes + r);
+        DL_REQUIRE(it != key.end() && *it == c * n_nodes + r, "adjacency is not symmetric (reverse of (%lld,%lld) missing)",
+                   (long long)r, (long long)c);
+        rev[e] = (int32_t)(it - key.begin());
+    }
+    out->n_nodes = n_nodes;
+    out->n_entries = (int32_t)E;
+    out->rowptr = dup(rowptr);
+    out->col = dup(col);
+    out->rev = dup(rev);
+    DL_REQUIRE(out->rowptr && out->col && out->rev, "out of memory");
+    return DL_OK;
+}
+
+void dl_host_csr_free(dl_host_csr* c) {
+    if (!c) return;
+    free(c->rowptr); free(c->col); free(c->rev);
+    memset(c, 0, sizeof(*c));
+}
+
+int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, const int32_t* col, int32_t seg_len,
+                       int32_t n_col_slices, const uint8_t* keep, dl_host_plan* out) {
+    DL_REQUIRE(out != nullptr, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    DL_REQUIRE(n_rows >= 0 && n_total >= n_rows && seg_len >= 1 && n_col_slices >= 1, "bad plan size");
+    DL_REQUIRE(n_rows == 0 || rowptr, "rowptr is NULL");
+    const int32_t n_streams = std::min<int32_t>(n_col_slices, 8);
+    const int64_t width = std::max<int64_t>(1, ((int64_t)n_total + n_col_slices - 1) / n_col_slices);
+    struct Seg { int32_t row, beg, end, slice, idx_in_row; };
+    std::vector<Seg> segs;
+    std::vector<int32_t> nseg_row((size_t)n_rows, 0);
+    for (int32_t i = 0; i < n_rows; ++i) {
+        // kept entries of the row: one contiguous run (checked)
+        int32_t b = rowptr[i], e = rowptr[i + 1];
+        if (keep) {
+            while (b < e && !keep[b]) ++b;
+            int32_t e2 = b;
+            while (e2 < e && keep[e2]) ++e2;
+            for (int32_t x = e2; x < e; ++x) DL_REQUIRE(!keep[x], "kept entries must be contiguous inside row %d", i);
+            e = e2;
+        }
+        int32_t pos = b, idx = 0;
+        while (pos < e) {
+            const int32_t q = n_col_slices > 1 ? (int32_t)(col[pos] / width) : 0;
+            int32_t gend = pos;
+            while (gend < e && (n_col_slices == 1 || col[gend] / width == q)) {
+                DL_REQUIRE(gend == pos || col[gend] >= col[gend - 1] || n_col_slices == 1,
+                           "sliced plans need col ascending inside every row");
+                ++gend;
+            }
+            for (int32_t sb = pos; sb < gend; sb += seg_len)
+                segs.push_back({i, sb, std::min(sb + seg_len, gend), q, idx++});
+            pos = gend;
+        }
+        if (idx == 0) segs.push_back({i, rowptr[i], rowptr[i], 0, idx++});   // empty rows own one empty segment
+        nseg_row[i] = idx;
+    }
+    // partial slots: consecutive per multi-segment row, in entry order
+    std::vector<int32_t> multi_row, multi_slot0(1, 0), row_slot0((size_t)n_rows, -1);
+    for (int32_t i = 0; i < n_rows; ++i)
+        if (nseg_row[i] > 1) {
+            row_slot0[i] = multi_slot0.back();
+            multi_row.push_back(i);
+            multi_slot0.push_back(multi_slot0.back() + nseg_row[i]);
+        }
+    // storage order: one stream per XCD (slice q -> stream q % 8), slices of a stream in time order
+    std::stable_sort(segs.begin(), segs.end(), [&](const Seg& a, const Seg& b) {
+        const int32_t sa = a.slice % n_streams, sb = b.slice % n_streams;
+        return sa != sb ? sa < sb : a.slice < b.slice;
+    });
+    const size_t S = segs.size();
+    std::vector<int32_t> seg_row(S), seg_beg(S), seg_end(S), seg_slot(S), slice_seg0((size_t)n_streams + 1, 0);
+    for (size_t s = 0; s < S; ++s) {
+        seg_row[s] = segs[s].row; seg_beg[s] = segs[s].beg; seg_end[s] = segs[s].end;
+        seg_slot[s] = row_slot0[segs[s].row] < 0 ? -1 : row_slot0[segs[s].row] + segs[s].idx_in_row;
+        slice_seg0[(size_t)(segs[s].slice % n_streams) + 1]++;
+    }
+    int32_t max_seg = 0;
+    for (int32_t x = 0; x < n_streams; ++x) {
+        max_seg = std::max(max_seg, slice_seg0[x + 1]);
+        slice_seg0[x + 1] += slice_seg0[x];
+    }
+    out->seg_len = seg_len; out->n_seg = (int32_t)S; out->n_slices = n_streams; out->slice_max_seg = max_seg;
+    out->n_multi = (int32_t)multi_row.size(); out->n_slots = multi_slot0.back();
+    out->seg_row = dup(seg_row); out->seg_beg = dup(seg_beg); out->seg_end = dup(seg_end); out->seg_slot = dup(seg_slot);
+    out->slice_seg0 = dup(slice_seg0); out->multi_row = dup(multi_row); out->multi_slot0 = dup(multi_slot0);
+    DL_REQUIRE(out->seg_row && out->seg_beg && out->seg_end && out->seg_slot && out->slice_seg0 && out->multi_row &&
+                   out->multi_slot0, "out of memory");
+    return DL_OK;
+}
+
+void dl_host_plan_free(dl_host_plan* p) {
+    if (!p) return;
+    free(p->seg_row); free(p->seg_beg); free(p->seg_end); free(p->seg_slot);
+    free(p->slice_seg0); free(p->multi_row); free(p->multi_slot0);
+    memset(p, 0, sizeof(*p));
+}
+
+}  // extern "C"

@@ -103,6 +103,36 @@ typedef struct dl_pair_incidence {
     int32_t n_pairs;            /* extent of the prob / g_prob arrays */
 } dl_pair_incidence;
 
+/* ---- host-side graph preparation (no GPU; the only entry points that allocate: malloc'd outputs are
+ * released by the matching *_free).  Counterpart of the dense adjacency construction of
+ * main_disentangled.py:137-142 for hosts without Python; disenlink_amd/graph.py builds identical arrays
+ * with torch index ops on the device.  Upload the arrays and point a dl_csr_plan at them. */
+typedef struct dl_host_csr {
+    int32_t n_nodes;
+    int32_t n_entries;
+    int32_t* rowptr;            /* [n_nodes+1] */
+    int32_t* col;               /* [n_entries], ascending inside a row */
+    int32_t* rev;               /* [n_entries] */
+} dl_host_csr;
+
+typedef struct dl_host_plan {   /* the segment-plan fields of dl_csr_plan, in host memory */
+    int32_t seg_len, n_seg, n_slices, slice_max_seg, n_multi, n_slots;
+    int32_t *seg_row, *seg_beg, *seg_end, *seg_slot, *slice_seg0, *multi_row, *multi_slot0;
+} dl_host_plan;
+
+/* Directed edge rows (duplicates allowed) -> CSR of the binarised adjacency; symmetrise != 0 reproduces
+ * adj_sym = (adj + adj.T) != 0.  Fails if the result is not symmetric. */
+int dl_host_csr_from_edges(const int64_t* src, const int64_t* dst, int64_t n_edge_rows, int32_t n_nodes,
+                           int symmetrise, dl_host_csr* out);
+void dl_host_csr_free(dl_host_csr* csr);
+
+/* Segment plan of a CSR (see dl_csr_plan): segments of <= seg_len entries, never spanning two of the
+ * n_col_slices column slices (1 = unsliced; a multiple of 8 = XCD streams x time), optionally only over
+ * the entries with keep[e] != 0 (one contiguous run per row, e.g. col >= row for symmetric routing). */
+int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, const int32_t* col, int32_t seg_len,
+                       int32_t n_col_slices, const uint8_t* keep, dl_host_plan* out);
+void dl_host_plan_free(dl_host_plan* plan);
+
 const char* dl_version(void);
 const char* dl_last_error(void);
 

@@ -220,3 +220,56 @@ def test_module_state_dict_and_projection_match_reference(name):
     assert Z.shape == (m["N"], m["K"], m["d"]) and Z.is_contiguous()
     np.testing.assert_allclose(Z.detach().numpy(), Zref.numpy(), rtol=1e-5, atol=1e-6)
     model.train(); model.eval()                      # must stay no-ops (main_disentangled.py:193,201)
+
+
+def _host_arr(ptr, n):
+    return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_c_abi_host_graph_prep_matches_python_builders(seed):
+    """dl_host_csr_from_edges / dl_host_plan_build (C++, for non-Python hosts) produce exactly the arrays
+    disenlink_amd.graph builds with torch ops: CSR, reverse permutation, plain / sliced / mirrored plans."""
+    import ctypes as C
+    from disenlink_amd import _lib
+    from disenlink_amd.graph import CsrPlan, Graph
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(20, 120))
+    E = int(rng.integers(n, 12 * n))
+    src, dst = rng.integers(0, n, E), rng.integers(0, n, E)
+    src[: n // 2] = 0                                                     # a hub
+    keepn = (src != n - 1) & (dst != n - 1)                               # an isolated node
+    src, dst = src[keepn].astype(np.int64), dst[keepn].astype(np.int64)
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), n, seg_len=8)
+    hc = _lib.DlHostCsr()
+    assert lib.dl_host_csr_from_edges(src.ctypes.data, dst.ctypes.data, src.size, n, 1, C.byref(hc)) == 0
+    try:
+        assert hc.n_nodes == n and hc.n_entries == G.n_edges
+        rowptr, col = _host_arr(hc.rowptr, n + 1), _host_arr(hc.col, hc.n_entries)
+        assert np.array_equal(rowptr, G.rowptr.numpy()) and np.array_equal(col, G.col.numpy())
+        assert np.array_equal(_host_arr(hc.rev, hc.n_entries), G.rev.numpy())
+        row_of = np.repeat(np.arange(n), np.diff(rowptr))
+        cases = [(8, 1, None, G.plan), (8, 8, None, CsrPlan.build(G.rowptr, G.col, n, seg_len=8, n_slices=8)),
+                 (5, 24, None, CsrPlan.build(G.rowptr, G.col, n, seg_len=5, n_slices=24)),
+                 (8, 1, (col >= row_of).astype(np.uint8), G.route)]
+        for seg_len, slices, keep, ref in cases:
+            hp = _lib.DlHostPlan()
+            kp = keep.ctypes.data if keep is not None else None
+            rc = lib.dl_host_plan_build(n, n, rowptr.ctypes.data, col.ctypes.data, seg_len, slices, kp, C.byref(hp))
+            assert rc == 0, lib.dl_last_error()
+            try:
+                got = (hp.n_seg, hp.n_slices, hp.slice_max_seg, hp.n_multi, hp.n_slots)
+                assert got == (ref.n_seg, ref.n_slices, ref.slice_max_seg, int(ref.multi_row.numel()), ref.n_slots)
+                for name, count in (("seg_row", hp.n_seg), ("seg_beg", hp.n_seg), ("seg_end", hp.n_seg),
+                                    ("seg_slot", hp.n_seg), ("slice_seg0", hp.n_slices + 1), ("multi_row", hp.n_multi),
+                                    ("multi_slot0", hp.n_multi + 1)):
+                    assert np.array_equal(_host_arr(getattr(hp, name), count), getattr(ref, name).numpy()), name
+            finally:
+                lib.dl_host_plan_free(C.byref(hp))
+    finally:
+        lib.dl_host_csr_free(C.byref(hc))
+    # asymmetric input without symmetrise is rejected, like Graph.from_edge_rows
+    one = np.array([0], dtype=np.int64), np.array([1], dtype=np.int64)
+    assert lib.dl_host_csr_from_edges(one[0].ctypes.data, one[1].ctypes.data, 1, 3, 0, C.byref(_lib.DlHostCsr())) == -1
+    assert b"not symmetric" in lib.dl_last_error()
