@@ -212,6 +212,16 @@ int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_
     return generic_score_allpairs_fwd((const float*)Z, (const float*)H, N, K, d, t, prob, (hipStream_t)stream);
 }
 
+int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g, void* ws,
+                size_t ws_bytes, void* stream) {
+    DL_REQUIRE(n_pairs >= 0, "negative size");
+    DL_REQUIRE(loss != nullptr, "loss is NULL");
+    DL_REQUIRE(ws != nullptr && ws_bytes >= 1024 + 256, "dl_pair_bce needs >= 1280 bytes of workspace");
+    if (n_pairs > 0) DL_REQUIRE(prob && y && w && g, "NULL argument");
+    float* partial = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    return pair_bce(prob, y, w, n_pairs, loss, g, partial, (hipStream_t)stream);
+}
+
 int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob, const float* coef,
                        float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream) {

@@ -800,6 +800,42 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g
     }
 }
 
+// ---------------------------------------------------------------------------- pair-list BCE
+// loss = sum_q w[q] * bce(prob[q], y[q]),  g[q] = dloss/dprob[q], in PROBABILITY space exactly as
+// F.binary_cross_entropy does it (main_disentangled.py:195): log clamped at -100, gradient
+// (p - y) / max(p (1 - p), 1e-12).  Saturated fp32 sigmoids keep their zero gradient downstream because the
+// scorer backward multiplies by p (1 - p).  Deterministic two-stage reduction (no float atomics).
+constexpr int BCE_BLOCKS = 256;
+
+__global__ __launch_bounds__(BLOCK) void pair_bce_kernel(const float* __restrict__ prob, const float* __restrict__ y,
+                                                         const float* __restrict__ w, int n, float* __restrict__ g,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[WAVES_PER_BLOCK];
+    float acc = 0.0f;
+    for (int q = blockIdx.x * BLOCK + threadIdx.x; q < n; q += BCE_BLOCKS * BLOCK) {
+        const float p = prob[q], yy = y[q], ww = w[q];
+        const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(logf(1.0f - p), -100.0f);
+        acc += ww * -(yy * lp + (1.0f - yy) * l1p);
+        g[q] = ww * (p - yy) / fmaxf(p * (1.0f - p), 1e-12f);
+    }
+    acc = wave_allreduce_sum(acc);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+        for (int i = 1; i < WAVES_PER_BLOCK; ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ void pair_bce_finish_kernel(const float* __restrict__ partial, float* __restrict__ loss) {
+    const int lane = threadIdx.x;                           // one wave
+    float acc = 0.0f;
+    for (int i = lane; i < BCE_BLOCKS; i += DL_WAVE) acc += partial[i];
+    acc = wave_allreduce_sum(acc);
+    if (lane == 0) loss[0] = acc;
+}
+
 // ---------------------------------------------------------------------------- host launchers
 static inline int pow2_at_least(int k) {
     int p = 1;
@@ -922,6 +958,13 @@ struct Ops {
 };
 
 }  // namespace fast
+
+int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,
+             hipStream_t st) {
+    hipLaunchKernelGGL(fast::pair_bce_kernel, dim3(fast::BCE_BLOCKS), dim3(BLOCK), 0, st, prob, y, w, n, g, partial);
+    hipLaunchKernelGGL(fast::pair_bce_finish_kernel, dim3(1), dim3(DL_WAVE), 0, st, partial, loss);
+    return check_launch("pair_bce");
+}
 
 // (K, D) pairs with a tuned instantiation.  D must be 4 * a power of two.
 #define DL_FAST_SHAPES_F32(X) \

@@ -44,6 +44,9 @@ int fast_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, i
 int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
                                hipStream_t st);
 
+int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,
+             hipStream_t st);
+
 // factor projection on the matrix cores (dl_project.hip)
 bool project_supported(int d);
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,

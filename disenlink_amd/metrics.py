@@ -17,6 +17,20 @@ def pair_bce_loss(prob_pos, label_pos, prob_neg, label_neg, m: int) -> torch.Ten
     return F.binary_cross_entropy(prob_pos, label_pos) + F.binary_cross_entropy(prob_neg, label_neg) / m
 
 
+def pair_bce_weights(n_pos: int, n_neg: int, m: int, device) -> torch.Tensor:
+    """Per-pair weights that turn sum_q w BCE into BCE_mean(pos) + BCE_mean(neg) / m for a list [pos | neg]."""
+    w = torch.empty(n_pos + n_neg, dtype=torch.float32, device=device)
+    w[:n_pos] = 1.0 / max(n_pos, 1)
+    w[n_pos:] = 1.0 / (m * max(n_neg, 1))
+    return w
+
+
+def pair_bce_loss_fused(prob_train, label_train, weight_train) -> torch.Tensor:
+    """The same loss from the fused HIP kernel (loss and its gradient in one pass); GPU tensors only."""
+    from .ops import PairBCE
+    return PairBCE.apply(prob_train, label_train, weight_train)
+
+
 def auc_tie_avg(label: torch.Tensor, score: torch.Tensor, check: bool = True) -> torch.Tensor:
     """0-dim float64 tensor on score.device.  ``check=True`` raises if only one class is present (one
     device->host sync); with ``check=False`` nothing here synchronises and a one-class input gives nan."""

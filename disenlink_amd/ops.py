@@ -321,6 +321,31 @@ class ProjectStacked(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class PairBCE(torch.autograd.Function):
+    """loss = sum_q w[q] BCE(prob[q], label[q]) with torch's clamps, loss and d loss / d prob from ONE kernel
+    (main_disentangled.py:195 on pair lists; see metrics.pair_bce_weights)."""
+
+    @staticmethod
+    def forward(ctx, prob, label, weight):
+        lib = _lib.load()
+        prob, label, weight = _f32c(prob), _f32c(label), _f32c(weight)
+        _need_cuda(prob, label, weight)
+        if not (prob.numel() == label.numel() == weight.numel()):
+            raise ValueError("prob, label and weight differ in length")
+        loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+        g = torch.empty_like(prob)
+        ws = _ws.get(2048, prob.device)
+        _lib.check(lib.dl_pair_bce(prob.data_ptr(), label.data_ptr(), weight.data_ptr(), prob.numel(), loss.data_ptr(),
+                                   g.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_pair_bce")
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        return g * g_loss, None, None
+
+
 class HotPathPairs(torch.autograd.Function):
     """Z [N,K,d] fp32 -> (emb [N,K,d] fp32, prob [P]): route + aggregate + pair scorer as ONE autograd node.
     ``table_dtype`` (torch.float32 / torch.bfloat16) is the storage type of the gathered Z and H tables;

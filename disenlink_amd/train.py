@@ -18,7 +18,7 @@ import torch
 from torch.optim import Adam
 
 from .graph import Graph, PairList
-from .metrics import auc_tie_avg, pair_bce_loss
+from .metrics import auc_tie_avg, pair_bce_loss, pair_bce_loss_fused, pair_bce_weights
 from .splits import LinkSplit
 
 
@@ -69,10 +69,17 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
     for lab in (run.label_val, run.label_test):                     # validated once: the per-epoch AUC never syncs
         if not 0 < float(lab.sum()) < lab.numel():
             raise ValueError("AUC undefined with one class")
+    fused = x.is_cuda                                               # fused loss+gradient kernel on the GPU path
+    if fused:
+        label_train = torch.cat([run.label_pos, run.label_neg])
+        weight_train = pair_bce_weights(run.n_pos, run.n_neg, run.m, x.device)
     for epoch in range(epochs):
         model.train()
         _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
-        loss = pair_bce_loss(prob[:a], run.label_pos, prob[a:b], run.label_neg, run.m)
+        if fused:
+            loss = pair_bce_loss_fused(prob[:b], label_train, weight_train)
+        else:
+            loss = pair_bce_loss(prob[:a], run.label_pos, prob[a:b], run.label_neg, run.m)
         opt.zero_grad()
         loss.backward()
         opt.step()

@@ -192,6 +192,14 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
                           float* prob, void* stream);
 
+/* Pair-list loss of main_disentangled.py:195 and its gradient in one pass:
+ *   loss[0] = sum_q w[q] * BCE(prob[q], y[q])       (log clamped at -100, like F.binary_cross_entropy)
+ *   g[q]    = w[q] * (prob[q] - y[q]) / max(prob[q] (1 - prob[q]), 1e-12)       = dloss / dprob[q]
+ * With w = 1/n_pos on the positive pairs and 1/(m n_neg) on the negative ones this is the reference's
+ * BCE(pos) + BCE(neg)/m.  ws: at least 1 KiB of scratch (256 partial sums). */
+int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g,
+                void* ws, size_t ws_bytes, void* stream);
+
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
  * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:
  *   gl = g_prob * prob * (1 - prob);  dH[u] += gl e_k H[v][k];  dZ[u] += gl (q_k e_k)/t Z[v][k]

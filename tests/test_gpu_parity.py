@@ -511,3 +511,28 @@ def test_full_size_benchmark_workload_matches_c_oracle():
     assert torch.equal(p, p2) and torch.equal(a, a2) and torch.equal(s, s2)
     assert torch.equal(H, ops.aggregate_fwd(graph, Z, beta, p, a, s))
     assert torch.equal(prob, ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs))
+
+
+def test_fused_pair_bce_matches_torch_bce():
+    """dl_pair_bce (loss + gradient in one kernel) vs F.binary_cross_entropy on pos / neg lists incl. saturated
+    probabilities (exact 0 and 1: log clamp at -100, gradient clamp 1e-12) and labels that disagree."""
+    import torch.nn.functional as F
+    from disenlink_amd.metrics import pair_bce_loss, pair_bce_loss_fused, pair_bce_weights
+    g = torch.Generator().manual_seed(0)
+    n_pos, n_neg, m = 3001, 7003, 5
+    prob = torch.rand(n_pos + n_neg, generator=g)
+    prob[:50] = 1.0
+    prob[50:80] = 0.0
+    prob[-40:] = 1.0
+    label = torch.cat([torch.ones(n_pos), torch.zeros(n_neg)])
+    label[n_pos: n_pos + 7] = 1.0                                        # a sampled "negative" that is an edge
+    pr = prob.to(DEV).requires_grad_(True)
+    lt = label.to(DEV)
+    ref = pair_bce_loss(pr[:n_pos], lt[:n_pos], pr[n_pos:], lt[n_pos:], m)
+    (g_ref,) = torch.autograd.grad(ref, pr)
+    pf = prob.to(DEV).requires_grad_(True)
+    fused = pair_bce_loss_fused(pf, lt, pair_bce_weights(n_pos, n_neg, m, DEV))
+    (g_f,) = torch.autograd.grad(fused * 2.0, pf)                       # upstream gradient is applied
+    assert abs(float(fused) - float(ref)) <= 1e-5 * abs(float(ref))
+    torch.testing.assert_close(g_f, 2.0 * g_ref, rtol=1e-5, atol=0)
+    assert torch.equal(fused, pair_bce_loss_fused(pf, lt, pair_bce_weights(n_pos, n_neg, m, DEV)))     # deterministic
