@@ -17,11 +17,16 @@ run = prepare_run(split, dev)
 x = torch.from_numpy(sg.features()).to(dev)
 torch.manual_seed(0)
 model = Disentangle(sg.n_feat, 512, 64, nfactor=8, beta=0.5, t=1).to(dev)
-run_link_prediction(model, x, run, epochs=3, lr=1e-4)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-res = run_link_prediction(model, x, run, epochs=30, lr=1e-4)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 31          # 30 epochs + the test forward
-print(f"{name}: {dt * 1e3:.2f} ms per epoch (train pairs {run.n_pos + run.n_neg}, val {run.label_val.numel()}); "
-      f"loss {res.losses[0]:.4f} -> {res.losses[-1]:.4f}, val auc {res.val_aucs[-1]:.4f}")
+sd = {k: v.clone() for k, v in model.state_dict().items()}
+for use_graph in (False, True):
+    model.load_state_dict(sd)
+    run_link_prediction(model, x, run, epochs=3, lr=1e-4, use_graph=use_graph)
+    model.load_state_dict(sd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_link_prediction(model, x, run, epochs=200, lr=1e-4, use_graph=use_graph)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 200         # incl. graph capture when use_graph
+    print(f"{name} use_graph={use_graph}: {dt * 1e3:.2f} ms per epoch (train pairs {run.n_pos + run.n_neg}, val "
+          f"{run.label_val.numel()}); loss {res.losses[0]:.4f} -> {res.losses[-1]:.4f}, val auc {res.val_aucs[-1]:.4f}, "
+          f"test auc {res.test_auc:.4f}")
