@@ -135,7 +135,9 @@ def _random_problem(seed, N, K, d, avg_deg, hub=True, scale=0.35):
 
 @pytest.mark.parametrize("force_generic", [0, 1])
 @pytest.mark.parametrize("K,d,N,deg", [(8, 64, 600, 12), (4, 32, 500, 9), (16, 128, 200, 8), (5, 64, 300, 10),
-                                        (3, 5, 97, 6), (1, 16, 64, 5), (8, 64, 2000, 30)])
+                                        (3, 5, 97, 6), (1, 16, 64, 5), (8, 64, 2000, 30),
+                                        (20, 32, 150, 8), (10, 64, 200, 8), (10, 32, 180, 7),     # recipes of hyperparameters_setting
+                                        (64, 8, 90, 6), (2, 1, 70, 5)])                           # K at its maximum; d = 1
 def test_forward_and_backward_match_oracle_on_random_graphs(K, d, N, deg, force_generic):
     from disenlink_amd import _lib, ops
     from disenlink_amd.graph import Graph, PairList
