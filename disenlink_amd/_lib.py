@@ -57,7 +57,10 @@ EXPORTS = {
     "dl_set_force_generic": (_i, [_i]),
     "dl_workspace_bytes": (_z, [C.POINTER(DlCsrPlan), _i, _i]),
     "dl_project_supported": (_i, [_i]),
-    "dl_project_fwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P]),
+    "dl_project_fwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "dl_project_fwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_project_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "dl_project_bwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
     "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
     "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P, _P]),
@@ -97,12 +100,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DL_LIB_PATH", LIB_PATH)      # override: kernel experiments with alternative builds
+    if not os.path.exists(path):
         raise DisenlinkHipError(
-            f"{LIB_PATH} not found: the HIP library is required (there is no CPU fallback). "
+            f"{path} not found: the HIP library is required (there is no CPU fallback). "
             "Build it with `python -m disenlink_amd.build` or __graft_entry__.build().")
     _hip_runtime_global()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
         fn.restype = res

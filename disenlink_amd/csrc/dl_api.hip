@@ -100,7 +100,7 @@ using namespace dl;
 
 extern "C" {
 
-const char* dl_version(void) { return "disenlink_hip 0.3 (gfx950)"; }
+const char* dl_version(void) { return "disenlink_hip 0.4 (gfx950)"; }
 const char* dl_last_error(void) { return g_err; }
 int dl_has_fast_path(int K, int d) { return fast_supported(K, d, DL_F32) ? 1 : 0; }
 int dl_has_fast_path_dtype(int K, int d, dl_dtype dtype) { return fast_supported(K, d, (int)dtype) ? 1 : 0; }
@@ -118,8 +118,14 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d) {
 
 int dl_project_supported(int d) { return project_supported(d) ? 1 : 0; }
 
+size_t dl_project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer) {
+    (void)F;
+    if (N <= 0 || K < 1 || nhid < 1 || d < 1) return 0;
+    return project_fwd_workspace_bytes(N, K, nhid, d, two_layer != 0);
+}
+
 int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                   const float* W2, const float* b2, float* Z, void* stream) {
+                   const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
     DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
@@ -127,7 +133,40 @@ int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const f
     DL_REQUIRE((W2 == nullptr) == (b2 == nullptr), "W2 and b2 must both be given (two-layer) or both NULL");
     if (N == 0) return DL_OK;
     DL_REQUIRE(x && W1 && b1 && Z, "NULL argument");
-    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, (hipStream_t)stream);
+    DL_REQUIRE((long long)N * K * d < (1LL << 40) && (long long)128 * F < (1LL << 31), "projection sizes out of range");
+    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer) {
+    if (N <= 0 || F < 1 || K < 1 || nhid < 1 || d < 1) return 0;
+    return project_bwd_workspace_bytes(N, F, K, two_layer ? nhid : 1, d, two_layer != 0);
+}
+
+int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                   const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
+                   size_t ws_bytes, void* stream) {
+    if (int rc = check_shape(K, d)) return rc;
+    DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
+    DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
+    DL_REQUIRE(K <= 4096, "K too large for the launch grid");
+    const bool two = W2 != nullptr;
+    DL_REQUIRE(dW1 && db1 && (!two || (dW2 && db2)), "NULL gradient output");
+    if (N == 0) {                                              // no nodes: every gradient is zero
+        hipStream_t st = (hipStream_t)stream;
+        const size_t m = two ? (size_t)nhid : (size_t)d;
+        hipMemsetAsync(dW1, 0, sizeof(float) * K * m * F, st);
+        hipMemsetAsync(db1, 0, sizeof(float) * K * m, st);
+        if (two) {
+            hipMemsetAsync(dW2, 0, sizeof(float) * (size_t)K * d * nhid, st);
+            hipMemsetAsync(db2, 0, sizeof(float) * (size_t)K * d, st);
+        }
+        return DL_OK;
+    }
+    DL_REQUIRE(x && W1 && b1 && dZ, "NULL argument");
+    const size_t need = project_bwd_workspace_bytes(N, F, K, two ? nhid : 1, d, two);
+    DL_REQUIRE(ws != nullptr && ws_bytes >= need, "workspace too small: %zu < %zu bytes (dl_project_bwd_workspace_bytes)",
+               ws_bytes, need);
+    return project_bwd(x, N, F, K, two ? nhid : 1, d, W1, b1, W2, dZ, dW1, db1, dW2, db2, ws, (hipStream_t)stream);
 }
 
 int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float t, uint8_t* p, float* a,

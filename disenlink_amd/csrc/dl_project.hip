@@ -3,29 +3,38 @@
 // is bit-for-bit a k-ordered fmaf chain (no reduced precision), so the result keeps the
 // reference's fp32 semantics up to summation order.
 //
-// Two-layer form (Factor2): one workgroup = 4 waves = 128 nodes x ONE factor k.  Per 32 hidden units:
-//   layer 1 (transposed):  hidT[32 hidden][32 nodes] = W1_k[32][F] . x^T        A = W1 rows, B = x^T
+// Two-layer form (Factor2): one workgroup = 8 waves = 128 nodes x ONE factor k, looping over (a group
+// of) 128-unit chunks of the hidden layer.  Waves are 4 x 2: node quarter wn, hidden half wh; each wave
+// owns a (64 hidden) x (32 nodes) tile = two independent accumulators; two waves share a SIMD, so one
+// wave's LDS reads and barrier waits hide behind the other's MFMA chain.
+//   layer 1 (transposed):  hidT[hidden][node] = W1_k[hidden][F] . x^T            A = W1 rows, B = x rows
 //   bias + ReLU in the accumulator registers
-//   layer 2:               Z^T[d][32 nodes] += W2_k[d][32 hidden] . hidT         B = the accumulator itself
+//   layer 2:               Z^T[d][node] += W2_k[d][hidden] . hidT                 B = the accumulator itself
 // A 32x32 accumulator has its column on the lane and its rows in the 16 registers, which is exactly
 // the B-operand shape of the next MFMA when that product sums over the accumulator's ROW index
-// (register r supplies the k-pair {(r&3)+8(r>>2), +4}); so the hidden activations never leave the
-// register file — no [N, K*nhid] tensor is written to HBM and re-read, unlike two library GEMMs.
-// Operand tiles are double-buffered in LDS (row pitch + 4 floats: aligned, conflict-free b128 accesses)
-// and the next step's tiles are fetched into registers behind the current step's MFMA chain.
+// (register r supplies the k-pair {acc_row(r,0), acc_row(r,1)}); so the hidden activations never leave
+// the register file — no [N, K*nhid] tensor is written to HBM and re-read, unlike two library GEMMs.
+// The layer-1 operand tiles ([128 rows][32 features], row pitch 36 floats: aligned, conflict-free b128
+// reads) are double-buffered in LDS and the next step's tiles are fetched into registers behind the
+// current step's MFMAs; the W2 operand (A[i = d][k = hidden], 4 consecutive hidden units per register
+// quad) is read straight from global memory, one d-tile ahead of its use.  The two hidden halves of a
+// node's Z are added through LDS at the end (fixed order).
+// Small graphs: the hidden chunks are split over G workgroups per (node tile, k) whose partial Z go to
+// G slabs, added in slab order by z_slab_sum_kernel (no atomics; needs the workspace).
+#include <algorithm>
 #include "dl_common.h"
 #include "dl_kernels.h"
+#include "dl_tiles.h"
 
 namespace dl {
 namespace project {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int TILE_N = 128;   // nodes per workgroup (4 waves x 32)
-constexpr int FC = 64;        // feature chunk staged per step
-constexpr int HC = 32;        // hidden units per step
-
-__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+constexpr int TN = 128;       // nodes per workgroup (4 wave quarters x 32)
+constexpr int TH = 128;       // hidden units per chunk (2 wave halves x 64)
+// feature chunk staged per step: 64 (one barrier per 64 MFMAs of a wave) where the registers allow, else 32;
+// LDS row pitch of the operand tiles = FC + 4 floats
+constexpr int fwd_fc(int D) { return D <= 64 ? 64 : 32; }
+constexpr int NTHR = 512;
 
 // stage rows [row0, row0+rows) x cols [col0, col0+cols) of a row-major [n_rows][n_cols] matrix into
 // LDS with leading dimension ld (zero fill outside the matrix)
@@ -38,206 +47,215 @@ __device__ __forceinline__ void stage_tile(float* lds, int ld, const float* __re
     }
 }
 
-// 4 consecutive elements (row, col..col+3) of a row-major [n_rows][n_cols] matrix, zero outside.
-// Branch-free: every load is issued unconditionally from a clamped (always valid) address and the
-// result is selected afterwards, so hipcc keeps all loads of a tile in flight together (a branch
-// around a load makes it wait for each one separately).  VEC: n_cols % 4 == 0, so a quad is either
-// fully inside a row or fully outside and 16-byte aligned.
+// 4 consecutive floats src[base .. base+3] of a vector of length n, loaded unconditionally from a clamped
+// address; zero4() afterwards clears what lies outside the vector.  Two steps so that the s_waitcnt of the
+// load lands at the use, not at the issue.  VEC: n % 4 == 0 and base % 4 == 0 (one aligned dwordx4).
 template <bool VEC>
-__device__ __forceinline__ float4 load_quad(const float* __restrict__ src, int n_rows, int n_cols, int row, int col) {
-    const bool row_ok = row < n_rows;
-    const size_t rbase = (size_t)(row_ok ? row : 0) * n_cols;
+__device__ __forceinline__ float4 load4_raw(const float* __restrict__ src, int base, int n) {
     if constexpr (VEC) {
-        const bool ok = row_ok && col < n_cols;
-        const float4 q = *reinterpret_cast<const float4*>(src + rbase + (ok ? col : 0));
-        return ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(src + (base < n ? base : 0));
     } else {
         float e[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = row_ok && col + i < n_cols;
-            const float v = src[rbase + (ok ? col + i : 0)];
-            e[i] = ok ? v : 0.0f;
-        }
+        for (int i = 0; i < 4; ++i) e[i] = src[base + i < n ? base + i : 0];
         return make_float4(e[0], e[1], e[2], e[3]);
     }
 }
-__device__ __forceinline__ void store_quad(float* lds, const float4& q) {
-    *reinterpret_cast<float4*>(lds) = q;                        // rows are padded by 4 floats: 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
+    if constexpr (VEC) {
+        const unsigned m = base < n ? 0xFFFFFFFFu : 0u;
+        return make_float4(mask_bits(q.x, m), mask_bits(q.y, m), mask_bits(q.z, m), mask_bits(q.w, m));
+    } else {
+        return make_float4(mask_bits(q.x, base + 0 < n ? 0xFFFFFFFFu : 0u), mask_bits(q.y, base + 1 < n ? 0xFFFFFFFFu : 0u),
+                           mask_bits(q.z, base + 2 < n ? 0xFFFFFFFFu : 0u), mask_bits(q.w, base + 3 < n ? 0xFFFFFFFFu : 0u));
+    }
 }
 
-// Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D], Z [N][K][D].
-// Software pipeline: the tiles of step s+1 are fetched into registers while the MFMAs of step s run,
-// written to the other LDS buffer afterwards; one barrier per step.
+// Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D].
+// VEC: F % 4 == 0 and nhid % 4 == 0.  grid = (node tiles of 128, K, G hidden-chunk groups).
+// out: Z [N][K][D] with b2 != nullptr (G == 1), or slab [G][N][K][D] of partial sums with b2 == nullptr.
 template <int D, bool VEC>
-__global__ __launch_bounds__(256) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
-                                                           const float* __restrict__ W1, const float* __restrict__ b1,
-                                                           const float* __restrict__ W2, const float* __restrict__ b2,
-                                                           float* __restrict__ Z, int K) {
+__global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
+                                                            const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            const float* __restrict__ W2, const float* __restrict__ b2,
+                                                            float* __restrict__ out, int K, int chunks_per_group) {
     constexpr int DT = D / 32;
-    // Row pitch = tile width + 4 floats: rows stay 16-byte aligned (ds_write_b128 / ds_read_b128) and the
-    // 16 lanes of a b128 read group land on 16 different 4-bank slots (pitch*4 B mod 256 B = 16 B).
-    constexpr int LDX = FC + 4, LDW2 = HC + 4;
-    constexpr int XQ = TILE_N * FC / 4 / 256;      // float4 per thread of the x tile        (8)
-    constexpr int WQ = HC * FC / 4 / 256;          // ... of the W1 tile                     (2)
-    constexpr int VQ = D * HC / 4 / 256;           // ... of the W2 tile                     (1, 2 or 4)
+    constexpr int FC = fwd_fc(D), LDT = FC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;                               // [2][TILE_N][LDX]
-    float* w1s = xs + 2 * TILE_N * LDX;            // [2][HC][LDX]
-    float* w2s = w1s + 2 * HC * LDX;               // [2][D][LDW2]
-    const int k = blockIdx.y;
-    const int n0 = blockIdx.x * TILE_N;
+    float* xs = lds;                               // [2][TN][LDT]
+    float* w1s = xs + 2 * TN * LDT;                // [2][TH][LDT]
+    const int k = blockIdx.y, grp = blockIdx.z;
+    const int n0 = blockIdx.x * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
+    const int wn = wave >> 1, wh = wave & 1;
     const float* W1k = W1 + (size_t)k * nhid * F;
     const float* W2k = W2 + (size_t)k * D * nhid;
-    const int nfc = (F + FC - 1) / FC, nhc = (nhid + HC - 1) / HC, steps = nfc * nhc;
+    const float* b1k = b1 + (size_t)k * nhid;
+    const int nfc = (F + FC - 1) / FC, nhc = (nhid + TH - 1) / TH;
+    const int hc0 = grp * chunks_per_group;
+    const int steps = nfc * max(0, min(chunks_per_group, nhc - hc0));
 
-    // With F <= 2*FC the two x chunks of the node tile fit the two LDS buffers for good: they are staged
-    // once (during the first hidden chunk) instead of once per hidden chunk.
-    const bool x_resident = nfc <= 2;
-    float4 xq[XQ], wq[WQ], vq[VQ];
-    float bq[16];
+    TileStage<TN, FC, VEC, NTHR> xt;
+    TileStage<TH, FC, VEC, NTHR> wt;
     auto fetch = [&](int s) {
-        const int hc = s / nfc, fc = s - hc * nfc;
-        if (!x_resident || hc == 0) {
-#pragma unroll
-            for (int j = 0; j < XQ; ++j) {
-                const int i = tid + 256 * j, r = i / (FC / 4), c4 = i % (FC / 4);
-                xq[j] = load_quad<VEC>(x, N, F, n0 + r, fc * FC + 4 * c4);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WQ; ++j) {
-            const int i = tid + 256 * j, r = i / (FC / 4), c4 = i % (FC / 4);
-            wq[j] = load_quad<VEC>(W1k, nhid, F, hc * HC + r, fc * FC + 4 * c4);
-        }
-        if (fc == 0) {
-#pragma unroll
-            for (int j = 0; j < VQ; ++j) {
-                const int i = tid + 256 * j, r = i / (HC / 4), c4 = i % (HC / 4);
-                vq[j] = load_quad<VEC>(W2k, D, nhid, r, hc * HC + 4 * c4);
-            }
-        }
-        if (fc == nfc - 1) {                                    // bias of this hidden chunk, needed after its last step
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int h = hc * HC + acc_row(r, half);
-                const float bv = b1[(size_t)k * nhid + (h < nhid ? h : 0)];
-                bq[r] = h < nhid ? bv : 0.0f;
-            }
-        }
+        const int hc = hc0 + s / nfc, fc = s % nfc;
+        xt.fetch(x + (size_t)n0 * F + fc * FC, F, N - n0, F - fc * FC, tid);
+        wt.fetch(W1k + (size_t)hc * TH * F + fc * FC, F, nhid - hc * TH, F - fc * FC, tid);
     };
     auto stash = [&](int s) {
-        const int hc = s / nfc, fc = s - hc * nfc;
-        float* xb = xs + (x_resident ? fc : (s & 1)) * TILE_N * LDX;
-        float* wb = w1s + (s & 1) * HC * LDX;
-        if (!x_resident || hc == 0) {
+        xt.template stash<LDT>(xs + (s & 1) * TN * LDT, tid);
+        wt.template stash<LDT>(w1s + (s & 1) * TH * LDT, tid);
+    };
+    // W2_k[dt*32 + li][hidden quad g of tile ht]: the A operand of layer 2 for d-tile dt
+    auto load_w2 = [&](float4 (&wv)[2][4], int dt, int hbase) {
 #pragma unroll
-            for (int j = 0; j < XQ; ++j) {
-                const int i = tid + 256 * j, r = i / (FC / 4), c4 = i % (FC / 4);
-                store_quad(xb + r * LDX + 4 * c4, xq[j]);
-            }
-        }
+        for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-        for (int j = 0; j < WQ; ++j) {
-            const int i = tid + 256 * j, r = i / (FC / 4), c4 = i % (FC / 4);
-            store_quad(wb + r * LDX + 4 * c4, wq[j]);
-        }
-        if (fc == 0) {
-            float* vb = w2s + (hc & 1) * D * LDW2;
-#pragma unroll
-            for (int j = 0; j < VQ; ++j) {
-                const int i = tid + 256 * j, r = i / (HC / 4), c4 = i % (HC / 4);
-                store_quad(vb + r * LDW2 + 4 * c4, vq[j]);
-            }
-        }
+            for (int g = 0; g < 4; ++g)
+                wv[ht][g] = load4_raw<VEC>(W2k + (size_t)(dt * 32 + li) * nhid, hbase + ht * 32 + 8 * g + 4 * half, nhid);
     };
 
-    f32x16 zacc[DT], hacc;
+    f32x16 hacc[2], zacc[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int ht = 0; ht < 2; ++ht) zero_acc(hacc[ht]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zacc[dt][r] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
+    for (int dt = 0; dt < DT; ++dt) zero_acc(zacc[dt]);
 
-    fetch(0);
-    stash(0);
+    // Software pipeline (one register set per tile, write-after-barrier): during step s the registers hold
+    // tile s+1, whose global loads were issued one step earlier; it goes to the other LDS buffer in the shadow
+    // of the first MFMA block of step s (every wave left that buffer at the barrier before), and the loads of
+    // tile s+2 are issued right behind it.
+    if (steps > 0) {
+        fetch(0);
+        stash(0);
+        if (steps > 1) fetch(1);
+    }
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
-        const int hc = s / nfc, fc = s - hc * nfc;
-        float bias[16];                                         // this chunk's bias, fetched one step ahead
+        const int hc = hc0 + s / nfc, fc = s % nfc;
+        const bool last = fc == nfc - 1;
+        const int hbase = hc * TH + wh * 64;                    // first hidden unit of this wave's tile
+        float4 bias[2][4], wnext[2][4];                         // quad g of tile ht = hidden rows 8g+4*half .. +3
+        if (last) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bias[r] = bq[r];
-        if (s + 1 < steps) fetch(s + 1);                        // global loads in flight behind the MFMAs
-        // MFMA step q contracts the feature pair {q, 32+q} of the chunk: lane half h owns features
-        // h*32 .. h*32+31, i.e. 32 CONTIGUOUS floats per operand -> 8 ds_read_b128 each, all issued
-        // before the 32-MFMA chain (one wave per SIMD: nothing else would hide the LDS latency).
-        const float4* xa = reinterpret_cast<const float4*>(xs + (x_resident ? fc : (s & 1)) * TILE_N * LDX +
-                                                           (wave * 32 + li) * LDX + half * 32);
-        const float4* wa = reinterpret_cast<const float4*>(w1s + (s & 1) * HC * LDX + li * LDX + half * 32);
-        float4 av[8], bv[8];
+            for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { av[q] = wa[q]; bv[q] = xa[q]; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, hacc, 0, 0, 0);
-            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, hacc, 0, 0, 0);
-            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, hacc, 0, 0, 0);
-            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, hacc, 0, 0, 0);
+                for (int g = 0; g < 4; ++g) bias[ht][g] = load4_raw<VEC>(b1k, hbase + ht * 32 + 8 * g + 4 * half, nhid);
+            load_w2(wnext, 0, hbase);
         }
-        if (fc == nfc - 1) {
-            // bias + ReLU on hidT (row = hidden unit, column = node), then layer 2 straight from registers
+        // lane half h owns features h*FC/2 .. h*FC/2 + FC/2-1 of the chunk; MFMA block j takes 2 quads of them
+        // per operand row (3 ds_read_b128, 16 MFMAs), block j+1's reads are issued ahead of block j's MFMAs
+        const float* xb = xs + (s & 1) * TN * LDT + (wn * 32 + li) * LDT + half * (FC / 2);
+        const float* wb = w1s + (s & 1) * TH * LDT + (wh * 64 + li) * LDT + half * (FC / 2);
+        constexpr int NB = FC / 16;
+        float4 a[2][2][2], b[2][2];                             // [parity of block][...]
+        auto read_block = [&](int j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hacc[r] = fmaxf(hacc[r] + bias[r], 0.0f);
-            // register r of hidT holds hidden rows acc_row(r, half): 4 runs of 4 consecutive rows -> 4 b128 reads
-            const float* vb = w2s + (hc & 1) * D * LDW2;
-            float4 wv[DT][4];
+            for (int q = 0; q < 2; ++q) {
+                b[j & 1][q] = *reinterpret_cast<const float4*>(xb + 8 * j + 4 * q);
+                a[j & 1][0][q] = *reinterpret_cast<const float4*>(wb + 8 * j + 4 * q);
+                a[j & 1][1][q] = *reinterpret_cast<const float4*>(wb + 32 * LDT + 8 * j + 4 * q);
+            }
+        };
+        read_block(0);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+        for (int j = 0; j < NB; ++j) {
+            if (j + 1 < NB) read_block(j + 1);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    wv[dt][g4] = *reinterpret_cast<const float4*>(vb + (dt * 32 + li) * LDW2 + 8 * g4 + 4 * half);
+            for (int q = 0; q < 2; ++q) {
+                DL_MFMA(hacc[0], a[j & 1][0][q].x, b[j & 1][q].x);
+                DL_MFMA(hacc[1], a[j & 1][1][q].x, b[j & 1][q].x);
+                DL_MFMA(hacc[0], a[j & 1][0][q].y, b[j & 1][q].y);
+                DL_MFMA(hacc[1], a[j & 1][1][q].y, b[j & 1][q].y);
+                DL_MFMA(hacc[0], a[j & 1][0][q].z, b[j & 1][q].z);
+                DL_MFMA(hacc[1], a[j & 1][1][q].z, b[j & 1][q].z);
+                DL_MFMA(hacc[0], a[j & 1][0][q].w, b[j & 1][q].w);
+                DL_MFMA(hacc[1], a[j & 1][1][q].w, b[j & 1][q].w);
+            }
+            if (j == 0) {
+                if (s + 1 < steps) stash(s + 1);
+                if (s + 2 < steps) fetch(s + 2);
+            }
+        }
+        if (last) {
+            // bias + ReLU on hidT (row = hidden unit, column = node), then layer 2 straight from the registers
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bias[ht][g] = zero4<VEC>(bias[ht][g], hbase + ht * 32 + 8 * g + 4 * half, nhid);
+                    hacc[ht][4 * g + 0] = fmaxf(hacc[ht][4 * g + 0] + bias[ht][g].x, 0.0f);
+                    hacc[ht][4 * g + 1] = fmaxf(hacc[ht][4 * g + 1] + bias[ht][g].y, 0.0f);
+                    hacc[ht][4 * g + 2] = fmaxf(hacc[ht][4 * g + 2] + bias[ht][g].z, 0.0f);
+                    hacc[ht][4 * g + 3] = fmaxf(hacc[ht][4 * g + 3] + bias[ht][g].w, 0.0f);
+                }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
+                float4 wv[2][4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    zacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[dt][g4].x, hacc[4 * g4 + 0], zacc[dt], 0, 0, 0);
-                    zacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[dt][g4].y, hacc[4 * g4 + 1], zacc[dt], 0, 0, 0);
-                    zacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[dt][g4].z, hacc[4 * g4 + 2], zacc[dt], 0, 0, 0);
-                    zacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[dt][g4].w, hacc[4 * g4 + 3], zacc[dt], 0, 0, 0);
-                }
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) wv[ht][g] = zero4<VEC>(wnext[ht][g], hbase + ht * 32 + 8 * g + 4 * half, nhid);
+                if (dt + 1 < DT) load_w2(wnext, dt + 1, hbase);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int ht = 0; ht < 2; ++ht) {
+                        DL_MFMA(zacc[dt], wv[ht][g].x, hacc[ht][4 * g + 0]);
+                        DL_MFMA(zacc[dt], wv[ht][g].y, hacc[ht][4 * g + 1]);
+                        DL_MFMA(zacc[dt], wv[ht][g].z, hacc[ht][4 * g + 2]);
+                        DL_MFMA(zacc[dt], wv[ht][g].w, hacc[ht][4 * g + 3]);
+                    }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
+            for (int ht = 0; ht < 2; ++ht) zero_acc(hacc[ht]);
         }
-        if (s + 1 < steps) stash(s + 1);
         __syncthreads();
     }
-    // epilogue: Z[n][k][dd] = Z^T[dd][n] + b2[k][dd]; registers 4g..4g+3 are 4 consecutive dd
-    const int n = n0 + wave * 32 + li;
-    if (n < N) {
+    // The two hidden halves (wh = 0, 1) of a node quarter hold partial Z sums: wave wh = 1 hands its half
+    // over through LDS and wave wh = 0 adds (fixed order), adds b2 and stores (registers 4g..4g+3 are 4
+    // consecutive dd of node column li).
+    float* red = lds;                                           // [wn][dt][16][64]
+    if (wh == 1) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int dd = dt * 32 + 8 * g4 + 4 * half;
-                const float4 bb = *reinterpret_cast<const float4*>(b2 + (size_t)k * D + dd);
-                float4 o;
-                o.x = zacc[dt][4 * g4 + 0] + bb.x;
-                o.y = zacc[dt][4 * g4 + 1] + bb.y;
-                o.z = zacc[dt][4 * g4 + 2] + bb.z;
-                o.w = zacc[dt][4 * g4 + 3] + bb.w;
-                *reinterpret_cast<float4*>(Z + ((size_t)n * K + k) * D + dd) = o;
+            for (int r = 0; r < 16; ++r) red[((wn * DT + dt) * 16 + r) * 64 + lane] = zacc[dt][r];
+    }
+    __syncthreads();
+    const int n = n0 + wn * 32 + li;
+    if (wh == 0 && n < N) {
+        float* orow = out + (((size_t)grp * N + n) * K + k) * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = dt * 32 + 8 * g + 4 * half;
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b2 != nullptr) bb = *reinterpret_cast<const float4*>(b2 + (size_t)k * D + dd);
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = zacc[dt][4 * g + j] + red[((wn * DT + dt) * 16 + 4 * g + j) * 64 + lane];
+                *reinterpret_cast<float4*>(orow + dd) = make_float4(o[0] + bb.x, o[1] + bb.y, o[2] + bb.z, o[3] + bb.w);
             }
-        }
     }
 }
 
-template <int D>
-static size_t project2_lds_bytes() {
-    return sizeof(float) * (2 * TILE_N * (FC + 4) + 2 * HC * (FC + 4) + 2 * D * (HC + 4));
+constexpr size_t project2_lds(int D) { return sizeof(float) * (2 * TN + 2 * TH) * (fwd_fc(D) + 4); }
+
+// Z[n][c] = b2[c] + sum_g slab[g][n][c] (g ascending), c over K*D; 4 columns per thread.
+__global__ __launch_bounds__(256) void z_slab_sum_kernel(const float* __restrict__ slab, int G, size_t NC, int C,
+                                                         const float* __restrict__ b2, float* __restrict__ Z) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= NC) return;
+    float4 acc = *reinterpret_cast<const float4*>(b2 + i % C);
+    for (int g = 0; g < G; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)g * NC + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(Z + i) = acc;
 }
 
 // Single-layer projection (Factor): W [K][D][F], b [K][D]:  Z[n][k][:] = W_k x[n] + b_k.
@@ -246,6 +264,7 @@ __global__ __launch_bounds__(256) void project1_fwd_kernel(const float* __restri
                                                            const float* __restrict__ W, const float* __restrict__ b,
                                                            float* __restrict__ Z, int K) {
     constexpr int DT = D / 32;
+    constexpr int TILE_N = 128;                               // nodes per workgroup (4 waves x 32)
     constexpr int FC = D == 128 ? 32 : 64;                    // keep xs + ws inside 64 KiB of static LDS
     __shared__ float xs[TILE_N * (FC + 1)];
     __shared__ float ws[D * (FC + 1)];
@@ -296,43 +315,64 @@ __global__ __launch_bounds__(256) void project1_fwd_kernel(const float* __restri
 
 bool project_supported(int d) { return d == 32 || d == 64 || d == 128; }
 
+// Hidden-chunk groups per (node tile, factor): 1 when the grid already covers the 256 CUs a few times
+// over, else enough groups to get there (each group = whole 128-unit chunks).
+static int project2_groups(int N, int K, int nhid) {
+    const long long wg = (long long)((N + project::TN - 1) / project::TN) * K;
+    const int nhc = (nhid + project::TH - 1) / project::TH;
+    if (wg >= 768) return 1;
+    const int cpg = std::max(1, (int)(nhc / std::min<long long>(nhc, (768 + wg - 1) / wg)));
+    return (nhc + cpg - 1) / cpg;
+}
+
+size_t project_fwd_workspace_bytes(int N, int K, int nhid, int d, bool two_layer) {
+    if (!two_layer || N <= 0) return 0;
+    const int G = project2_groups(N, K, nhid);
+    return G > 1 ? sizeof(float) * (size_t)G * N * K * d : 0;
+}
+
 template <int D, bool VEC>
-static void launch2_t(dim3 grid, dim3 block, hipStream_t st, const float* x, int N, int F, int nhid, const float* W1,
-                      const float* b1, const float* W2, const float* b2, float* Z, int K) {
+static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float* x, int F, int nhid, const float* W1,
+                      const float* b1, const float* W2, const float* b2, float* out) {
     using namespace project;
     static bool attr_done = false;                         // > 64 KiB of dynamic LDS needs the attribute once
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)project2_lds_bytes<D>());
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)project2_lds(D));
         attr_done = true;
     }
-    hipLaunchKernelGGL((project2_fwd_kernel<D, VEC>), grid, block, project2_lds_bytes<D>(), st, x, N, F, nhid, W1, b1, W2,
-                       b2, Z, K);
-}
-
-static void launch2(int d, bool vec, dim3 grid, dim3 block, hipStream_t st, const float* x, int N, int F, int nhid,
-                    const float* W1, const float* b1, const float* W2, const float* b2, float* Z, int K) {
-#define DL_P2(DD)                                                                             \
-    if (d == DD) {                                                                            \
-        if (vec) launch2_t<DD, true>(grid, block, st, x, N, F, nhid, W1, b1, W2, b2, Z, K);   \
-        else launch2_t<DD, false>(grid, block, st, x, N, F, nhid, W1, b1, W2, b2, Z, K);      \
-        return;                                                                               \
-    }
-    DL_P2(32) DL_P2(64) DL_P2(128)
-#undef DL_P2
+    const dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)K, (unsigned)G);
+    hipLaunchKernelGGL((project2_fwd_kernel<D, VEC>), grid, dim3(NTHR), project2_lds(D), st, x, N, F, nhid, W1, b1, W2, b2,
+                       out, K, cpg);
 }
 
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* b2, float* Z, hipStream_t st) {
+                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, hipStream_t st) {
     using namespace project;
-    const dim3 grid((unsigned)((N + TILE_N - 1) / TILE_N), (unsigned)K), block(256);
     if (W2 == nullptr) {          // single Linear(F -> d): W1 is [K][d][F], b1 is [K][d]
+        const dim3 grid((unsigned)((N + 127) / 128), (unsigned)K), block(256);
         if (d == 32) hipLaunchKernelGGL(project1_fwd_kernel<32>, grid, block, 0, st, x, N, F, W1, b1, Z, K);
         else if (d == 64) hipLaunchKernelGGL(project1_fwd_kernel<64>, grid, block, 0, st, x, N, F, W1, b1, Z, K);
         else hipLaunchKernelGGL(project1_fwd_kernel<128>, grid, block, 0, st, x, N, F, W1, b1, Z, K);
-    } else {
-        const bool vec = (F % 4 == 0) && (nhid % 4 == 0);      // quads never straddle a row end
-        launch2(d, vec, grid, block, st, x, N, F, nhid, W1, b1, W2, b2, Z, K);
+        return check_launch("project_fwd");
+    }
+    const bool vec = (F % 4 == 0) && (nhid % 4 == 0);      // quads never straddle a row end
+    int G = project2_groups(N, K, nhid);
+    if (G > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)G * N * K * d)) G = 1;   // no workspace: one group
+    const int nhc = (nhid + TH - 1) / TH;
+    const int cpg = (nhc + G - 1) / G;
+    float* out = G > 1 ? static_cast<float*>(ws) : Z;
+    const float* bias2 = G > 1 ? nullptr : b2;
+#define DL_P2(DD)                                                                                       \
+    if (d == DD) {                                                                                      \
+        if (vec) launch2_t<DD, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out);             \
+        else launch2_t<DD, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out);                \
+    }
+    DL_P2(32) DL_P2(64) DL_P2(128)
+#undef DL_P2
+    if (G > 1) {
+        const size_t NC = (size_t)N * K * d;
+        hipLaunchKernelGGL(z_slab_sum_kernel, dim3((unsigned)((NC / 4 + 255) / 256)), dim3(256), 0, st, out, G, NC, K * d, b2, Z);
     }
     return check_launch("project_fwd");
 }

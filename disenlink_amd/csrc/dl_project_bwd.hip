@@ -1,0 +1,480 @@
+// Backward of the factor projection on the matrix cores: the weight gradients of the K factor MLPs
+// (autograd of model.py:13-15, 24-27 as driven by main_disentangled.py:198).  x is data: no dx.
+//
+//   two-layer:   hid = relu(x W1_k^T + b1_k)               recomputed, never read from HBM
+//                dhid = (dZ_k W2_k) . [hid > 0]            -> workspace [N][K][nhid]
+//                dW2_k = dZ_k^T hid,  db1_k = colsum(dhid)  (kernel A: project2_bwd_hidden_kernel)
+//                dW1_k = dhid^T x                           (kernel B: nodes_contract_kernel)
+//                db2   = colsum(dZ)                         (colsum_kernel)
+//   one layer:   dW_k = dZ_k^T x (kernel B),  db = colsum(dZ)
+//
+// Every contraction over the NODE index is split into S node ranges whose partial results go to
+// separate slabs and are added in slab order by slab_sum_kernel: no float atomics, so the gradients
+// are bitwise reproducible run to run (like the rest of the path).
+//
+// Register layout used throughout: a 32x32 MFMA accumulator keeps its COLUMN on the lane and its 16
+// rows (acc_row(r, half)) in the registers.  Kernel A computes hid and dhid as [node][hidden] tiles
+// (node = row), so both can be fed back unchanged as the B operand of products that contract over the
+// node index — dW2 += dZ^T . hid takes hid straight from the accumulator registers.
+#include <algorithm>
+#include "dl_common.h"
+#include "dl_kernels.h"
+#include "dl_tiles.h"
+
+namespace dl {
+namespace project {
+
+constexpr int TILE_N = 128;   // nodes per workgroup step (4 wave quarters x 32)
+constexpr int BFC = 32;       // feature chunk staged per step
+constexpr int LDB = BFC + 4;  // LDS row pitch of the layer-1 operand tiles
+constexpr int BTHR = 512;
+
+// hidden units per workgroup of kernel A: 2 wave halves x HT tiles of 32 (HT = 1 for D = 128: LDS budget)
+constexpr int bwd_ht(int D) { return D <= 64 ? 2 : 1; }
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A.  grid = (hidden chunks of 64*HT, K, S node ranges); one workgroup = 8 waves = 128 nodes per
+// node tile: node quarter wn (32 nodes) x hidden half wh (32*HT units).  Same write-after-barrier staging
+// pipeline as the forward kernel (dl_project.hip).  Per node tile, once the layer-1 sum over F is complete:
+//   hid  = relu(acc + b1)                       [node][hidden]: node rows in registers, hidden on lanes
+//   dW2 += dZ^T . hid                           A = dZ^T from LDS (b32), B = hid registers
+//   dhid = (dZ . W2^T) masked by hid > 0        A = dZ rows, B = W2^T rows, both b128 from LDS
+// VEC: F % 4 == 0 (x and W1 rows are sequences of aligned quads).
+template <int D, bool VEC>
+__global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
+    const float* __restrict__ x, int N, int F, int nhid, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ dZ, int K, int tiles_per_range,
+    float* __restrict__ dhid, float* __restrict__ dW2p, float* __restrict__ db1p) {
+    constexpr int DT = D / 32, HT = bwd_ht(D), HB = 64 * HT;
+    constexpr int LDZ = D + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                               // [2][TILE_N][LDB]
+    float* w1s = xs + 2 * TILE_N * LDB;            // [2][HB][LDB]
+    float* dzs = w1s + 2 * HB * LDB;               // [TILE_N][LDZ]   dZ_k rows of the current node tile
+    float* w2t = dzs + TILE_N * LDZ;               // [HB][LDZ]       W2_k[:, chunk]^T, staged once
+    const int hc = blockIdx.x, k = blockIdx.y, rng = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, half = lane >> 5;
+    const int wn = wave >> 1, wh = wave & 1;
+    const int n_tiles = (N + TILE_N - 1) / TILE_N;
+    const int tile0 = rng * tiles_per_range;
+    const int my_tiles = max(0, min(tiles_per_range, n_tiles - tile0));
+    const float* W1k = W1 + (size_t)k * nhid * F;
+    const float* W2k = W2 + (size_t)k * D * nhid;
+    const float* dZk = dZ + (size_t)k * D;         // row n at dZk + n*K*D
+    const int nfc = (F + BFC - 1) / BFC;
+    const int steps = my_tiles * nfc;
+    const int hw0 = hc * HB + wh * 32 * HT;        // first hidden unit of this wave
+
+    for (int i = tid; i < HB * D; i += BTHR) {     // W2^T chunk: w2t[h][dd] = W2_k[dd][hc*HB + h]
+        const int dd = i / HB, h = i - dd * HB;
+        const int hh = hc * HB + h;
+        w2t[h * LDZ + dd] = hh < nhid ? W2k[(size_t)dd * nhid + hh] : 0.0f;
+    }
+    float b1v[HT];
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+        const int h = hw0 + ht * 32 + li;
+        b1v[ht] = h < nhid ? b1[(size_t)k * nhid + h] : 0.0f;
+    }
+
+    TileStage<TILE_N, BFC, VEC, BTHR> xt;
+    TileStage<HB, BFC, VEC, BTHR> wt;
+    TileStage<TILE_N, D, true, BTHR> zt;           // dZ rows: D % 32 == 0, row stride K*D: always aligned quads
+    auto fetch = [&](int s) {
+        const int tl = s / nfc, fc = s % nfc;
+        const int n0 = (tile0 + tl) * TILE_N;
+        xt.fetch(x + (size_t)n0 * F + fc * BFC, F, N - n0, F - fc * BFC, tid);
+        wt.fetch(W1k + (size_t)hc * HB * F + fc * BFC, F, nhid - hc * HB, F - fc * BFC, tid);
+    };
+    auto stash = [&](int s) {
+        xt.template stash<LDB>(xs + (s & 1) * TILE_N * LDB, tid);
+        wt.template stash<LDB>(w1s + (s & 1) * HB * LDB, tid);
+    };
+
+    f32x16 hacc[HT], w2acc[DT][HT];
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+        zero_acc(hacc[ht]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) zero_acc(w2acc[dt][ht]);
+    }
+    float b1acc[HT];
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) b1acc[ht] = 0.0f;
+
+    if (steps > 0) {
+        fetch(0);
+        stash(0);
+        if (steps > 1) fetch(1);
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int tl = s / nfc, fc = s % nfc;
+        const bool last = fc == nfc - 1;
+        const int n0 = (tile0 + tl) * TILE_N;
+        if (last) zt.fetch(dZk + (size_t)n0 * K * D, K * D, N - n0, D, tid);      // consumed after the MFMAs below
+        // hid[node][hidden] += x[node][f] . W1[hidden][f]: A = x rows of this node quarter, B = W1 rows
+        const float* xb = xs + (s & 1) * TILE_N * LDB + (wn * 32 + li) * LDB + half * (BFC / 2);
+        const float* wb = w1s + (s & 1) * HB * LDB + (wh * 32 * HT + li) * LDB + half * (BFC / 2);
+        constexpr int NB = BFC / 16;
+        float4 a[2][2], b[2][HT][2];
+        auto read_block = [&](int j) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a[j & 1][q] = *reinterpret_cast<const float4*>(xb + 8 * j + 4 * q);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht)
+                    b[j & 1][ht][q] = *reinterpret_cast<const float4*>(wb + ht * 32 * LDB + 8 * j + 4 * q);
+            }
+        };
+        read_block(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j + 1 < NB) read_block(j + 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], a[j & 1][q].x, b[j & 1][ht][q].x);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], a[j & 1][q].y, b[j & 1][ht][q].y);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], a[j & 1][q].z, b[j & 1][ht][q].z);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], a[j & 1][q].w, b[j & 1][ht][q].w);
+            }
+            if (j == 0) {
+                if (s + 1 < steps) stash(s + 1);
+                if (s + 2 < steps) fetch(s + 2);
+            }
+        }
+        if (last) {
+            // every wave is past the previous tile's use of dzs (barrier at the end of that step)
+            zt.template stash<LDZ>(dzs, tid);
+            __syncthreads();
+            float hid[HT][16];
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hid[ht][r] = fmaxf(hacc[ht][r] + b1v[ht], 0.0f);
+            // dW2[dd][hidden] += dZ[node][dd] . hid[node][hidden]: the k-pair of register r is the node pair
+            // {acc_row(r,0), acc_row(r,1)} of this quarter
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float zv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zv[r] = dzs[(wn * 32 + acc_row(r, half)) * LDZ + dt * 32 + li];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int ht = 0; ht < HT; ++ht) DL_MFMA(w2acc[dt][ht], zv[r], hid[ht][r]);
+            }
+            // dhid[node][hidden] = dZ[node][dd] . W2^T[hidden][dd], masked by the ReLU
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) zero_acc(hacc[ht]);
+            const float* za = dzs + (wn * 32 + li) * LDZ + half * (D / 2);
+            const float* va = w2t + (wh * 32 * HT + li) * LDZ + half * (D / 2);
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q) {
+                const float4 zq = *reinterpret_cast<const float4*>(za + 4 * q);
+                float4 vq[HT];
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) vq[ht] = *reinterpret_cast<const float4*>(va + ht * 32 * LDZ + 4 * q);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], zq.x, vq[ht].x);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], zq.y, vq[ht].y);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], zq.z, vq[ht].z);
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], zq.w, vq[ht].w);
+            }
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) {
+                const int h = hw0 + ht * 32 + li;
+                float colsum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = hid[ht][r] > 0.0f ? hacc[ht][r] : 0.0f;
+                    const int n = n0 + wn * 32 + acc_row(r, half);
+                    if (n < N && h < nhid) dhid[((size_t)n * K + k) * nhid + h] = g;
+                    colsum += g;
+                }
+                b1acc[ht] += colsum;
+                zero_acc(hacc[ht]);
+            }
+        }
+        __syncthreads();
+    }
+    // cross-wave reduction (fixed order over the 4 node quarters) of the dW2 / db1 partials of this range
+    constexpr int RW = DT * HT * 16 + HT;                       // floats per lane and wave
+    float* red = lds;                                           // [8 waves][RW][64 lanes]
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * RW + (dt * HT + ht) * 16 + r) * 64 + lane] = w2acc[dt][ht][r];
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) red[(wave * RW + DT * HT * 16 + ht) * 64 + lane] = b1acc[ht];
+    __syncthreads();
+    if (wn == 0) {                                              // waves 0 (wh = 0) and 1 (wh = 1) write out
+        float* out = dW2p + ((size_t)rng * K + k) * D * nhid;
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+            const int h = hw0 + ht * 32 + li;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v += red[((2 * q + wh) * RW + (dt * HT + ht) * 16 + r) * 64 + lane];
+                    if (h < nhid) out[(size_t)(dt * 32 + acc_row(r, half)) * nhid + h] = v;
+                }
+            float v = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* p = red + ((2 * q + wh) * RW + DT * HT * 16 + ht) * 64;
+                v += p[li] + p[32 + li];
+            }
+            if (half == 0 && h < nhid) db1p[((size_t)rng * K + k) * nhid + h] = v;
+        }
+    }
+}
+
+constexpr size_t project2_bwd_lds(int D) {
+    const size_t stage = 2 * TILE_N * LDB + 2 * 64 * bwd_ht(D) * LDB + TILE_N * (D + 4) + 64 * bwd_ht(D) * (D + 4);
+    const size_t red = 8 * (size_t)((D / 32) * bwd_ht(D) * 16 + bwd_ht(D)) * 64;
+    return sizeof(float) * (stage > red ? stage : red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel B.  C[k][m][f] (+slab) = sum over the nodes of one range of  Y[n][k][m] * X[n][f]
+//   Y row n at Y + n*ldY + k*M (M columns), X [N][F] row-major.  Output slab [K][M][F].
+// grid = (f tiles of 128, m tiles of 128, K * S); 4 waves as 2 x 2, each 64 m x 64 f (4 accumulators),
+// two workgroups per CU.  Node chunk of 32 per step; MFMA step q contracts the node pair {base(q), base(q)+8}:
+// with a row pitch of 132 floats the two halves of a wavefront read banks 32 apart -> conflict-free ds_read_b32.
+constexpr int CT = 128, NC = 32, LDC = CT + 4;
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void nodes_contract_kernel(const float* __restrict__ Y, int ldY, int M,
+                                                                const float* __restrict__ X, int F, int N, int K,
+                                                                int chunks_per_range, float* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ys = lds;                    // [2][NC][LDC]
+    float* xs = ys + 2 * NC * LDC;      // [2][NC][LDC]
+    const int f0 = blockIdx.x * CT, m0 = blockIdx.y * CT;
+    const int k = blockIdx.z % K, rng = blockIdx.z / K;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wf = wave & 1;
+    const int n_chunks = (N + NC - 1) / NC;
+    const int chunk0 = rng * chunks_per_range;
+    const int my_chunks = max(0, min(chunks_per_range, n_chunks - chunk0));
+    const float* Yk = Y + (size_t)k * M + m0;
+
+    TileStage<NC, CT, VEC, 256> yt, xt;
+    auto fetch = [&](int c) {
+        const int n0 = (chunk0 + c) * NC;
+        yt.fetch(Yk + (size_t)n0 * ldY, ldY, N - n0, M - m0, tid);
+        xt.fetch(X + (size_t)n0 * F + f0, F, N - n0, F - f0, tid);
+    };
+    auto stash = [&](int c) {
+        yt.template stash<LDC>(ys + (c & 1) * NC * LDC, tid);
+        xt.template stash<LDC>(xs + (c & 1) * NC * LDC, tid);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) zero_acc(acc[a][b]);
+    if (my_chunks > 0) {
+        fetch(0);
+        stash(0);
+        if (my_chunks > 1) fetch(1);
+    }
+    __syncthreads();
+    for (int c = 0; c < my_chunks; ++c) {
+        const float* yb = ys + (c & 1) * NC * LDC + wm * 64 + li;
+        const float* xb = xs + (c & 1) * NC * LDC + wf * 64 + li;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int node = (q >> 3) * 16 + (q & 7) + 8 * half;
+            const float a0 = yb[node * LDC], a1 = yb[node * LDC + 32];
+            const float b0 = xb[node * LDC], b1 = xb[node * LDC + 32];
+            DL_MFMA(acc[0][0], a0, b0);
+            DL_MFMA(acc[0][1], a0, b1);
+            DL_MFMA(acc[1][0], a1, b0);
+            DL_MFMA(acc[1][1], a1, b1);
+            if (q == 3) {                                       // staging in the shadow of the MFMAs
+                if (c + 1 < my_chunks) stash(c + 1);
+                if (c + 2 < my_chunks) fetch(c + 2);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = C + ((size_t)rng * K + k) * M * F;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int f = f0 + wf * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + acc_row(r, half);
+                if (m < M && f < F) out[(size_t)m * F + f] = acc[a][b][r];
+            }
+        }
+}
+
+// out[i] = sum_s slabs[s][i], s ascending (fixed order).
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int S, size_t n,
+                                                       float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.0f;
+    for (int s = 0; s < S; ++s) v += slabs[(size_t)s * n + i];
+    out[i] = v;
+}
+
+// Column sums of a row-major [N][C] matrix over S row ranges -> part[S][C].  Block = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int N, int C, int rows_per_range,
+                                                     float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_range, r1 = min(N, r0 + rows_per_range);
+    float v = 0.0f;
+    if (c < C)
+        for (int r = r0 + rl; r < r1; r += 4) v += A[(size_t)r * C + c];
+    red[rl][cl] = v;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// ---------------------------------------------------------------- host side: ranges, workspace, launches
+struct BwdLayout {
+    int sA, tiles_per_range;       // kernel A node ranges
+    int sB, chunks_per_range;      // kernel B node ranges
+    int sC, rows_per_range;        // colsum ranges
+    int Mb;                        // rows of the kernel-B output per factor (nhid, or d for one layer)
+    size_t off_dhid, off_w1p, off_w2p, off_b1p, off_b2p, bytes;
+};
+
+static int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer) {
+    BwdLayout L{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int target = 768;                                    // workgroups wanted per launch (256 CUs x 3)
+    const int n_tiles = ceil_div(N, TILE_N), n_chunks = ceil_div(N, NC);
+    L.Mb = two_layer ? nhid : d;
+    const long long wgA = (long long)ceil_div(nhid, 64 * bwd_ht(d)) * K;
+    L.sA = (int)std::max(1LL, std::min<long long>(n_tiles, ceil_div(target, wgA)));
+    L.tiles_per_range = ceil_div(n_tiles, L.sA);
+    L.sA = ceil_div(n_tiles, L.tiles_per_range);
+    const long long wgB = (long long)ceil_div(L.Mb, CT) * ceil_div(F, CT) * K;
+    L.sB = (int)std::max(1LL, std::min<long long>(n_chunks, ceil_div(target, wgB)));
+    L.chunks_per_range = ceil_div(n_chunks, L.sB);
+    L.sB = ceil_div(n_chunks, L.chunks_per_range);
+    const int colblocks = ceil_div((long long)K * d, 64);
+    L.sC = (int)std::max(1LL, std::min<long long>(ceil_div(N, 64), ceil_div(target, colblocks)));
+    L.rows_per_range = ceil_div(N, L.sC);
+    L.sC = ceil_div(N, L.rows_per_range);
+    size_t off = 0;
+    L.off_dhid = off; off += two_layer ? al(sizeof(float) * (size_t)N * K * nhid) : 0;
+    L.off_w1p = off;  off += L.sB > 1 ? al(sizeof(float) * (size_t)L.sB * K * L.Mb * F) : 0;
+    L.off_w2p = off;  off += two_layer ? al(sizeof(float) * (size_t)L.sA * K * d * nhid) : 0;
+    L.off_b1p = off;  off += two_layer ? al(sizeof(float) * (size_t)L.sA * K * nhid) : 0;
+    L.off_b2p = off;  off += al(sizeof(float) * (size_t)L.sC * K * d);
+    L.bytes = off;
+    return L;
+}
+
+}  // namespace project
+
+size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer) {
+    if (N <= 0) return 0;
+    return project::bwd_layout(N, F, K, nhid, d, two_layer).bytes;
+}
+
+template <int D, bool VEC>
+static void launchA_t(dim3 grid, hipStream_t st, const float* x, int N, int F, int nhid, const float* W1,
+                      const float* b1, const float* W2, const float* dZ, int K, int tpr, float* dhid, float* dW2p,
+                      float* db1p) {
+    using namespace project;
+    static bool attr_done = false;
+    constexpr size_t lds = project2_bwd_lds(D);
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1, b1, W2, dZ,
+                       K, tpr, dhid, dW2p, db1p);
+}
+
+static void slab_sum(const float* slabs, int S, size_t n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(project::slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, S, n, out);
+}
+
+int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
+                hipStream_t st) {
+    using namespace project;
+    const bool two = W2 != nullptr;
+    const BwdLayout L = bwd_layout(N, F, K, nhid, d, two);
+    char* base = static_cast<char*>(ws);
+    float* dhid = reinterpret_cast<float*>(base + L.off_dhid);
+    float* w1p = reinterpret_cast<float*>(base + L.off_w1p);
+    float* w2p = reinterpret_cast<float*>(base + L.off_w2p);
+    float* b1p = reinterpret_cast<float*>(base + L.off_b1p);
+    float* b2p = reinterpret_cast<float*>(base + L.off_b2p);
+    const bool vecA = F % 4 == 0;                                   // kernel A: x and W1 rows
+    const bool vecB = F % 4 == 0 && L.Mb % 4 == 0;                  // kernel B: Y rows (stride K*Mb) and x rows
+
+    // bias of the output layer: column sums of dZ [N][K*d]
+    float* dbo = two ? db2 : db1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div((long long)K * d, 64), (unsigned)L.sC), dim3(256), 0, st,
+                       dZ, N, K * d, L.rows_per_range, b2p);
+    slab_sum(b2p, L.sC, (size_t)K * d, dbo, st);
+
+    const float* Y = dZ;
+    int ldY = K * d;
+    if (two) {
+        const dim3 grid((unsigned)ceil_div(nhid, 64 * bwd_ht(d)), (unsigned)K, (unsigned)L.sA);
+#define DL_PA(DD)                                                                                               \
+    if (d == DD) {                                                                                              \
+        if (vecA) launchA_t<DD, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p);  \
+        else launchA_t<DD, false>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p);      \
+    }
+        DL_PA(32) DL_PA(64) DL_PA(128)
+#undef DL_PA
+        slab_sum(w2p, L.sA, (size_t)K * d * nhid, dW2, st);
+        slab_sum(b1p, L.sA, (size_t)K * nhid, db1, st);
+        Y = dhid;
+        ldY = K * nhid;
+    }
+    {
+        static bool attr_done = false;
+        const size_t lds = sizeof(float) * 4 * NC * LDC;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        const dim3 grid((unsigned)ceil_div(F, CT), (unsigned)ceil_div(L.Mb, CT), (unsigned)(K * L.sB));
+        float* out = L.sB > 1 ? w1p : dW1;
+        if (vecB) hipLaunchKernelGGL(nodes_contract_kernel<true>, grid, dim3(256), lds, st, Y, ldY, L.Mb, x, F, N, K,
+                                    L.chunks_per_range, out);
+        else hipLaunchKernelGGL(nodes_contract_kernel<false>, grid, dim3(256), lds, st, Y, ldY, L.Mb, x, F, N, K,
+                                L.chunks_per_range, out);
+        if (L.sB > 1) slab_sum(w1p, L.sB, (size_t)K * L.Mb * F, dW1, st);
+    }
+    return check_launch("project_bwd");
+}
+
+}  // namespace dl

@@ -1,0 +1,95 @@
+// Tile staging and MFMA helpers shared by the projection kernels (dl_project.hip, dl_project_bwd.hip).
+//
+// fp32 matrix-core products use v_mfma_f32_32x32x2_f32: a 32x32 accumulator keeps its COLUMN on the
+// lane (lane & 31) and 16 of its rows in the registers — register r of lane half h (lane >> 5) is row
+// acc_row(r, h).  Operand A supplies A[row = lane & 31][k = half], operand B supplies B[k = half][col = lane & 31].
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dl {
+namespace project {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ void zero_acc(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+}
+
+// x where m is all ones, +0.0f where m is 0 — exact for any x (a multiply by 0 would turn inf / NaN garbage
+// into NaN), and not something the compiler can turn back into a branch around the load that produced x.
+__device__ __forceinline__ float mask_bits(float x, unsigned m) { return __uint_as_float(__float_as_uint(x) & m); }
+
+#define DL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
+
+// A [ROWS][COLS] tile of a row-major matrix (row stride ld floats) on its way global -> registers -> LDS
+// (row pitch PITCH floats), split so that the global loads can be issued before a long MFMA chain and the
+// LDS stores after it.  `origin` points at the tile's first element (always a valid element);
+// rows_valid / cols_valid = how much of the tile lies inside the matrix (the rest reads as zero).
+//   VEC:  every row start and the matrix width are multiples of 4 floats (16-byte aligned quads that are
+//         fully inside or fully outside): one dwordx4 load per quad.
+//   else: scalar loads, consecutive lanes on consecutive floats (fully coalesced; rows of odd length have
+//         no common alignment).
+// Offsets are 32-bit from a wave-uniform origin (saddr + voffset addressing, no 64-bit VALU math).  Full
+// tiles take an unchecked path; edge tiles load from clamped, always valid addresses and select afterwards
+// (a branch around a load would make hipcc wait for each load separately).
+template <int ROWS, int COLS, bool VEC, int THREADS>
+struct TileStage {
+    static constexpr int NV = ROWS * COLS / THREADS;   // floats per thread
+    static_assert(ROWS * COLS % (4 * THREADS) == 0, "tile does not divide over the workgroup");
+    float v[NV];
+    int rows_valid, cols_valid;                        // of the tile in flight (wave-uniform)
+
+    // Issue the loads only.  Nothing here consumes a loaded value: the zero fill of the part outside the
+    // matrix happens in stash(), so the s_waitcnt for these loads lands after the MFMA chain in between.
+    __device__ __forceinline__ void fetch(const float* __restrict__ origin, int ld, int rv, int cv, int tid) {
+        rows_valid = rv;
+        cols_valid = cv;
+        const bool full = rv >= ROWS && cv >= COLS;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < NV / 4; ++j) {
+                const int i = tid + THREADS * j, r = i / (COLS / 4), c = 4 * (i % (COLS / 4));
+                const bool ok = full || (r < rv && c < cv);
+                const float4 q = *reinterpret_cast<const float4*>(origin + (ok ? (unsigned)(r * ld + c) : 0u));
+                v[4 * j + 0] = q.x;
+                v[4 * j + 1] = q.y;
+                v[4 * j + 2] = q.z;
+                v[4 * j + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = tid + THREADS * j, r = i / COLS, c = i % COLS;
+                const bool ok = full || (r < rv && c < cv);
+                v[j] = origin[ok ? (unsigned)(r * ld + c) : 0u];
+            }
+        }
+    }
+    template <int PITCH>
+    __device__ __forceinline__ void stash(float* lds, int tid) const {
+        const bool full = rows_valid >= ROWS && cols_valid >= COLS;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < NV / 4; ++j) {
+                const int i = tid + THREADS * j, r = i / (COLS / 4), c = 4 * (i % (COLS / 4));
+                const unsigned m = (full || (r < rows_valid && c < cols_valid)) ? 0xFFFFFFFFu : 0u;
+                *reinterpret_cast<float4*>(lds + r * PITCH + c) =
+                    make_float4(mask_bits(v[4 * j], m), mask_bits(v[4 * j + 1], m), mask_bits(v[4 * j + 2], m),
+                                mask_bits(v[4 * j + 3], m));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = tid + THREADS * j, r = i / COLS, c = i % COLS;
+                const unsigned m = (full || (r < rows_valid && c < cols_valid)) ? 0xFFFFFFFFu : 0u;
+                lds[r * PITCH + c] = mask_bits(v[j], m);
+            }
+        }
+    }
+};
+
+}  // namespace project
+}  // namespace dl

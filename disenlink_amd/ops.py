@@ -8,6 +8,8 @@ There is no fallback: tensors must be CUDA(HIP) fp32 tensors and the library mus
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -219,12 +221,35 @@ def route_aggregate_bwd_phase2(g: Graph, Z, beta: float, t: float, p, a, s, dH, 
     return dZ_out
 
 
-def project_fwd(x, W1, b1, W2=None, b2=None) -> torch.Tensor:
+_xpad_cache: dict = {}
+
+
+def _pad_features(x, W1):
+    """Rows of F floats with F % 4 != 0 have no common 16-byte alignment, which would force the kernels onto
+    scalar loads.  Zero-pad the feature axis of x (once per tensor: the features are constant data) and of W1
+    (per call: one small copy) to a multiple of 4; zero columns add nothing to any product."""
+    F = x.shape[1]
+    Fp = (F + 3) // 4 * 4
+    if Fp == F:
+        return x, W1
+    key = (x.data_ptr(), x._version, tuple(x.shape), x.device)
+    hit = _xpad_cache.get("x")
+    if hit is None or hit[0] != key:
+        hit = (key, torch.nn.functional.pad(x, (0, Fp - F)))
+        _xpad_cache["x"] = hit
+    return hit[1], torch.nn.functional.pad(W1, (0, Fp - F))
+
+
+def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True) -> torch.Tensor:
     """Z [N,K,d] = K MLPs of x on the matrix cores.  Two-layer: W1 [K,nhid,F], b1 [K,nhid], W2 [K,d,nhid],
     b2 [K,d]; single layer: W1 [K,d,F], b1 [K,d], W2 = b2 = None.  model.py:13-15 / 24-27 / 106."""
     lib = _lib.load()
     x, W1, b1 = _f32c(x), _f32c(W1), _f32c(b1)
     _need_cuda(x, W1, b1)
+    if W1.shape[2] != x.shape[1]:
+        raise ValueError("W1 does not match the feature count of x")
+    if pad:
+        x, W1 = _pad_features(x, W1)
     N, F = x.shape
     K = W1.shape[0]
     if W2 is None:
@@ -237,9 +262,44 @@ def project_fwd(x, W1, b1, W2=None, b2=None) -> torch.Tensor:
     if W1.shape[2] != F:
         raise ValueError("W1 does not match the feature count of x")
     Z = torch.empty((N, K, d), dtype=torch.float32, device=x.device)
+    ws = _ws.get(int(lib.dl_project_fwd_workspace_bytes(N, F, K, nhid, d, int(W2 is not None))), x.device)
     _lib.check(lib.dl_project_fwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(), w2p, b2p,
-                                  Z.data_ptr(), _stream()), "dl_project_fwd")
+                                  Z.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_project_fwd")
     return Z
+
+
+def project_bwd(x, W1, b1, W2, dZ, pad: bool = True):
+    """Weight / bias gradients of the projection from dZ [N,K,d]: (dW1, db1, dW2, db2), shaped like the weights
+    (dW2 = db2 = None for the single layer).  autograd of model.py:13-15 / 24-27."""
+    lib = _lib.load()
+    x, W1, b1, dZ = _f32c(x), _f32c(W1), _f32c(b1), _f32c(dZ)
+    _need_cuda(x, W1, b1, dZ)
+    if W1.shape[2] != x.shape[1]:
+        raise ValueError("inconsistent projection shapes")
+    F_true = x.shape[1]
+    if pad:
+        x, W1 = _pad_features(x, W1)
+    N, F = x.shape
+    K = W1.shape[0]
+    two = W2 is not None
+    if two:
+        W2 = _f32c(W2)
+        d, nhid = W2.shape[1], W1.shape[1]
+    else:
+        d, nhid = W1.shape[1], 1
+    if dZ.shape != (N, K, d) or W1.shape[2] != F:
+        raise ValueError("inconsistent projection shapes")
+    dW1, db1 = torch.empty_like(W1), torch.empty_like(b1)
+    dW2 = torch.empty_like(W2) if two else None
+    db2 = torch.empty((K, d), dtype=torch.float32, device=x.device) if two else None
+    ws = _ws.get(int(lib.dl_project_bwd_workspace_bytes(N, F, K, nhid, d, int(two))), x.device)
+    _lib.check(lib.dl_project_bwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
+                                  W2.data_ptr() if two else None, dZ.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
+                                  dW2.data_ptr() if two else None, db2.data_ptr() if two else None,
+                                  ws.data_ptr(), ws.numel(), _stream()), "dl_project_bwd")
+    if F != F_true:
+        dW1 = dW1[..., :F_true].contiguous()
+    return dW1, db1, dW2, db2
 
 
 def project_supported(d: int) -> bool:
@@ -249,8 +309,8 @@ def project_supported(d: int) -> bool:
 # ---------------------------------------------------------------------- autograd
 class Project(torch.autograd.Function):
     """Z = MLP_k(x) for all k.  Forward: the fused MFMA kernel (hidden activations never leave the
-    register file).  Backward: library GEMMs on the recomputed hidden layer (a native backward is the
-    next step for this row); x is data and gets no gradient."""
+    register file).  Backward: dl_project_bwd (hidden layer recomputed on the matrix cores); x is data and
+    gets no gradient."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2):
@@ -286,7 +346,10 @@ class RouteAggregate(torch.autograd.Function):
 
 
 def _project_grads(x, W1, b1, W2, dZ):
-    """Library-GEMM backward of the projection on stacked weights -> (dW1, db1, dW2, db2)."""
+    """Backward of the projection on stacked weights -> (dW1, db1, dW2, db2): the MFMA kernels of
+    dl_project_bwd (env DL_PROJECT_BWD=library selects the library-GEMM form kept for timing comparisons)."""
+    if os.environ.get("DL_PROJECT_BWD", "native") != "library":
+        return project_bwd(x, W1, b1, W2, dZ)
     if W2 is None:                                              # Z[n,k,:] = W1[k] x[n] + b1[k]
         return torch.einsum("nkd,nf->kdf", dZ, x), dZ.sum(dim=0), None, None
     pre = torch.einsum("nf,khf->nkh", x, W1) + b1               # [N,K,nhid]

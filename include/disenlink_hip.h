@@ -151,11 +151,28 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
  *                          W1 [K][nhid][F], b1 [K][nhid], W2 [K][d][nhid], b2 [K][d]
  *   single layer (Factor): pass W2 = b2 = NULL, nhid = 1:  Z[n][k][:] = W1[k] . x[n] + b1[k],  W1 [K][d][F], b1 [K][d]
  * x is fp32 [N][F] row-major, Z fp32 [N][K][d].  d must be 32, 64 or 128 (dl_project_supported).
- * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain). */
+ * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain).
+ * ws (optional, dl_project_fwd_workspace_bytes): on small graphs the hidden layer is split over several
+ * workgroups per node tile whose partial sums meet in ws (added in a fixed order); without it (NULL / too
+ * small) one workgroup walks the whole hidden layer — same result up to summation order, less parallelism. */
 int dl_project_supported(int d);
+size_t dl_project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer);
 int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d,
                    const float* W1, const float* b1, const float* W2, const float* b2,
-                   float* Z, void* stream);
+                   float* Z, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of the projection: replaces autograd of model.py:13-15 / 24-27 under loss.backward()
+ * (main_disentangled.py:198).  dZ fp32 [N][K][d] in; weight and bias gradients out, shaped like the weights
+ * (dW1 like W1, db1 like b1, dW2 like W2, db2 like b2; single layer: W2 = dW2 = db2 = NULL, nhid = 1).
+ * x is data and gets no gradient.  The hidden layer is recomputed on the matrix cores (never read from HBM);
+ * ws needs dl_project_bwd_workspace_bytes(...) bytes (the masked hidden gradient [N][K][nhid] plus the
+ * per-node-range partial slabs).  Sums over nodes are taken range by range in a fixed order (no float
+ * atomics): the gradients are bitwise reproducible. */
+size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer);
+int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d,
+                   const float* W1, const float* b1, const float* W2, const float* dZ,
+                   float* dW1, float* db1, float* dW2, float* db2,
+                   void* ws, size_t ws_bytes, void* stream);
 
 /* Routing: replaces model.py:56-72 restricted to adj==1 entries.
  *   per edge e=(i,j):  sigma_k = z_k[i].z_k[j] / t ; e_k = exp(sigma_k) ; alpha_k = e_k / sum_k e_k

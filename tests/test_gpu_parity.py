@@ -461,6 +461,75 @@ def test_mfma_projection_matches_cpu_mlp(N, F, K, nhid, d):
         assert float((pg.grad.cpu() - pr.grad).abs().max()) <= 1e-4 * s, name
 
 
+@pytest.mark.parametrize("N,F,K,nhid,d", [(5201, 128, 8, 512, 64), (1000, 50, 3, 40, 32), (257, 70, 2, 33, 128),
+                                           (700, 128, 4, 1, 64), (4100, 300, 5, 64, 32), (90, 1433, 2, 1, 128),
+                                           (2000, 129, 2, 100, 64)])
+def test_projection_backward_kernels(N, F, K, nhid, d):
+    """dl_project_bwd (recomputed hidden layer, node-range slabs) against an fp64 restatement of the MLP
+    gradients (autograd of model.py:13-15 / 24-27): error relative to each gradient's largest entry within
+    fp32 summation noise, no worse than the fp32 library form, and bitwise reproducible."""
+    from disenlink_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + F)
+    two = nhid > 1
+    dZ = torch.randn(N, K, d, generator=g)
+    if two:
+        # layer 1 on small dyadic values: its sums are exact in fp32 in any order, so the ReLU mask cannot differ
+        # from the fp64 one through rounding of a pre-activation next to zero
+        x = torch.randint(-2, 3, (N, F), generator=g).float()
+        W1 = torch.randint(-8, 9, (K, nhid, F), generator=g).float() / 64
+        b1 = torch.randint(-8, 9, (K, nhid), generator=g).float() / 64
+        W2 = torch.randn(K, d, nhid, generator=g) / nhid ** 0.5
+    else:
+        x = torch.randn(N, F, generator=g)
+        W1, b1, W2 = torch.randn(K, d, F, generator=g) / F ** 0.5, torch.randn(K, d, generator=g), None
+
+    def grads64():
+        X, G = x.double(), dZ.double()
+        if not two:
+            return torch.einsum("nkd,nf->kdf", G, X), G.sum(0), None, None
+        pre = torch.einsum("nf,khf->nkh", X, W1.double()) + b1.double()
+        hid = pre.clamp_min(0)
+        dh = torch.einsum("nkd,kdh->nkh", G, W2.double()) * (pre > 0)
+        return torch.einsum("nkh,nf->khf", dh, X), dh.sum(0), torch.einsum("nkd,nkh->kdh", G, hid), G.sum(0)
+
+    dev = [None if v is None else v.to(DEV) for v in (x, W1, b1, W2, dZ)]
+    ref = grads64()
+    for pad in (True, False):                  # False: rows of odd length go through the scalar-load kernels
+        out = ops.project_bwd(*dev, pad=pad)
+        again = ops.project_bwd(*dev, pad=pad)
+        for name, got, rep, want in zip(("dW1", "db1", "dW2", "db2"), out, again, ref):
+            if want is None:
+                assert got is None
+                continue
+            assert got.shape == want.shape, name
+            assert torch.equal(got, rep), name + " not reproducible"
+            scale = float(want.abs().max())
+            err = float((got.cpu().double() - want).abs().max())
+            assert err <= 2e-5 * scale, (name, pad, err, scale)
+    if two:                                    # forward, both load paths, against fp64
+        Zref = torch.einsum("nkh,kdh->nkd", (torch.einsum("nf,khf->nkh", x.double(), W1.double()) + b1.double()).clamp_min(0),
+                            W2.double())
+        for pad in (True, False):
+            Z = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], torch.zeros(K, d, device=DEV), pad=pad)
+            assert float((Z.cpu().double() - Zref).abs().max()) <= 2e-5 * float(Zref.abs().max())
+
+
+def test_projection_backward_rejects_bad_arguments():
+    from disenlink_amd import _lib, ops
+    x, dZ = torch.randn(10, 8, device=DEV), torch.randn(10, 2, 32, device=DEV)
+    W1, b1 = torch.randn(2, 32, 8, device=DEV), torch.randn(2, 32, device=DEV)
+    with pytest.raises(ValueError):
+        ops.project_bwd(x, W1, b1, None, dZ[:, :1])
+    lib = _lib.load()
+    out = torch.empty_like(W1)
+    rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 32, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(),
+                            out.data_ptr(), b1.data_ptr(), None, None, None, 0, None)
+    assert rc != 0 and b"workspace" in lib.dl_last_error()
+    rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 48, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(),
+                            out.data_ptr(), b1.data_ptr(), None, None, None, 0, None)
+    assert rc != 0 and b"32, 64, 128" in lib.dl_last_error()
+
+
 def test_cli_runs_the_reference_flag_set():
     """`python -m disenlink_amd.main` with the flag names of main_disentangled.py:21-50 (incl. a stray token,
     which parse_known_args ignores like the reference's chameleon recipe) on a synthetic stand-in."""

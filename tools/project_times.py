@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from disenlink_amd import ops
 
-for (N, F, K, nhid, d) in [(5201, 128, 8, 512, 64), (2277, 128, 8, 512, 64), (41554, 128, 16, 256, 128), (5201, 2089, 8, 512, 64)]:
+for (N, F, K, nhid, d) in [(5201, 128, 8, 512, 64), (2277, 128, 8, 512, 64), (41554, 128, 16, 256, 128), (5201, 2089, 8, 512, 64), (5201, 2088, 8, 512, 64), (2277, 2325, 5, 512, 32), (41554, 4814, 16, 512, 128)]:
     torch.manual_seed(0)
     x = torch.randn(N, F, device="cuda")
     W1 = torch.randn(K, nhid, F, device="cuda") / F ** 0.5
