@@ -73,20 +73,22 @@ __device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
 }
 
 // Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D].
-// VEC: F % 4 == 0 and nhid % 4 == 0.  grid = (node tiles of 128, K, G hidden-chunk groups).
+// VEC: F % 4 == 0 and nhid % 4 == 0.  1-D grid of xcd_grid(node tiles of 128, K * G hidden-chunk groups).
 // out: Z [N][K][D] with b2 != nullptr (G == 1), or slab [G][N][K][D] of partial sums with b2 == nullptr.
 template <int D, bool VEC>
 __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ b2,
-                                                            float* __restrict__ out, int K, int chunks_per_group) {
+                                                            float* __restrict__ out, int K, int G, int chunks_per_group) {
     constexpr int DT = D / 32;
     constexpr int FC = fwd_fc(D), LDT = FC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                               // [2][TN][LDT]
     float* w1s = xs + 2 * TN * LDT;                // [2][TH][LDT]
-    const int k = blockIdx.y, grp = blockIdx.z;
-    const int n0 = blockIdx.x * TN;
+    const XcdItem item = xcd_item(blockIdx.x, (N + TN - 1) / TN, K * G);
+    if (!item.valid) return;
+    const int k = item.b % K, grp = item.b / K;
+    const int n0 = item.a * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
     const int wn = wave >> 1, wh = wave & 1;
@@ -341,9 +343,9 @@ static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float*
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)project2_lds(D));
         attr_done = true;
     }
-    const dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)K, (unsigned)G);
+    const dim3 grid((unsigned)xcd_grid((N + TN - 1) / TN, K * G));
     hipLaunchKernelGGL((project2_fwd_kernel<D, VEC>), grid, dim3(NTHR), project2_lds(D), st, x, N, F, nhid, W1, b1, W2, b2,
-                       out, K, cpg);
+                       out, K, G, cpg);
 }
 
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,

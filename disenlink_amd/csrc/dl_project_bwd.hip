@@ -33,7 +33,7 @@ constexpr int BTHR = 512;
 constexpr int bwd_ht(int D) { return D <= 64 ? 2 : 1; }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A.  grid = (hidden chunks of 64*HT, K, S node ranges); one workgroup = 8 waves = 128 nodes per
+// Kernel A.  1-D grid of xcd_grid(S node ranges, hidden chunks of 64*HT x K); one workgroup = 8 waves = 128 nodes per
 // node tile: node quarter wn (32 nodes) x hidden half wh (32*HT units).  Same write-after-barrier staging
 // pipeline as the forward kernel (dl_project.hip).  Per node tile, once the layer-1 sum over F is complete:
 //   hid  = relu(acc + b1)                       [node][hidden]: node rows in registers, hidden on lanes
@@ -52,11 +52,15 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     float* w1s = xs + 2 * TILE_N * LDB;            // [2][HB][LDB]
     float* dzs = w1s + 2 * HB * LDB;               // [TILE_N][LDZ]   dZ_k rows of the current node tile
     float* w2t = dzs + TILE_N * LDZ;               // [HB][LDZ]       W2_k[:, chunk]^T, staged once
-    const int hc = blockIdx.x, k = blockIdx.y, rng = blockIdx.z;
+    const int n_tiles = (N + TILE_N - 1) / TILE_N;
+    const int nhc = (nhid + HB - 1) / HB;
+    // a = node range (shares the x tiles), b = (hidden chunk, factor) (shares the W1 chunk): see xcd_item
+    const XcdItem item = xcd_item(blockIdx.x, (n_tiles + tiles_per_range - 1) / tiles_per_range, nhc * K);
+    if (!item.valid) return;
+    const int hc = item.b % nhc, k = item.b / nhc, rng = item.a;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
     const int wn = wave >> 1, wh = wave & 1;
-    const int n_tiles = (N + TILE_N - 1) / TILE_N;
     const int tile0 = rng * tiles_per_range;
     const int my_tiles = max(0, min(tiles_per_range, n_tiles - tile0));
     const float* W1k = W1 + (size_t)k * nhid * F;
@@ -252,7 +256,7 @@ constexpr size_t project2_bwd_lds(int D) {
 // ------------------------------------------------------------------------------------------------
 // Kernel B.  C[k][m][f] (+slab) = sum over the nodes of one range of  Y[n][k][m] * X[n][f]
 //   Y row n at Y + n*ldY + k*M (M columns), X [N][F] row-major.  Output slab [K][M][F].
-// grid = (f tiles of 128, m tiles of 128, K * S); 4 waves as 2 x 2, each 64 m x 64 f (4 accumulators),
+// 1-D grid of xcd_grid(S node ranges x f tiles of 128, m tiles of 128 x K); 4 waves as 2 x 2, each 64 m x 64 f (4 accumulators),
 // two workgroups per CU.  Node chunk of 32 per step; MFMA step q contracts the node pair {base(q), base(q)+8}:
 // with a row pitch of 132 floats the two halves of a wavefront read banks 32 apart -> conflict-free ds_read_b32.
 constexpr int CT = 128, NC = 32, LDC = CT + 4;
@@ -264,12 +268,16 @@ __global__ __launch_bounds__(256, 2) void nodes_contract_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ys = lds;                    // [2][NC][LDC]
     float* xs = ys + 2 * NC * LDC;      // [2][NC][LDC]
-    const int f0 = blockIdx.x * CT, m0 = blockIdx.y * CT;
-    const int k = blockIdx.z % K, rng = blockIdx.z / K;
+    const int n_chunks = (N + NC - 1) / NC;
+    const int nf = (F + CT - 1) / CT, nm = (M + CT - 1) / CT;
+    // a = (node range, f tile): shares the X tile (and, over adjacent f tiles, the Y tile); b = (m tile, factor)
+    const XcdItem item = xcd_item(blockIdx.x, ((n_chunks + chunks_per_range - 1) / chunks_per_range) * nf, nm * K);
+    if (!item.valid) return;
+    const int f0 = (item.a % nf) * CT, rng = item.a / nf;
+    const int m0 = (item.b % nm) * CT, k = item.b / nm;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wf = wave & 1;
-    const int n_chunks = (N + NC - 1) / NC;
     const int chunk0 = rng * chunks_per_range;
     const int my_chunks = max(0, min(chunks_per_range, n_chunks - chunk0));
     const float* Yk = Y + (size_t)k * M + m0;
@@ -443,7 +451,7 @@ int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const floa
     const float* Y = dZ;
     int ldY = K * d;
     if (two) {
-        const dim3 grid((unsigned)ceil_div(nhid, 64 * bwd_ht(d)), (unsigned)K, (unsigned)L.sA);
+        const dim3 grid((unsigned)xcd_grid(L.sA, ceil_div(nhid, 64 * bwd_ht(d)) * K));
 #define DL_PA(DD)                                                                                               \
     if (d == DD) {                                                                                              \
         if (vecA) launchA_t<DD, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p);  \
@@ -466,7 +474,7 @@ int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const floa
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
-        const dim3 grid((unsigned)ceil_div(F, CT), (unsigned)ceil_div(L.Mb, CT), (unsigned)(K * L.sB));
+        const dim3 grid((unsigned)xcd_grid(L.sB * ceil_div(F, CT), ceil_div(L.Mb, CT) * K));
         float* out = L.sB > 1 ? w1p : dW1;
         if (vecB) hipLaunchKernelGGL(nodes_contract_kernel<true>, grid, dim3(256), lds, st, Y, ldY, L.Mb, x, F, N, K,
                                     L.chunks_per_range, out);

@@ -24,6 +24,28 @@ __device__ __forceinline__ float mask_bits(float x, unsigned m) { return __uint_
 
 #define DL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
 
+// XCD-aware work assignment for a 1-D grid whose work items form an (n_a x n_b) rectangle — a = node tile,
+// b = weight chunk.  Workgroup h runs on XCD h % 8 (round-robin dispatch), and each XCD has its own L2: so
+// the 32 workgroups an XCD starts together should share operands.  The items are put in a blocked order
+// (blocks of 4 a-values x 8 b-values, edge blocks smaller: 12 distinct operand tiles per 32 items instead of
+// up to 64) and dealt to the XCDs in runs of 32 consecutive items, so every XCD gets the same amount of work.
+// Workgroups past the last item return at once.  grid = xcd_grid(n_a, n_b).
+struct XcdItem { int a, b; bool valid; };
+__host__ __device__ inline int xcd_grid(int n_a, int n_b) { return (n_a * n_b + 255) / 256 * 256; }
+__device__ __forceinline__ XcdItem xcd_item(int h, int n_a, int n_b) {
+    const int xcd = h & 7, j = h >> 3;
+    const int i = (j >> 5) * 256 + xcd * 32 + (j & 31);         // position in the blocked order
+    XcdItem it;
+    it.valid = i < n_a * n_b;
+    const int bg = i / (n_a * 8), r = i - bg * n_a * 8;
+    const int bw = min(8, n_b - bg * 8);                        // width of this b block (>= 1 while valid)
+    const int ag = r / (4 * max(bw, 1)), r2 = r - ag * 4 * bw;
+    const int aw = max(1, min(4, n_a - ag * 4));
+    it.a = ag * 4 + r2 % aw;
+    it.b = bg * 8 + r2 / aw;
+    return it;
+}
+
 // A [ROWS][COLS] tile of a row-major matrix (row stride ld floats) on its way global -> registers -> LDS
 // (row pitch PITCH floats), split so that the global loads can be issued before a long MFMA chain and the
 // LDS stores after it.  `origin` points at the tile's first element (always a valid element);

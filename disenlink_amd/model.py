@@ -47,8 +47,11 @@ class Disentangle(nn.Module):
         """Extensions (the reference has neither):
         ``table_dtype``: storage type of the gathered Z / H tables in ``forward_pairs`` — torch.float32
         (reference precision) or torch.bfloat16 (half the gather bytes, fp32 arithmetic and gradients).
-        ``projection``: "mfma" = the fused fp32 MFMA kernel of libdisenlink_hip.so, "library" = two library
-        GEMMs (rocBLAS through torch), "auto" = the kernel where it measured faster (d == 128, F <= 128)."""
+        ``projection``: "mfma" = the fused fp32 MFMA kernels of libdisenlink_hip.so (forward and backward; the hidden
+        layer never reaches HBM and is recomputed in the backward), "library" = library GEMMs (rocBLAS through torch,
+        hidden layer kept for the backward), "auto" = the kernels where the epoch measured faster with them: narrow
+        features (F <= 256), where fusing bias/ReLU/layer 2 outweighs recomputing layer 1; for wide features layer 1
+        is one big plain GEMM and goes to the library (tools/epoch_time.py)."""
         super().__init__()
         if projection not in ("auto", "mfma", "library"):
             raise ValueError("projection must be 'auto', 'mfma' or 'library'")
@@ -128,14 +131,14 @@ class Disentangle(nn.Module):
 
     # ------------------------------------------------------------------ projection (model.py:106)
     def project(self, x: torch.Tensor) -> torch.Tensor:
-        """Z [N,K,d] = K independent MLPs of x.  On the GPU (d in {32,64,128}): the fused MFMA kernel of
-        libdisenlink_hip.so.  Otherwise (CPU tests of the host logic, odd d): one wide library GEMM + one
-        K-batched GEMM — plain torch plumbing, the reference's own ops."""
+        """Z [N,K,d] = K independent MLPs of x.  On the GPU (d in {32,64,128}, see ``projection``): the fused MFMA
+        kernels of libdisenlink_hip.so.  Otherwise (wide features, CPU tests of the host logic, odd d): one wide
+        library GEMM + one K-batched GEMM — plain torch plumbing, the reference's own ops."""
         fs = self.factors
         K, d = self.nfactor, self.nebed
         use_kernel = x.is_cuda and x.dtype == torch.float32 and self.projection != "library" and ops.project_supported(d)
         if use_kernel and self.projection == "auto":
-            use_kernel = d == 128 and x.shape[1] <= 128         # measured: tools/project_times.py, DESIGN.md §3
+            use_kernel = x.shape[1] <= 256                      # measured: tools/epoch_time.py, DESIGN.md §3
         if use_kernel:
             flat = self._stacked_params()
             if flat is not None:                                # zero-copy: the kernel reads the shared buffers

@@ -81,11 +81,11 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_train, weight_train
         for p in model.parameters():
             p.grad = torch.zeros_like(p)
         snap = model.snapshot_state() if hasattr(model, "snapshot_state") else deepcopy(model.state_dict())
-        opt_state = deepcopy(opt.state_dict())
         for _ in range(2):
             epoch()
         model.load_state_dict(snap)                                 # warm-up must not train
-        opt.load_state_dict(opt_state)
+        # Adam's moments and step counters were created by the warm-up steps and must stay the SAME tensors for
+        # the capture (state created inside the capture would be re-initialised by every replay): reset in place
         for st in opt.state.values():
             for v in st.values():
                 if torch.is_tensor(v):

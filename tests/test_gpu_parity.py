@@ -184,7 +184,10 @@ def test_forward_and_backward_match_oracle_on_random_graphs(K, d, N, deg, force_
         assert np.abs(dZs.cpu().numpy() - dZs_o).max() <= tol(dZs_o)
         # the stored-terms backward (tuned path only): per-factor logit terms from the forward
         prob_c, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
-        assert torch.equal(prob_c, prob)
+        if K <= 8:
+            assert torch.equal(prob_c, prob)
+        else:           # factor-blocked kernels: the two instantiations may contract their FMAs differently
+            assert torch.allclose(prob_c, prob, rtol=2e-6, atol=1e-7)
         if coef is not None:
             _pr, q_o, e_o = sparse_ref.score_pairs(Zh, H_o, pu, pv, t, return_parts=True)
             np.testing.assert_allclose(coef[0].cpu().numpy(), e_o, rtol=1e-5)
@@ -528,6 +531,27 @@ def test_projection_backward_rejects_bad_arguments():
     rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 48, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(),
                             out.data_ptr(), b1.data_ptr(), None, None, None, 0, None)
     assert rc != 0 and b"32, 64, 128" in lib.dl_last_error()
+
+
+def test_graph_replayed_epochs_follow_the_eager_trajectory():
+    """use_graph=True replays the epoch (forward, fused loss, backward, Adam, AUC) from a captured HIP graph: the
+    loss / AUC sequence must follow the eager loop's (Adam's moments and step counter live across replays)."""
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sg = synthetic_graph("cora", seed=3)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=3)
+    run = prepare_run(split, torch.device(DEV))
+    x = torch.from_numpy(sg.features()).to(DEV)
+    out = {}
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        model = Disentangle(sg.n_feat, 64, 32, nfactor=4, beta=0.6, t=1).to(DEV)
+        out[use_graph] = run_link_prediction(model, x, run, epochs=10, lr=1e-3, use_graph=use_graph)
+    np.testing.assert_allclose(out[True].losses, out[False].losses, rtol=2e-3)
+    np.testing.assert_allclose(out[True].val_aucs, out[False].val_aucs, atol=2e-3)
+    assert abs(out[True].test_auc - out[False].test_auc) <= 2e-3
 
 
 def test_cli_runs_the_reference_flag_set():
