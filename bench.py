@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 256 FLOP/clk/CU x 256 CUs x 2.4 GHz
 # kernel behind each timed phase (the name rocprofv3 reports) -> PMC summary of tools/pmc_traffic.py
 PHASE_KERNEL = {"route": "dl::fast::route_seg_kernel<8, 64, float>",
                 "aggregate": "dl::fast::aggregate_seg_kernel<8, 64, float>",
@@ -241,6 +242,34 @@ def main():
     torch.cuda.synchronize()
     fb_ms = (time.perf_counter() - t0) / nb * 1e3
 
+    # extra: the projection (excluded from the headline) — the path's only MFMA-bound kernels.
+    # fp32 in / fp32 accumulate: priced against the fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU).
+    proj = None
+    if ops.project_supported(d) and not model.single_layer:
+        st = model._stacked
+        W1, b1 = st[("mlp1", "weight")], st[("mlp1", "bias")]
+        W2, b2 = st[("mlp2", "weight")], st[("mlp2", "bias")]
+        gZ = torch.randn(N, K, d, device=device)
+        def ev_time(fn, reps=10):
+            for _ in range(2):
+                fn()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            e[0].record()
+            for i in range(reps):
+                fn()
+                e[i + 1].record()
+            torch.cuda.synchronize()
+            return float(np.mean([e[i].elapsed_time(e[i + 1]) for i in range(reps)])) * 1e-3
+        Fx, nh = x.shape[1], W1.shape[1]
+        t_f = ev_time(lambda: ops.project_fwd(x, W1, b1, W2, b2))
+        t_b = ev_time(lambda: ops.project_bwd(x, W1, b1, W2, gZ))
+        fl_f = 2.0 * N * K * nh * (Fx + d)
+        fl_b = 2.0 * N * K * nh * (2 * Fx + 2 * d)              # recomputed layer 1, dW1, dhid, dW2
+        proj = {"bound": "mfma", "dtype": "f32", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "shape": {"N": N, "F": Fx, "K": K, "nhid": nh, "d": d},
+                "fwd": {"avg_us": t_f * 1e6, "achieved": fl_f / t_f / 1e12, "frac": fl_f / t_f / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+                "bwd": {"avg_us": t_b * 1e6, "achieved": fl_b / t_b / 1e12, "frac": fl_b / t_b / 1e12 / FP32_MFMA_PEAK_TFLOPS}}
+
     units = E + P
     result = {
         "metric": "edges/sec (aggregate+score) at K=8 d=64",
@@ -267,6 +296,7 @@ def main():
                          "edges_per_s": E / scatter_t},
         "kernels": kernels,
         "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},
+        "projection": proj,
     }
     if not args.no_cpu_baseline:
         gcpu = graph.to("cpu")
