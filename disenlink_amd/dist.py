@@ -56,13 +56,12 @@ def pair_slices(pu_sorted: np.ndarray, n_nodes: int, world: int):
     return cuts
 
 
-def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None) -> None:
-    """In place: every rank contributes rows [lo, hi) of `full` (equal sizes on all ranks)."""
-    local = full[lo:hi]
-    if full.is_cuda:
-        dist.all_gather_into_tensor(full, local, group=group)        # RCCL, in place
-    else:
-        dist.all_gather_into_tensor(full, local.clone(), group=group)  # gloo: no aliasing
+def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None, src: torch.Tensor | None = None) -> None:
+    """Every rank contributes rows [lo, hi) of `full` (equal sizes on all ranks) and receives all rows.  The
+    send buffer never aliases the receive buffer: `src` if the caller still holds the local rows elsewhere,
+    else a copy of full[lo:hi] (a few microseconds against a collective of 8x the bytes)."""
+    local = src if src is not None else full[lo:hi].clone()
+    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
 
 
 # --------------------------------------------------------------------------- backends
@@ -164,8 +163,7 @@ class ShardedHotPath(torch.autograd.Function):
         K, d = Z_loc.shape[1], Z_loc.shape[2]
         dev = Z_loc.device
         Z = torch.empty((sh.n_pad, K, d), dtype=torch.float32, device=dev)
-        Z[sh.lo:sh.hi] = Z_loc
-        all_gather_rows(Z, sh.lo, sh.hi, group)
+        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().float())
         s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
         p, a = backend.route_fwd(sh.graph, Z, t, s)
         all_gather_rows(s, sh.lo, sh.hi, group)
@@ -261,8 +259,7 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     H = torch.empty_like(Z)
 
     def step():
-        Z[shard.lo:shard.hi] = Z_loc
-        all_gather_rows(Z, shard.lo, shard.hi)
+        all_gather_rows(Z, shard.lo, shard.hi, src=Z_loc)
         p, a = backend.route_fwd(shard.graph, Z, t, s)
         all_gather_rows(s, shard.lo, shard.hi)
         backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
@@ -284,12 +281,36 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     E, P = int(counts[0]), int(counts[1])
     wall_s = float(wall[0])
+    # roofline of the dominant kernel on THIS rank's shard: HIP events on the launch stream, kernels only
+    # (the collectives are left out of this loop; every rank runs it so nobody waits at the teardown barrier)
+    reps = max(5, min(args.steps, 50))
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    for i in range(reps):
+        ev[i][0].record()
+        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        ev[i][1].record()
+        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+        ev[i][2].record()
+        backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        ev[i][3].record()
+    torch.cuda.synchronize()
+    kt = [float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(reps)])) * 1e-3 for j in range(3)]
+    e_loc, p_loc, rows = shard.graph.n_edges, shard.pairs.n_pairs, shard.hi - shard.lo
+    kb = [e_loc * (K * d * 4 + 9) + rows * (K * d * 4 + K * 4 + 4),            # SURVEY.md §8(d), as bench.algorithmic_bytes
+          e_loc * (d * 4 + 13) + rows * (2 * K * d * 4 + K * 4 + 4),
+          p_loc * (4 * K * d * 4 + 12)]
+    j = int(np.argmax(kt))
+    roofline = {"bound": "hbm", "kernel": ("route", "aggregate", "score")[j], "achieved": kb[j] / kt[j] / 1e9,
+                "peak": 8000.0, "unit": "GB/s", "frac": kb[j] / kt[j] / 1e9 / 8000.0, "traffic": None,
+                "algorithmic_bytes": kb[j], "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
+    dist.barrier()
     return {
         "metric": "edges/sec (aggregate+score) at K=8 d=64",
         "value": (E + P) * args.steps / wall_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall_s / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "roofline": roofline,
         "config": {"workload": f"{args.workload}-synthetic x{world} (seed 0): N={sg.n_nodes}, edge rows={sg.src.size}, "
                                f"85/5/10 split, E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}; row-sharded over "
                                f"{world} GPUs, all-gather of Z, s and H over RCCL each step; forward route+aggregate+score",
