@@ -339,8 +339,8 @@ static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float*
     using namespace project;
     static bool attr_done = false;                         // > 64 KiB of dynamic LDS needs the attribute once
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)project2_lds(D));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)project2_lds(D));
         attr_done = true;
     }
     const dim3 grid((unsigned)xcd_grid((N + TN - 1) / TN, K * G));

@@ -17,6 +17,7 @@
 // (node = row), so both can be fed back unchanged as the B operand of products that contract over the
 // node index — dW2 += dZ^T . hid takes hid straight from the accumulator registers.
 #include <algorithm>
+#include <cstdlib>
 #include "dl_common.h"
 #include "dl_kernels.h"
 #include "dl_tiles.h"
@@ -336,12 +337,12 @@ __global__ __launch_bounds__(256, 2) void nodes_contract_kernel(const float* __r
         }
 }
 
-// out[i] = sum_s slabs[s][i], s ascending (fixed order).
+// out[i] (+)= sum_s slabs[s][i], s ascending (fixed order); accumulate: on top of what out holds (node blocks).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int S, size_t n,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int accumulate) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float v = 0.0f;
+    float v = accumulate ? out[i] : 0.0f;
     for (int s = 0; s < S; ++s) v += slabs[(size_t)s * n + i];
     out[i] = v;
 }
@@ -372,7 +373,19 @@ struct BwdLayout {
 
 static int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer) {
+// Node block of the two-layer backward: the masked hidden gradient of one block ([rows][K][nhid] fp32) is capped
+// at 1 GiB, so the workspace does not grow with the graph (2.9M nodes x K=8 x 512 would be 48 GB); the blocks
+// are processed in order and accumulate into the gradients.
+static int bwd_block_rows(int N, int K, int nhid, bool two_layer) {
+    if (!two_layer) return N;
+    long long cap_bytes = 1LL << 30;
+    if (const char* e = getenv("DL_BWD_BLOCK_BYTES")) cap_bytes = std::max(1LL, atoll(e));   // tests: force blocking
+    const long long cap = cap_bytes / ((long long)K * nhid * 4);
+    const long long rows = std::max<long long>(4096, cap / TILE_N * TILE_N);
+    return (int)std::min<long long>(N, rows);
+}
+
+static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer, bool blocked = false) {
     BwdLayout L{};
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const int target = 768;                                    // workgroups wanted per launch (256 CUs x 3)
@@ -392,7 +405,7 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
     L.sC = ceil_div(N, L.rows_per_range);
     size_t off = 0;
     L.off_dhid = off; off += two_layer ? al(sizeof(float) * (size_t)N * K * nhid) : 0;
-    L.off_w1p = off;  off += L.sB > 1 ? al(sizeof(float) * (size_t)L.sB * K * L.Mb * F) : 0;
+    L.off_w1p = off;  off += (L.sB > 1 || blocked) ? al(sizeof(float) * (size_t)L.sB * K * L.Mb * F) : 0;
     L.off_w2p = off;  off += two_layer ? al(sizeof(float) * (size_t)L.sA * K * d * nhid) : 0;
     L.off_b1p = off;  off += two_layer ? al(sizeof(float) * (size_t)L.sA * K * nhid) : 0;
     L.off_b2p = off;  off += al(sizeof(float) * (size_t)L.sC * K * d);
@@ -404,7 +417,12 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
 
 size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer) {
     if (N <= 0) return 0;
-    return project::bwd_layout(N, F, K, nhid, d, two_layer).bytes;
+    using namespace project;
+    const int R = bwd_block_rows(N, K, nhid, two_layer);
+    const bool blocked = R < N;
+    size_t bytes = bwd_layout(R, F, K, nhid, d, two_layer, blocked).bytes;
+    if (blocked && N % R != 0) bytes = std::max(bytes, bwd_layout(N % R, F, K, nhid, d, two_layer, true).bytes);
+    return bytes;
 }
 
 template <int D, bool VEC>
@@ -415,24 +433,26 @@ static void launchA_t(dim3 grid, hipStream_t st, const float* x, int N, int F, i
     static bool attr_done = false;
     constexpr size_t lds = project2_bwd_lds(D);
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1, b1, W2, dZ,
                        K, tpr, dhid, dW2p, db1p);
 }
 
-static void slab_sum(const float* slabs, int S, size_t n, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(project::slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, S, n, out);
+static void slab_sum(const float* slabs, int S, size_t n, float* out, bool accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(project::slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, S, n, out,
+                       accumulate ? 1 : 0);
 }
 
-int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
-                hipStream_t st) {
+// One node block [row0, row0 + N) of the backward; acc: add to the gradients instead of overwriting them.
+static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                              const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2,
+                              void* ws, bool blocked, bool acc, hipStream_t st) {
     using namespace project;
     const bool two = W2 != nullptr;
-    const BwdLayout L = bwd_layout(N, F, K, nhid, d, two);
+    const BwdLayout L = bwd_layout(N, F, K, nhid, d, two, blocked);
     char* base = static_cast<char*>(ws);
     float* dhid = reinterpret_cast<float*>(base + L.off_dhid);
     float* w1p = reinterpret_cast<float*>(base + L.off_w1p);
@@ -446,7 +466,7 @@ int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const floa
     float* dbo = two ? db2 : db1;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div((long long)K * d, 64), (unsigned)L.sC), dim3(256), 0, st,
                        dZ, N, K * d, L.rows_per_range, b2p);
-    slab_sum(b2p, L.sC, (size_t)K * d, dbo, st);
+    slab_sum(b2p, L.sC, (size_t)K * d, dbo, acc, st);
 
     const float* Y = dZ;
     int ldY = K * d;
@@ -459,8 +479,8 @@ int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const floa
     }
         DL_PA(32) DL_PA(64) DL_PA(128)
 #undef DL_PA
-        slab_sum(w2p, L.sA, (size_t)K * d * nhid, dW2, st);
-        slab_sum(b1p, L.sA, (size_t)K * nhid, db1, st);
+        slab_sum(w2p, L.sA, (size_t)K * d * nhid, dW2, acc, st);
+        slab_sum(b1p, L.sA, (size_t)K * nhid, db1, acc, st);
         Y = dhid;
         ldY = K * nhid;
     }
@@ -468,20 +488,32 @@ int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         static bool attr_done = false;
         const size_t lds = sizeof(float) * 4 * NC * LDC;
         if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
         const dim3 grid((unsigned)xcd_grid(L.sB * ceil_div(F, CT), ceil_div(L.Mb, CT) * K));
-        float* out = L.sB > 1 ? w1p : dW1;
+        const bool direct = L.sB == 1 && !blocked;                  // one range, one block: straight into dW1
+        float* out = direct ? dW1 : w1p;
         if (vecB) hipLaunchKernelGGL(nodes_contract_kernel<true>, grid, dim3(256), lds, st, Y, ldY, L.Mb, x, F, N, K,
                                     L.chunks_per_range, out);
         else hipLaunchKernelGGL(nodes_contract_kernel<false>, grid, dim3(256), lds, st, Y, ldY, L.Mb, x, F, N, K,
                                 L.chunks_per_range, out);
-        if (L.sB > 1) slab_sum(w1p, L.sB, (size_t)K * L.Mb * F, dW1, st);
+        if (!direct) slab_sum(w1p, L.sB, (size_t)K * L.Mb * F, dW1, acc, st);
     }
+}
+
+int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
+                hipStream_t st) {
+    const bool two = W2 != nullptr;
+    const int R = project::bwd_block_rows(N, K, nhid, two);
+    const bool blocked = R < N;
+    for (int row0 = 0; row0 < N; row0 += R)
+        project_bwd_block(x + (size_t)row0 * F, std::min(R, N - row0), F, K, nhid, d, W1, b1, W2,
+                          dZ + (size_t)row0 * K * d, dW1, db1, dW2, db2, ws, blocked, row0 > 0, st);
     return check_launch("project_bwd");
 }
 

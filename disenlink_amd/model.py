@@ -51,7 +51,8 @@ class Disentangle(nn.Module):
         layer never reaches HBM and is recomputed in the backward), "library" = library GEMMs (rocBLAS through torch,
         hidden layer kept for the backward), "auto" = the kernels where the epoch measured faster with them: narrow
         features (F <= 256), where fusing bias/ReLU/layer 2 outweighs recomputing layer 1; for wide features layer 1
-        is one big plain GEMM and goes to the library (tools/epoch_time.py)."""
+        is one big plain GEMM and goes to the library (tools/epoch_time.py) — unless its [N,K,nhid]
+        activations would run to several GB, which the kernels never store."""
         super().__init__()
         if projection not in ("auto", "mfma", "library"):
             raise ValueError("projection must be 'auto', 'mfma' or 'library'")
@@ -138,7 +139,10 @@ class Disentangle(nn.Module):
         K, d = self.nfactor, self.nebed
         use_kernel = x.is_cuda and x.dtype == torch.float32 and self.projection != "library" and ops.project_supported(d)
         if use_kernel and self.projection == "auto":
-            use_kernel = x.shape[1] <= 256                      # measured: tools/epoch_time.py, DESIGN.md §3
+            # measured: tools/epoch_time.py; past a few GB the library path's [N,K,nhid] activations
+            # (kept for its backward) are what decides: the kernels never materialise them
+            hidden_bytes = x.shape[0] * K * (1 if self.single_layer else fs[0].mlp1.out_features) * 4
+            use_kernel = x.shape[1] <= 256 or hidden_bytes > (4 << 30)
         if use_kernel:
             flat = self._stacked_params()
             if flat is not None:                                # zero-copy: the kernel reads the shared buffers

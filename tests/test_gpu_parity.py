@@ -517,6 +517,25 @@ def test_projection_backward_kernels(N, F, K, nhid, d):
             assert float((Z.cpu().double() - Zref).abs().max()) <= 2e-5 * float(Zref.abs().max())
 
 
+def test_projection_backward_in_node_blocks(monkeypatch):
+    """Graphs whose masked hidden gradient would exceed the workspace cap are processed in node blocks that
+    accumulate into the gradients (cap forced down here): same result as one block, up to summation order."""
+    from disenlink_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, F, K, nhid, d = 10000, 48, 2, 64, 32
+    x = torch.randint(-2, 3, (N, F), generator=g).float()
+    W1 = torch.randint(-8, 9, (K, nhid, F), generator=g).float() / 64
+    b1 = torch.randint(-8, 9, (K, nhid), generator=g).float() / 64
+    W2 = torch.randn(K, d, nhid, generator=g) / 8
+    dZ = torch.randn(N, K, d, generator=g)
+    dev = [v.to(DEV) for v in (x, W1, b1, W2, dZ)]
+    whole = ops.project_bwd(*dev)
+    monkeypatch.setenv("DL_BWD_BLOCK_BYTES", str(1 << 20))          # 4096-row blocks: 4096 + 4096 + 1808
+    blocks = ops.project_bwd(*dev)
+    for name, a, b in zip(("dW1", "db1", "dW2", "db2"), whole, blocks):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
+
+
 def test_projection_backward_rejects_bad_arguments():
     from disenlink_amd import _lib, ops
     x, dZ = torch.randn(10, 8, device=DEV), torch.randn(10, 2, 32, device=DEV)
