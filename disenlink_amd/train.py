@@ -10,6 +10,7 @@ the weights before the step, :202-204), best weights snapshotted after the step 
 """
 from __future__ import annotations
 
+import os
 from copy import deepcopy
 from dataclasses import dataclass, field
 
@@ -59,11 +60,14 @@ class RunResult:
     val_aucs: list = field(default_factory=list)
 
 
+_FUSED_ADAM = os.environ.get("DL_FUSED_ADAM", "1") != "0"
+
+
 def _graphed_epoch(model, x, run, lr, weight_decay, b, label_train, weight_train):
     """Capture one full epoch (forward, fused loss, backward, Adam step, validation AUC) into a HIP graph:
     every launch of the epoch — ours and torch's — is replayed with one host call, which removes the
     launch-bound host time of small graphs.  Returns (replay, out) with out = [loss, auc] on the device."""
-    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
+    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=_FUSED_ADAM)
     out = torch.zeros(2, dtype=torch.float64, device=x.device)
 
     def epoch():
@@ -108,7 +112,9 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
     schedule; only the host-side launch cost disappears)."""
     if use_graph and x.is_cuda:
         return _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log)
-    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+    # same update rule as the reference's Adam (main_disentangled.py:150); on the GPU torch's single-kernel
+    # ("fused") implementation of it instead of one multi-tensor launch per elementwise step
+    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=bool(x.is_cuda) and _FUSED_ADAM)
     snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
     best_auc, stale, weights = 0.0, 0, snapshot()
     res = RunResult(float("nan"), 0.0, 0)
