@@ -22,6 +22,7 @@
 // Small graphs: the hidden chunks are split over G workgroups per (node tile, k) whose partial Z go to
 // G slabs, added in slab order by z_slab_sum_kernel (no atomics; needs the workspace).
 #include <algorithm>
+#include <cstdlib>
 #include "dl_common.h"
 #include "dl_kernels.h"
 #include "dl_tiles.h"
@@ -317,13 +318,14 @@ __global__ __launch_bounds__(256) void project1_fwd_kernel(const float* __restri
 
 bool project_supported(int d) { return d == 32 || d == 64 || d == 128; }
 
-// Hidden-chunk groups per (node tile, factor): 1 when the grid already covers the 256 CUs a few times
-// over, else enough groups to get there (each group = whole 128-unit chunks).
+// Hidden-chunk groups per (node tile, factor): 1 when the grid already covers the 256 CUs twice over, else
+// enough groups to get there (each group = whole 128-unit chunks; measured at N=5,201: 2 groups beat 1 and 4).
 static int project2_groups(int N, int K, int nhid) {
     const long long wg = (long long)((N + project::TN - 1) / project::TN) * K;
     const int nhc = (nhid + project::TH - 1) / project::TH;
-    if (wg >= 768) return 1;
-    const int cpg = std::max(1, (int)(nhc / std::min<long long>(nhc, (768 + wg - 1) / wg)));
+    if (const char* e = getenv("DL_FWD_GROUPS")) return std::max(1, std::min(nhc, atoi(e)));     // tuning knob
+    if (wg >= 512) return 1;
+    const int cpg = std::max(1, (int)(nhc / std::min<long long>(nhc, (512 + wg - 1) / wg)));
     return (nhc + cpg - 1) / cpg;
 }
 
