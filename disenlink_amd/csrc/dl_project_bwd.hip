@@ -337,14 +337,21 @@ __global__ __launch_bounds__(256, 2) void nodes_contract_kernel(const float* __r
         }
 }
 
-// out[i] (+)= sum_s slabs[s][i], s ascending (fixed order); accumulate: on top of what out holds (node blocks).
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int S, size_t n,
-                                                       float* __restrict__ out, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float v = accumulate ? out[i] : 0.0f;
-    for (int s = 0; s < S; ++s) v += slabs[(size_t)s * n + i];
-    out[i] = v;
+// out[i] (+)= sum_s slabs[s][i], s ascending (fixed order), for up to 4 independent (slabs, out) jobs in one
+// launch (the four gradients of a backward); accumulate: on top of what out holds (node blocks).
+struct SlabJob { const float* slabs; float* out; size_t n; int S; unsigned block0; };
+struct SlabJobs { SlabJob j[4]; int count; };
+__global__ __launch_bounds__(256) void slab_sum_kernel(SlabJobs jobs, int accumulate) {
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < 4; ++t)
+        if (t < jobs.count && blockIdx.x >= jobs.j[t].block0) q = t;
+    const SlabJob job = jobs.j[q];
+    const size_t i = (size_t)(blockIdx.x - job.block0) * 256 + threadIdx.x;
+    if (i >= job.n) return;
+    float v = accumulate ? job.out[i] : 0.0f;
+    for (int s = 0; s < job.S; ++s) v += job.slabs[(size_t)s * job.n + i];
+    job.out[i] = v;
 }
 
 // Column sums of a row-major [N][C] matrix over S row ranges -> part[S][C].  Block = 64 columns x 4 row lanes.
@@ -441,10 +448,17 @@ static void launchA_t(dim3 grid, hipStream_t st, const float* x, int N, int F, i
                        K, tpr, dhid, dW2p, db1p);
 }
 
-static void slab_sum(const float* slabs, int S, size_t n, float* out, bool accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(project::slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, S, n, out,
-                       accumulate ? 1 : 0);
-}
+struct SlabBatch {
+    project::SlabJobs jobs{};
+    unsigned blocks = 0;
+    void add(const float* slabs, int S, size_t n, float* out) {
+        jobs.j[jobs.count++] = project::SlabJob{slabs, out, n, S, blocks};
+        blocks += (unsigned)((n + 255) / 256);
+    }
+    void run(bool accumulate, hipStream_t st) {
+        if (jobs.count) hipLaunchKernelGGL(project::slab_sum_kernel, dim3(blocks), dim3(256), 0, st, jobs, accumulate ? 1 : 0);
+    }
+};
 
 // One node block [row0, row0 + N) of the backward; acc: add to the gradients instead of overwriting them.
 static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
@@ -466,7 +480,8 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
     float* dbo = two ? db2 : db1;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div((long long)K * d, 64), (unsigned)L.sC), dim3(256), 0, st,
                        dZ, N, K * d, L.rows_per_range, b2p);
-    slab_sum(b2p, L.sC, (size_t)K * d, dbo, acc, st);
+    SlabBatch sums;                                                 // all slab sums of this block in one launch, at the end
+    sums.add(b2p, L.sC, (size_t)K * d, dbo);
 
     const float* Y = dZ;
     int ldY = K * d;
@@ -479,8 +494,8 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
     }
         DL_PA(32) DL_PA(64) DL_PA(128)
 #undef DL_PA
-        slab_sum(w2p, L.sA, (size_t)K * d * nhid, dW2, acc, st);
-        slab_sum(b1p, L.sA, (size_t)K * nhid, db1, acc, st);
+        sums.add(w2p, L.sA, (size_t)K * d * nhid, dW2);
+        sums.add(b1p, L.sA, (size_t)K * nhid, db1);
         Y = dhid;
         ldY = K * nhid;
     }
@@ -501,8 +516,9 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
                                     L.chunks_per_range, out);
         else hipLaunchKernelGGL(nodes_contract_kernel<false>, grid, dim3(256), lds, st, Y, ldY, L.Mb, x, F, N, K,
                                 L.chunks_per_range, out);
-        if (!direct) slab_sum(w1p, L.sB, (size_t)K * L.Mb * F, dW1, acc, st);
+        if (!direct) sums.add(w1p, L.sB, (size_t)K * L.Mb * F, dW1);
     }
+    sums.run(acc, st);
 }
 
 int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
