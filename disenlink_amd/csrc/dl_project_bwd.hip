@@ -395,19 +395,29 @@ static int bwd_block_rows(int N, int K, int nhid, bool two_layer) {
 static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer, bool blocked = false) {
     BwdLayout L{};
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const int target = 768;                                    // workgroups wanted per launch (256 CUs x 3)
+    // Node ranges per launch: enough workgroups to cover the 256 CUs (>= 256, at most ~1536 so the partial slabs
+    // stay small), but never so many that a workgroup runs fewer than ~24 pipeline steps — its prologue (W2^T
+    // staging, first tile) and the slab it writes are per-workgroup costs.  Measured (DL_BWD_TARGET sweeps):
+    // narrow features want few long ranges, wide features many short ones.
+    auto pick = [](int n_units, int steps_per_unit, long long wg_per_range, int min_steps) {
+        if (const char* e = getenv("DL_BWD_TARGET"))                       // tuning knob: workgroups per launch
+            return (int)std::max(1LL, std::min<long long>(n_units, ceil_div(std::max(1, atoi(e)), wg_per_range)));
+        const long long lo = ceil_div(256, wg_per_range), hi = ceil_div(1536, wg_per_range);
+        const long long by_steps = n_units / std::max(1, ceil_div(min_steps, steps_per_unit));
+        return (int)std::max(1LL, std::min<long long>(n_units, std::min(hi, std::max(lo, by_steps))));
+    };
     const int n_tiles = ceil_div(N, TILE_N), n_chunks = ceil_div(N, NC);
     L.Mb = two_layer ? nhid : d;
     const long long wgA = (long long)ceil_div(nhid, 64 * bwd_ht(d)) * K;
-    L.sA = (int)std::max(1LL, std::min<long long>(n_tiles, ceil_div(target, wgA)));
+    L.sA = pick(n_tiles, ceil_div(F, BFC), wgA, 24);
     L.tiles_per_range = ceil_div(n_tiles, L.sA);
     L.sA = ceil_div(n_tiles, L.tiles_per_range);
     const long long wgB = (long long)ceil_div(L.Mb, CT) * ceil_div(F, CT) * K;
-    L.sB = (int)std::max(1LL, std::min<long long>(n_chunks, ceil_div(target, wgB)));
+    L.sB = pick(n_chunks, 1, wgB, 20);
     L.chunks_per_range = ceil_div(n_chunks, L.sB);
     L.sB = ceil_div(n_chunks, L.chunks_per_range);
     const int colblocks = ceil_div((long long)K * d, 64);
-    L.sC = (int)std::max(1LL, std::min<long long>(ceil_div(N, 64), ceil_div(target, colblocks)));
+    L.sC = (int)std::max(1LL, std::min<long long>(ceil_div(N, 64), ceil_div(768, colblocks)));
     L.rows_per_range = ceil_div(N, L.sC);
     L.sC = ceil_div(N, L.rows_per_range);
     size_t off = 0;
