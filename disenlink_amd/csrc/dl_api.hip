@@ -154,12 +154,11 @@ int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d, const f
     if (N == 0) {                                              // no nodes: every gradient is zero
         hipStream_t st = (hipStream_t)stream;
         const size_t m = two ? (size_t)nhid : (size_t)d;
-        hipMemsetAsync(dW1, 0, sizeof(float) * K * m * F, st);
-        hipMemsetAsync(db1, 0, sizeof(float) * K * m, st);
-        if (two) {
-            hipMemsetAsync(dW2, 0, sizeof(float) * (size_t)K * d * nhid, st);
-            hipMemsetAsync(db2, 0, sizeof(float) * (size_t)K * d, st);
-        }
+        hipError_t e = hipMemsetAsync(dW1, 0, sizeof(float) * K * m * F, st);
+        if (e == hipSuccess) e = hipMemsetAsync(db1, 0, sizeof(float) * K * m, st);
+        if (two && e == hipSuccess) e = hipMemsetAsync(dW2, 0, sizeof(float) * (size_t)K * d * nhid, st);
+        if (two && e == hipSuccess) e = hipMemsetAsync(db2, 0, sizeof(float) * (size_t)K * d, st);
+        DL_REQUIRE(e == hipSuccess, "hipMemsetAsync: %s", hipGetErrorString(e));
         return DL_OK;
     }
     DL_REQUIRE(x && W1 && b1 && dZ, "NULL argument");

@@ -675,7 +675,6 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
-    const int kb = FL::factor_base(c);
     Chunk<VEC> accZ[K], accH[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { accZ[k] = zero_chunk<VEC>(); accH[k] = zero_chunk<VEC>(); }

@@ -48,6 +48,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--data-file", type=str, default=None, help="binary dataset written by datasets.save_binary")
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic stand-in of --dataset")
     p.add_argument("--table-dtype", choices=["f32", "bf16"], default="f32")
+    p.add_argument("--no-graph", action="store_true",
+                   help="launch every epoch from Python instead of replaying it from a captured HIP graph")
     p.add_argument("--quiet", action="store_true")
     return p
 
@@ -106,7 +108,7 @@ def main(argv=None):
         model = Disentangle(x.shape[1], args.nhidden, args.nembed, nfactor=args.nfactor, beta=args.beta,
                             t=args.temperature, table_dtype=tdt).to(device)
         res = run_link_prediction(model, x, prepared, epochs=args.epochs, lr=args.lr,
-                                  log=None if args.quiet else print)
+                                  log=None if args.quiet else print, use_graph=not args.no_graph)
         if not args.quiet:
             print("test auc:", res.test_auc)
         result.append(res.test_auc)
