@@ -306,6 +306,58 @@ def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic):
         _lib.load().dl_set_force_generic(old)
 
 
+def test_sharded_training_step_over_rccl_matches_the_unsharded_module():
+    """dist.sharded_forward + backward + allreduce_gradients with the HIP backend and RCCL collectives (a
+    one-rank group: the only size one GPU can host) against forward_pairs of the same module."""
+    import torch.distributed as tdist
+    from disenlink_amd import dist as dl_dist
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.graph import Graph, PairList
+    from disenlink_amd.metrics import pair_bce_loss
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    sg = synthetic_graph("cora", seed=1)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=1)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    lab = np.concatenate([np.ones(split.pos_train.u.size, np.float32), np.zeros(split.neg_train.u.size, np.float32)])
+    order = np.lexsort((pv, pu))
+    pu, pv, lab = pu[order], pv[order], torch.from_numpy(lab[order]).to(DEV)
+    x = torch.from_numpy(sg.features()).to(DEV)
+    torch.manual_seed(0)
+    model = Disentangle(sg.n_feat, 64, 32, nfactor=4, beta=0.6, t=1).to(DEV)
+
+    def loss_of(prob):
+        w = torch.where(lab > 0, 1.0 / float(lab.sum()), 0.2 / float((1 - lab).sum()))
+        return -(w * (lab * prob.clamp_min(1e-12).log() + (1 - lab) * (1 - prob).clamp_min(1e-12).log())).sum()
+
+    graph = Graph.from_edge_rows(torch.from_numpy(split.train_src).to(DEV), torch.from_numpy(split.train_dst).to(DEV), sg.n_nodes)
+    pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), sg.n_nodes)
+    emb, prob = model.forward_pairs(x, graph, pairs)
+    model.zero_grad()
+    loss_of(prob).backward()
+    want = [p.grad.clone() for p in model.parameters()]
+
+    own_group = not tdist.is_initialized()
+    if own_group:
+        tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1,
+                                 device_id=torch.device(DEV))
+    try:
+        shard = dl_dist.Shard.build(0, 1, sg.n_nodes, split.train_src, split.train_dst, pu, pv, torch.device(DEV))
+        emb_s, prob_s = dl_dist.sharded_forward(model, x, shard)
+        model.zero_grad()
+        loss_of(prob_s).backward()
+        dl_dist.allreduce_gradients(model)
+        torch.cuda.synchronize()
+    finally:
+        if own_group:
+            tdist.destroy_process_group()
+    np.testing.assert_allclose(emb_s.detach().cpu().numpy(), emb.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(prob_s.detach().cpu().numpy(), prob.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    for p, w in zip(model.parameters(), want):
+        assert float((p.grad - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-8)
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops
