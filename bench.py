@@ -155,14 +155,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DL_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the collectives go through gloo — a functional
+    # rehearsal of the N>1 code on a one-GPU box (RCCL refuses two ranks on one device); never a measurement.
+    rehearse = bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU"))
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     sharded = world > 1 or bool(os.environ.get("DL_FORCE_SHARDED"))     # the env var rehearses the N>1 code on 1 GPU
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from disenlink_amd import _lib, ops
     lib = _lib.load()

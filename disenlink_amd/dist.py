@@ -61,6 +61,11 @@ def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None, src: torch
     send buffer never aliases the receive buffer: `src` if the caller still holds the local rows elsewhere,
     else a copy of full[lo:hi] (a few microseconds against a collective of 8x the bytes)."""
     local = src if src is not None else full[lo:hi].clone()
+    if full.is_cuda and dist.get_backend(group) == "gloo":          # one-GPU rehearsal: gloo moves host memory
+        host = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
+        full.copy_(host)
+        return
     dist.all_gather_into_tensor(full, local.contiguous(), group=group)
 
 
@@ -275,9 +280,10 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
         step()
     torch.cuda.synchronize()
     dist.barrier()
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    red_dev = "cpu" if dist.get_backend() == "gloo" else device
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    counts = torch.tensor([shard.graph.n_edges, shard.pairs.n_pairs], dtype=torch.int64, device=device)
+    counts = torch.tensor([shard.graph.n_edges, shard.pairs.n_pairs], dtype=torch.int64, device=red_dev)
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     E, P = int(counts[0]), int(counts[1])
     wall_s = float(wall[0])
