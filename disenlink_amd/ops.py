@@ -461,6 +461,7 @@ class ScorePairs(torch.autograd.Function):
 class ScoreAllPairs(torch.autograd.Function):
     """(Z, H) -> prob [N,N], the dense output the reference's caller indexes with masks
     (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero."""
+    _plan_cache = None
 
     @staticmethod
     def forward(ctx, Z, H, t: float):
@@ -475,8 +476,15 @@ class ScoreAllPairs(torch.autograd.Function):
         Z, H, prob = ctx.saved_tensors
         N = Z.shape[0]
         nz = torch.nonzero(g_prob)
-        pairs = PairList.build(nz[:, 0], nz[:, 1], N)
-        flat = nz[:, 0] * N + nz[:, 1]
+        # the caller's masks are fixed for a run (main_disentangled.py:134-190), so the set of entries with a
+        # gradient repeats every epoch: keep the last pair plan and reuse it while the index set is unchanged
+        hit = ScoreAllPairs._plan_cache
+        if hit is not None and hit[0].shape == nz.shape and hit[0].device == nz.device and torch.equal(hit[0], nz):
+            _nz, pairs, flat = hit
+        else:
+            pairs = PairList.build(nz[:, 0], nz[:, 1], N)
+            flat = nz[:, 0] * N + nz[:, 1]
+            ScoreAllPairs._plan_cache = (nz, pairs, flat)
         dZ, dH = score_pairs_bwd(Z, H, pairs, ctx.t, prob.reshape(-1)[flat].contiguous(),
                                  g_prob.reshape(-1)[flat].contiguous())
         return dZ, dH, None
