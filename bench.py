@@ -277,6 +277,24 @@ def main():
                 "fwd": {"avg_us": t_f * 1e6, "achieved": fl_f / t_f / 1e12, "frac": fl_f / t_f / 1e12 / FP32_MFMA_PEAK_TFLOPS},
                 "bwd": {"avg_us": t_b * 1e6, "achieved": fl_b / t_b / 1e12, "frac": fl_b / t_b / 1e12 / FP32_MFMA_PEAK_TFLOPS}}
 
+    # extra: the dense [N,N] scorer of the drop-in forward (model.py:109-113 as written): Gram products on MFMA
+    dense = None
+    if N <= 12000 and args.dtype == "f32":
+        Hd = ops.aggregate_fwd(graph, Z, beta, *ops.route_fwd(graph, Z, t))
+        for _ in range(2):
+            ops.score_allpairs_fwd(Z, Hd, t)
+        evd = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        evd[0].record()
+        for i in range(5):
+            ops.score_allpairs_fwd(Z, Hd, t)
+            evd[i + 1].record()
+        torch.cuda.synchronize()
+        t_d = float(np.mean([evd[i].elapsed_time(evd[i + 1]) for i in range(5)])) * 1e-3
+        fl_d = 4.0 * N * N * K * d
+        dense = {"bound": "mfma", "dtype": "f32", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "pairs": N * N,
+                 "avg_us": t_d * 1e6, "achieved": fl_d / t_d / 1e12, "frac": fl_d / t_d / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 "pairs_per_s": N * N / t_d}
+
     units = E + P
     result = {
         "metric": "edges/sec (aggregate+score) at K=8 d=64",
@@ -304,6 +322,7 @@ def main():
         "kernels": kernels,
         "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},
         "projection": proj,
+        "dense_allpairs": dense,
     }
     if not args.no_cpu_baseline:
         gcpu = graph.to("cpu")

@@ -244,6 +244,8 @@ int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_
     DL_REQUIRE(t != 0.0f, "temperature is 0");
     if (N == 0) return DL_OK;
     DL_REQUIRE(Z && H && prob, "NULL argument");
+    if (!g_force_generic && dtype == DL_F32 && dense_mfma_supported(d))      // Gram products on the matrix cores
+        return dense_mfma_score_allpairs_fwd((const float*)Z, (const float*)H, N, K, d, t, prob, (hipStream_t)stream);
     if (!g_force_generic && fast_supported(K, d, dtype))
         return fast_score_allpairs_fwd(Z, H, N, K, d, dtype, t, prob, (hipStream_t)stream);
     DL_REQUIRE(dtype == DL_F32, "bf16 tables need a tuned kernel for K=%d d=%d", K, d);

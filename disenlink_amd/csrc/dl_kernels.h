@@ -44,6 +44,11 @@ int fast_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, i
 int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
                                hipStream_t st);
 
+// dense scorer on the matrix cores (dl_score_dense.hip): fp32 tables, d % 32 == 0
+bool dense_mfma_supported(int d);
+int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
+                                  hipStream_t st);
+
 int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,
              hipStream_t st);
 

@@ -1,0 +1,149 @@
+// Dense [N][N] link scorer on the matrix cores: the reference's link_pred (model.py:109-113),
+//   P[u][v] = sigmoid( sum_k (h_k[u].h_k[v]) * exp(z_k[u].z_k[v] / t) )        for ALL pairs,
+// which the drop-in forward(x, adj) must return.  Per factor it is two N x N x d Gram products —
+// GEMM-shaped work (4*N^2*K*d FLOP, 55 GFLOP at squirrel size), so unlike the pair-list scorer (a gather
+// bound by L2 bandwidth) it belongs on MFMA: fp32 in / fp32 accumulate, v_mfma_f32_32x32x2_f32.
+//
+// One workgroup = 8 waves = a 128 (u) x 128 (v) tile of P; waves are 4 u-quarters x 2 v-halves, each owning
+// 32 u x 64 v = two accumulators, two waves per SIMD.  Per factor k: S = Z_k[u] Z_k[v]^T accumulated over d in
+// chunks of 32 features (operand tiles [128 rows][32], pitch 36 floats, double-buffered in LDS with the
+// write-after-barrier staging of dl_project.hip), e = exp(S / t) in the accumulator registers, then
+// Q = H_k[u] H_k[v]^T the same way and term += Q * e.  Nothing but P is written: no [K][N][N] tensor.
+// Work items (u tile, v tile) are dealt to the XCDs in runs that share operand tiles (xcd_item).
+#include "dl_common.h"
+#include "dl_kernels.h"
+#include "dl_tiles.h"
+
+namespace dl {
+namespace dense {
+
+using namespace project;       // TileStage, f32x16, acc_row, DL_MFMA, xcd_item
+
+constexpr int TT = 128;        // tile edge (u and v)
+constexpr int DC = 32;         // features per step
+constexpr int LDD = DC + 4;
+constexpr int DTHR = 512;
+
+__global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* __restrict__ Z, const float* __restrict__ H,
+                                                                   int N, int K, int D, float t, float* __restrict__ prob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* us = lds;                       // [2][TT][LDD]
+    float* vs = us + 2 * TT * LDD;         // [2][TT][LDD]
+    const int nt = (N + TT - 1) / TT;
+    const XcdItem item = xcd_item(blockIdx.x, nt, nt);
+    if (!item.valid) return;
+    const int u0 = item.a * TT, v0 = item.b * TT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, half = lane >> 5;
+    const int wu = wave >> 1, wv = wave & 1;
+    const int nd = D / DC;
+    const int steps = K * 2 * nd;
+    const int ld = K * D;
+
+    TileStage<TT, DC, true, DTHR> ut, vt;
+    auto fetch = [&](int s) {
+        const int k = s / (2 * nd), r = s - k * 2 * nd;
+        const float* src = r < nd ? Z : H;
+        const int dc = r < nd ? r : r - nd;
+        ut.fetch(src + ((size_t)u0 * K + k) * D + dc * DC, ld, N - u0, DC, tid);
+        vt.fetch(src + ((size_t)v0 * K + k) * D + dc * DC, ld, N - v0, DC, tid);
+    };
+    auto stash = [&](int s) {
+        ut.template stash<LDD>(us + (s & 1) * TT * LDD, tid);
+        vt.template stash<LDD>(vs + (s & 1) * TT * LDD, tid);
+    };
+
+    f32x16 acc[2], term[2];
+    float e[2][16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        zero_acc(acc[b]);
+        zero_acc(term[b]);
+    }
+    fetch(0);
+    stash(0);
+    if (steps > 1) fetch(1);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int r = s % (2 * nd);
+        // A = u rows of this quarter (lane = u), B = v rows (lane = v): acc[u][v], u rows in the registers
+        const float* ub = us + (s & 1) * TT * LDD + (wu * 32 + li) * LDD + half * (DC / 2);
+        const float* vb = vs + (s & 1) * TT * LDD + (wv * 64 + li) * LDD + half * (DC / 2);
+        float4 a[2][2], b[2][2][2];
+        auto read_block = [&](int j) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a[j & 1][q] = *reinterpret_cast<const float4*>(ub + 8 * j + 4 * q);
+                b[j & 1][0][q] = *reinterpret_cast<const float4*>(vb + 8 * j + 4 * q);
+                b[j & 1][1][q] = *reinterpret_cast<const float4*>(vb + 32 * LDD + 8 * j + 4 * q);
+            }
+        };
+        read_block(0);
+#pragma unroll
+        for (int j = 0; j < DC / 16; ++j) {
+            if (j + 1 < DC / 16) read_block(j + 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                DL_MFMA(acc[0], a[j & 1][q].x, b[j & 1][0][q].x);
+                DL_MFMA(acc[1], a[j & 1][q].x, b[j & 1][1][q].x);
+                DL_MFMA(acc[0], a[j & 1][q].y, b[j & 1][0][q].y);
+                DL_MFMA(acc[1], a[j & 1][q].y, b[j & 1][1][q].y);
+                DL_MFMA(acc[0], a[j & 1][q].z, b[j & 1][0][q].z);
+                DL_MFMA(acc[1], a[j & 1][q].z, b[j & 1][1][q].z);
+                DL_MFMA(acc[0], a[j & 1][q].w, b[j & 1][0][q].w);
+                DL_MFMA(acc[1], a[j & 1][q].w, b[j & 1][1][q].w);
+            }
+            if (j == 0) {
+                if (s + 1 < steps) stash(s + 1);
+                if (s + 2 < steps) fetch(s + 2);
+            }
+        }
+        if (r == nd - 1) {                                      // S complete: e = exp(S / t)  (model.py:56)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) e[bb][i] = expf(div_t(acc[bb][i], t));
+                zero_acc(acc[bb]);
+            }
+        } else if (r == 2 * nd - 1) {                           // Q complete: term += Q * e  (model.py:110-112)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) term[bb][i] += acc[bb][i] * e[bb][i];
+                zero_acc(acc[bb]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int v = v0 + wv * 64 + bb * 32 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int u = u0 + wu * 32 + acc_row(i, half);
+            if (u < N && v < N) prob[(size_t)u * N + v] = sigmoid_ref(term[bb][i]);
+        }
+    }
+}
+
+}  // namespace dense
+
+bool dense_mfma_supported(int d) { return d % dense::DC == 0; }
+
+int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
+                                  hipStream_t st) {
+    using namespace dense;
+    static bool attr_done = false;
+    constexpr size_t lds = sizeof(float) * 4 * TT * LDD;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&score_allpairs_mfma_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int nt = (N + TT - 1) / TT;
+    hipLaunchKernelGGL(score_allpairs_mfma_kernel, dim3((unsigned)project::xcd_grid(nt, nt)), dim3(DTHR), lds, st, Z, H, N,
+                       K, d, t, prob);
+    return check_launch("score_allpairs_fwd(mfma)");
+}
+
+}  // namespace dl

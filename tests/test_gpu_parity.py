@@ -358,6 +358,34 @@ def test_sharded_training_step_over_rccl_matches_the_unsharded_module():
         assert float((p.grad - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-8)
 
 
+@pytest.mark.parametrize("K,d,N", [(8, 64, 700), (3, 32, 385), (16, 128, 260), (5, 64, 128), (2, 96, 129)])
+def test_dense_scorer_on_the_matrix_cores_matches_the_pair_scorer(K, d, N):
+    """dl_score_allpairs_fwd (Gram products on MFMA, 128x128 tiles incl. ragged edges) against the pair-list
+    scorer evaluated on all N^2 pairs and against the fp64 formula; overflowing factors behave alike."""
+    from disenlink_amd import ops
+    g = torch.Generator().manual_seed(K * 100 + d)
+    amp = 0.3 * (32 / d) ** 0.5 * (4 / K) ** 0.25       # keeps the logits O(1): sigmoid not saturated, exp tame
+    Z = (torch.randn(N, K, d, generator=g) * amp).to(DEV)
+    H = (torch.randn(N, K, d, generator=g) * amp).to(DEV)
+    t = 1.0 if K != 3 else 2.0
+    P = ops.score_allpairs_fwd(Z, H, t)
+    idx = torch.arange(N, dtype=torch.int32, device=DEV)
+    Pp = ops.score_pairs_fwd(Z, H, idx.repeat_interleave(N), idx.repeat(N), t).view(N, N)
+    assert P.shape == (N, N)
+    np.testing.assert_allclose(P.cpu().numpy(), Pp.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    Zd, Hd = Z.double().cpu(), H.double().cpu()
+    ref = torch.sigmoid((torch.einsum("ukd,vkd->kuv", Hd, Hd) * torch.exp(torch.einsum("ukd,vkd->kuv", Zd, Zd) / t)).sum(0))
+    np.testing.assert_allclose(P.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(P, ops.score_allpairs_fwd(Z, H, t))                    # reproducible
+    Zb = Z.clone()
+    Zb[1, 0] = 12.0                                                           # exp(z.z) overflows for (1,1)
+    Pb = ops.score_allpairs_fwd(Zb, H, t)
+    Pbp = ops.score_pairs_fwd(Zb, H, idx.repeat_interleave(N), idx.repeat(N), t).view(N, N)
+    assert torch.equal(torch.isnan(Pb), torch.isnan(Pbp))
+    ok = ~torch.isnan(Pb)       # large exponents amplify the summation-order difference of the two kernels
+    np.testing.assert_allclose(Pb[ok].cpu().numpy(), Pbp[ok].cpu().numpy(), rtol=1e-3, atol=1e-6)
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops
