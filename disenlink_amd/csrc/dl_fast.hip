@@ -814,8 +814,9 @@ __global__ __launch_bounds__(BLOCK) void pair_bce_kernel(const float* __restrict
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < n; q += BCE_BLOCKS * BLOCK) {
         const float p = prob[q], yy = y[q], ww = w[q];
         const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(logf(1.0f - p), -100.0f);
-        acc += ww * -(yy * lp + (1.0f - yy) * l1p);
-        g[q] = ww * (p - yy) / fmaxf(p * (1.0f - p), 1e-12f);
+        // weight 0 = "not part of the loss" (e.g. validation pairs riding along): exactly nothing, even for a NaN p
+        acc += ww == 0.0f ? 0.0f : ww * -(yy * lp + (1.0f - yy) * l1p);
+        g[q] = ww == 0.0f ? 0.0f : ww * (p - yy) / fmaxf(p * (1.0f - p), 1e-12f);
     }
     acc = wave_allreduce_sum(acc);
     if (lane_id() == 0) red[threadIdx.x >> 6] = acc;

@@ -416,6 +416,7 @@ class HotPathPairs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Z, graph: Graph, pairs: PairList, beta: float, t: float, table_dtype):
+        ctx.set_materialize_grads(False)        # an unused output (emb in the training loss) arrives as None, not zeros
         Zt = _f32c(Z) if table_dtype == torch.float32 else _f32c(Z).to(table_dtype)
         p, a, s = route_fwd(graph, Zt, t)
         H = aggregate_fwd(graph, Zt, beta, p, a, s)

@@ -63,7 +63,18 @@ class RunResult:
 _FUSED_ADAM = os.environ.get("DL_FUSED_ADAM", "1") != "0"
 
 
-def _graphed_epoch(model, x, run, lr, weight_decay, b, label_train, weight_train):
+def _loss_vectors(run, device):
+    """Labels and weights over the WHOLE scored list [pos | neg | validation]: the validation pairs carry weight
+    zero, so the fused loss runs on the scorer's output as it is — no slice, hence no zero-filled gradient
+    buffer and copy in the backward."""
+    n_val = run.label_val.numel()
+    label = torch.cat([run.label_pos, run.label_neg, run.label_val.to(run.label_pos.dtype)])
+    weight = torch.cat([pair_bce_weights(run.n_pos, run.n_neg, run.m, device),
+                        torch.zeros(n_val, dtype=torch.float32, device=device)])
+    return label, weight
+
+
+def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     """Capture one full epoch (forward, fused loss, backward, Adam step, validation AUC) into a HIP graph:
     every launch of the epoch — ours and torch's — is replayed with one host call, which removes the
     launch-bound host time of small graphs.  Returns (replay, out) with out = [loss, auc] on the device."""
@@ -72,7 +83,7 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_train, weight_train
 
     def epoch():
         _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
-        loss = pair_bce_loss_fused(prob[:b], label_train, weight_train)
+        loss = pair_bce_loss_fused(prob, label_all, weight_all)
         opt.zero_grad(set_to_none=False)
         loss.backward()
         opt.step()
@@ -124,13 +135,12 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
             raise ValueError("AUC undefined with one class")
     fused = x.is_cuda                                               # fused loss+gradient kernel on the GPU path
     if fused:
-        label_train = torch.cat([run.label_pos, run.label_neg])
-        weight_train = pair_bce_weights(run.n_pos, run.n_neg, run.m, x.device)
+        label_all, weight_all = _loss_vectors(run, x.device)
     for epoch in range(epochs):
         model.train()
         _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
         if fused:
-            loss = pair_bce_loss_fused(prob[:b], label_train, weight_train)
+            loss = pair_bce_loss_fused(prob, label_all, weight_all)
         else:
             loss = pair_bce_loss(prob[:a], run.label_pos, prob[a:b], run.label_neg, run.m)
         opt.zero_grad()
@@ -164,9 +174,8 @@ def _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log) -> RunR
         if not 0 < float(lab.sum()) < lab.numel():
             raise ValueError("AUC undefined with one class")
     b = run.n_pos + run.n_neg
-    label_train = torch.cat([run.label_pos, run.label_neg])
-    weight_train = pair_bce_weights(run.n_pos, run.n_neg, run.m, x.device)
-    replay, out = _graphed_epoch(model, x, run, lr, weight_decay, b, label_train, weight_train)
+    label_all, weight_all = _loss_vectors(run, x.device)
+    replay, out = _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all)
     snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
     best_auc, stale, weights = 0.0, 0, snapshot()
     res = RunResult(float("nan"), 0.0, 0)
