@@ -9,7 +9,10 @@
 // chunks of 32 features (operand tiles [128 rows][32], pitch 36 floats, double-buffered in LDS with the
 // write-after-barrier staging of dl_project.hip), e = exp(S / t) in the accumulator registers, then
 // Q = H_k[u] H_k[v]^T the same way and term += Q * e.  Nothing but P is written: no [K][N][N] tensor.
-// Work items (u tile, v tile) are dealt to the XCDs in runs that share operand tiles (xcd_item).
+// P is symmetric — bit for bit, because entry (u,v) and entry (v,u) are the same products summed in the same
+// order — so only the tile pairs with u tile <= v tile are computed and an off-diagonal tile is also stored
+// transposed (4 consecutive u per register quad: 16-byte stores).  Work items are dealt to the XCDs in runs
+// of 32 consecutive (same u tile, consecutive v tiles) items.
 #include "dl_common.h"
 #include "dl_kernels.h"
 #include "dl_tiles.h"
@@ -30,9 +33,16 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* 
     float* us = lds;                       // [2][TT][LDD]
     float* vs = us + 2 * TT * LDD;         // [2][TT][LDD]
     const int nt = (N + TT - 1) / TT;
-    const XcdItem item = xcd_item(blockIdx.x, nt, nt);
-    if (!item.valid) return;
-    const int u0 = item.a * TT, v0 = item.b * TT;
+    // item i of the upper triangle in row-major order: rows a = 0.. hold nt - a items
+    const int h = blockIdx.x;
+    const int i = ((h >> 3) >> 5) * 256 + (h & 7) * 32 + ((h >> 3) & 31);        // runs of 32 items per XCD
+    if (i >= nt * (nt + 1) / 2) return;
+    int ta = (int)((2.0f * nt + 1.0f - sqrtf((2.0f * nt + 1.0f) * (2.0f * nt + 1.0f) - 8.0f * (float)i)) * 0.5f);
+    ta = max(0, min(nt - 1, ta));
+    while (ta > 0 && i < ta * nt - ta * (ta - 1) / 2) --ta;                      // first item of row a = a*nt - a(a-1)/2
+    while (i >= (ta + 1) * nt - (ta + 1) * ta / 2) ++ta;
+    const int tb = ta + (i - (ta * nt - ta * (ta - 1) / 2));
+    const int u0 = ta * TT, v0 = tb * TT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
     const int wu = wave >> 1, wv = wave & 1;
@@ -119,9 +129,25 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* 
     for (int bb = 0; bb < 2; ++bb) {
         const int v = v0 + wv * 64 + bb * 32 + li;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int u = u0 + wu * 32 + acc_row(i, half);
-            if (u < N && v < N) prob[(size_t)u * N + v] = sigmoid_ref(term[bb][i]);
+        for (int r = 0; r < 16; ++r) {
+            term[bb][r] = sigmoid_ref(term[bb][r]);
+            const int u = u0 + wu * 32 + acc_row(r, half);
+            if (u < N && v < N) prob[(size_t)u * N + v] = term[bb][r];
+        }
+        if (ta != tb && v < N) {                                // mirror: P[v][u], registers 4g..4g+3 = 4 consecutive u
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = u0 + wu * 32 + 8 * g + 4 * half;
+                float* dst = prob + (size_t)v * N + u;
+                if (u + 3 < N && (N & 3) == 0) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(term[bb][4 * g], term[bb][4 * g + 1], term[bb][4 * g + 2],
+                                                                  term[bb][4 * g + 3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (u + j < N) dst[j] = term[bb][4 * g + j];
+                }
+            }
         }
     }
 }
@@ -141,7 +167,8 @@ int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, 
         attr_done = true;
     }
     const int nt = (N + TT - 1) / TT;
-    hipLaunchKernelGGL(score_allpairs_mfma_kernel, dim3((unsigned)project::xcd_grid(nt, nt)), dim3(DTHR), lds, st, Z, H, N,
+    const int items = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(score_allpairs_mfma_kernel, dim3((unsigned)((items + 255) / 256 * 256)), dim3(DTHR), lds, st, Z, H, N,
                        K, d, t, prob);
     return check_launch("score_allpairs_fwd(mfma)");
 }

@@ -377,6 +377,7 @@ def test_dense_scorer_on_the_matrix_cores_matches_the_pair_scorer(K, d, N):
     ref = torch.sigmoid((torch.einsum("ukd,vkd->kuv", Hd, Hd) * torch.exp(torch.einsum("ukd,vkd->kuv", Zd, Zd) / t)).sum(0))
     np.testing.assert_allclose(P.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(P, ops.score_allpairs_fwd(Z, H, t))                    # reproducible
+    assert torch.equal(P, P.t())                                              # mirrored tiles: exactly symmetric
     Zb = Z.clone()
     Zb[1, 0] = 12.0                                                           # exp(z.z) overflows for (1,1)
     Pb = ops.score_allpairs_fwd(Zb, H, t)
