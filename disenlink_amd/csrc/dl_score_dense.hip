@@ -13,6 +13,7 @@
 // order — so only the tile pairs with u tile <= v tile are computed and an off-diagonal tile is also stored
 // transposed (4 consecutive u per register quad: 16-byte stores).  Work items are dealt to the XCDs in runs
 // of 32 consecutive (same u tile, consecutive v tiles) items.
+#include <cstdlib>
 #include "dl_common.h"
 #include "dl_kernels.h"
 #include "dl_tiles.h"
@@ -23,12 +24,13 @@ namespace dense {
 using namespace project;       // TileStage, f32x16, acc_row, DL_MFMA, xcd_item
 
 constexpr int TT = 128;        // tile edge (u and v)
-constexpr int DC = 32;         // features per step
-constexpr int LDD = DC + 4;
 constexpr int DTHR = 512;
 
+// DC = features per step (64 when d allows: one barrier per 64 MFMAs of a wave), LDS row pitch DC + 4
+template <int DC>
 __global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* __restrict__ Z, const float* __restrict__ H,
                                                                    int N, int K, int D, float t, float* __restrict__ prob) {
+    constexpr int LDD = DC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* us = lds;                       // [2][TT][LDD]
     float* vs = us + 2 * TT * LDD;         // [2][TT][LDD]
@@ -154,22 +156,28 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* 
 
 }  // namespace dense
 
-bool dense_mfma_supported(int d) { return d % dense::DC == 0; }
+bool dense_mfma_supported(int d) { return d % 32 == 0; }
 
-int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
-                                  hipStream_t st) {
+template <int DC>
+static void launch_dense(const float* Z, const float* H, int N, int K, int d, float t, float* prob, hipStream_t st) {
     using namespace dense;
     static bool attr_done = false;
-    constexpr size_t lds = sizeof(float) * 4 * TT * LDD;
+    constexpr size_t lds = sizeof(float) * 4 * TT * (DC + 4);
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&score_allpairs_mfma_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&score_allpairs_mfma_kernel<DC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int nt = (N + TT - 1) / TT;
     const int items = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(score_allpairs_mfma_kernel, dim3((unsigned)((items + 255) / 256 * 256)), dim3(DTHR), lds, st, Z, H, N,
-                       K, d, t, prob);
+    hipLaunchKernelGGL(score_allpairs_mfma_kernel<DC>, dim3((unsigned)((items + 255) / 256 * 256)), dim3(DTHR), lds, st, Z, H,
+                       N, K, d, t, prob);
+}
+
+int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
+                                  hipStream_t st) {
+    if (d % 64 == 0 && !getenv("DL_DENSE_DC32")) launch_dense<64>(Z, H, N, K, d, t, prob, st);
+    else launch_dense<32>(Z, H, N, K, d, t, prob, st);
     return check_launch("score_allpairs_fwd(mfma)");
 }
 
