@@ -322,9 +322,14 @@ __device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
 }
 
 template <int TOT, typename TX, typename TO>
-__global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const float* __restrict__ part, int pstride,
+__global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const float* __restrict__ part0, int pstride,
                                                             const TX* __restrict__ X, float cx, float cp,
-                                                            TO* __restrict__ out, int accumulate) {
+                                                            TO* __restrict__ out0, int accumulate,
+                                                            const float* __restrict__ part1 = nullptr,
+                                                            TO* __restrict__ out1 = nullptr) {
+    // gridDim.y == 2: two independent (partials, output) pairs over the same plan in one launch
+    const float* __restrict__ part = blockIdx.y ? part1 : part0;
+    TO* __restrict__ out = blockIdx.y ? out1 : out0;
     constexpr int TOT4 = TOT / 4;
     constexpr int NQ = (TOT4 + DL_WAVE - 1) / DL_WAVE;
     __shared__ float4 red[WAVES_PER_BLOCK][NQ * DL_WAVE];
@@ -937,22 +942,16 @@ struct Ops {
                                inc->inc_pair, (const T*)Z, t, prob, g_prob, coef_q, dZ, part);
             hipLaunchKernelGGL((score_bwd_coef_seg_kernel<K, D, T, 1>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
                                inc->inc_pair, (const T*)H, t, prob, g_prob, coef, dH, part_h);
-            if (g->n_multi > 0) {
-                hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
-                                   part, ROW, no_x, 0.0f, 1.0f, dZ, 0);
-                hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
-                                   part_h, ROW, no_x, 0.0f, 1.0f, dH, 0);
-            }
+            if (g->n_multi > 0)
+                hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g,
+                                   part, ROW, no_x, 0.0f, 1.0f, dZ, 0, part_h, dH);
             return check_launch("score_pairs_bwd(fast, stored terms)");
         }
         hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
                            (const T*)Z, (const T*)H, t, prob, g_prob, dZ, dH, part);
-        if (g->n_multi > 0) {
-            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, part,
-                               2 * ROW, no_x, 0.0f, 1.0f, dZ, 0);
-            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
-                               part + ROW, 2 * ROW, no_x, 0.0f, 1.0f, dH, 0);
-        }
+        if (g->n_multi > 0)
+            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g, part,
+                               2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
         return check_launch("score_pairs_bwd(fast)");
     }
 };
