@@ -53,7 +53,7 @@ def algorithmic_bytes(K, d, n_nodes, n_edges, n_pairs, w=4):
     return dict(route=route, aggregate=aggregate, score=score)
 
 
-def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0):
+def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0, elem_bytes=4):
     from disenlink_amd.data import synthetic_graph
     from disenlink_amd.graph import Graph, PairList
     from disenlink_amd.model import Disentangle
@@ -61,13 +61,13 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0):
     sg = synthetic_graph(name, seed=seed, scale=scale)
     split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=m, seed=seed)
     graph = Graph.from_edge_rows(torch.from_numpy(split.train_src).to(device),
-                                 torch.from_numpy(split.train_dst).to(device), sg.n_nodes, row_bytes=K * d * 4)
+                                 torch.from_numpy(split.train_dst).to(device), sg.n_nodes, row_bytes=K * d * elem_bytes)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
     order = np.lexsort((pv, pu))                      # pair list laid out by u: long runs share the u rows
     pu, pv = pu[order], pv[order]
     pairs = PairList.build(torch.from_numpy(pu).to(device), torch.from_numpy(pv).to(device), sg.n_nodes,
-                           row_bytes=K * d * 4)
+                           row_bytes=K * d * elem_bytes)
     torch.manual_seed(seed)
     model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.5, t=1).to(device)
     x = torch.from_numpy(sg.features()).to(device)
@@ -187,7 +187,8 @@ def main():
         dist.destroy_process_group()
         return
 
-    sg, split, graph, pairs, model, x, Z = build_workload(args.workload, device, K, d, args.nhidden, scale=args.scale)
+    sg, split, graph, pairs, model, x, Z = build_workload(args.workload, device, K, d, args.nhidden, scale=args.scale,
+                                                          elem_bytes=2 if args.dtype == "bf16" else 4)
     E, P, N = graph.n_edges, pairs.n_pairs, graph.n_nodes
     wbytes = 4
     if args.dtype == "bf16":
