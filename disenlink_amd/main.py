@@ -103,7 +103,7 @@ def main(argv=None):
         if not args.quiet:
             print("run:", run)
         split = make_link_split(ds.src, ds.dst, ds.n_nodes, m=args.m, seed=args.seed + run)
-        prepared = prepare_run(split, device, row_bytes=args.nfactor * args.nembed * 4)
+        prepared = prepare_run(split, device, row_bytes=args.nfactor * args.nembed * (2 if args.table_dtype == "bf16" else 4))
         torch.manual_seed(args.seed + run)
         model = Disentangle(x.shape[1], args.nhidden, args.nembed, nfactor=args.nfactor, beta=args.beta,
                             t=args.temperature, table_dtype=tdt).to(device)

@@ -38,7 +38,7 @@ class PreparedRun:
 
 
 def prepare_run(split: LinkSplit, device, seg_len: int = 32, row_bytes: int = 2048) -> PreparedRun:
-    """``row_bytes`` = K * d * 4 of the model (sizes the XCD slicing of the pair plans)."""
+    """``row_bytes`` = K * d * (4, or 2 with bf16 tables) of the model (sizes the XCD slicing of the pair plans)."""
     t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
     graph = Graph.from_edge_rows(t(split.train_src), t(split.train_dst), split.n_nodes, seg_len=seg_len,
                                  row_bytes=row_bytes)
