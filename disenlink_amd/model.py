@@ -11,6 +11,8 @@ list instead; the reference has no counterpart for it.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -169,11 +171,19 @@ class Disentangle(nn.Module):
         return Z.contiguous()
 
     # ------------------------------------------------------------------ graph cache
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_graph_cache"] = None              # holds a weak reference: not copyable / picklable, and only a cache
+        return state
+
     def _graph_for(self, adj: torch.Tensor) -> Graph:
-        key = (adj.data_ptr(), tuple(adj.shape), adj._version, adj.device)
-        if self._graph_cache is None or self._graph_cache[0] != key:
-            self._graph_cache = (key, Graph.from_dense(adj, row_bytes=self.nfactor * self.nebed * 4))
-        return self._graph_cache[1]
+        """CSR + plans of a dense adjacency, built once per adjacency tensor: keyed on the tensor OBJECT (weak
+        reference) and its version counter — an address can be reused by a different tensor, an object cannot."""
+        hit = self._graph_cache
+        if hit is None or hit[0]() is not adj or hit[1] != adj._version:
+            hit = (weakref.ref(adj), adj._version, Graph.from_dense(adj, row_bytes=self.nfactor * self.nebed * 4))
+            self._graph_cache = hit
+        return hit[2]
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, adj):

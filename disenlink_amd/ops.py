@@ -9,6 +9,7 @@ There is no fallback: tensors must be CUDA(HIP) fp32 tensors and the library mus
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -232,12 +233,13 @@ def _pad_features(x, W1):
     Fp = (F + 3) // 4 * 4
     if Fp == F:
         return x, W1
-    key = (x.data_ptr(), x._version, tuple(x.shape), x.device)
+    # keyed on the tensor OBJECT (weak reference) and its version counter: an address can be reused by another
+    # tensor of the same shape once this one is freed, an object cannot
     hit = _xpad_cache.get("x")
-    if hit is None or hit[0] != key:
-        hit = (key, torch.nn.functional.pad(x, (0, Fp - F)))
+    if hit is None or hit[0]() is not x or hit[1] != x._version:
+        hit = (weakref.ref(x), x._version, torch.nn.functional.pad(x, (0, Fp - F)))
         _xpad_cache["x"] = hit
-    return hit[1], torch.nn.functional.pad(W1, (0, Fp - F))
+    return hit[2], torch.nn.functional.pad(W1, (0, Fp - F))
 
 
 def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True) -> torch.Tensor:

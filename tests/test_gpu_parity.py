@@ -387,6 +387,43 @@ def test_dense_scorer_on_the_matrix_cores_matches_the_pair_scorer(K, d, N):
     np.testing.assert_allclose(Pb[ok].cpu().numpy(), Pbp[ok].cpu().numpy(), rtol=1e-3, atol=1e-6)
 
 
+def test_caches_follow_tensor_identity_not_addresses():
+    """The per-adjacency graph cache of the drop-in module and the padded-feature cache must not serve a freed
+    tensor's entry to a new tensor that happens to reuse its address."""
+    from disenlink_amd import ops
+    from disenlink_amd.model import Disentangle
+    torch.manual_seed(3)
+    N, Fdim = 60, 10                                            # F % 4 != 0: the feature-padding cache is in play
+    model = Disentangle(Fdim, 16, 32, nfactor=4, beta=0.5, projection="mfma").to(DEV)
+    x = torch.randn(N, Fdim, device=DEV)
+
+    def adj_of(seed):
+        g = torch.Generator().manual_seed(seed)
+        a = (torch.rand(N, N, generator=g) < 0.1).float()
+        return ((a + a.t()) > 0).float().to(DEV)
+
+    a1 = adj_of(1)
+    addr = a1.data_ptr()
+    _e1, p1 = model(x, a1)
+    p1 = p1.detach().clone()
+    del a1, _e1
+    a2 = adj_of(2)                                              # same shape: the allocator usually reuses the block
+    _e2, p2 = model(x, a2)
+    fresh = Disentangle(Fdim, 16, 32, nfactor=4, beta=0.5, projection="mfma").to(DEV)
+    fresh.load_state_dict(model.state_dict())
+    _e3, p3 = fresh(x, a2)
+    assert torch.equal(p2, p3), ("stale graph served", a2.data_ptr() == addr)
+    assert not torch.equal(p1, p2)
+    x1 = torch.randn(N, Fdim, device=DEV)
+    z1 = model.project(x1).detach().clone()
+    xaddr = x1.data_ptr()
+    del x1
+    x2 = torch.randn(N, Fdim, device=DEV)
+    z2 = model.project(x2)
+    assert torch.allclose(z2, fresh.project(x2), atol=1e-6), ("stale padded features served", x2.data_ptr() == xaddr)
+    assert not torch.equal(z1, z2)
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops

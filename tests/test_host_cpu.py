@@ -273,3 +273,19 @@ def test_c_abi_host_graph_prep_matches_python_builders(seed):
     one = np.array([0], dtype=np.int64), np.array([1], dtype=np.int64)
     assert lib.dl_host_csr_from_edges(one[0].ctypes.data, one[1].ctypes.data, 1, 3, 0, C.byref(_lib.DlHostCsr())) == -1
     assert b"not symmetric" in lib.dl_last_error()
+
+
+def test_module_copies_and_pickles_without_its_caches():
+    import copy
+    import io
+    from disenlink_amd.model import Disentangle
+    m = Disentangle(6, 5, 8, nfactor=3, beta=0.5)
+    m._graph_cache = (lambda: None, 0, None)                     # stands in for a live cache entry
+    c = copy.deepcopy(m)
+    assert c._graph_cache is None
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), c.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    x = torch.randn(4, 6)
+    assert torch.equal(c.project(x), m.project(x))               # the copy re-stacks its own parameters
