@@ -339,12 +339,8 @@ template <int D, bool VEC>
 static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float* x, int F, int nhid, const float* W1,
                       const float* b1, const float* W2, const float* b2, float* out) {
     using namespace project;
-    static bool attr_done = false;                         // > 64 KiB of dynamic LDS needs the attribute once
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)project2_lds(D));
-        attr_done = true;
-    }
+    static unsigned long long lds_done = 0;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>), project2_lds(D), lds_done);
     const dim3 grid((unsigned)xcd_grid((N + TN - 1) / TN, K * G));
     hipLaunchKernelGGL((project2_fwd_kernel<D, VEC>), grid, dim3(NTHR), project2_lds(D), st, x, N, F, nhid, W1, b1, W2, b2,
                        out, K, G, cpg);

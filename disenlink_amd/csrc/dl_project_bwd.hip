@@ -447,13 +447,9 @@ static void launchA_t(dim3 grid, hipStream_t st, const float* x, int N, int F, i
                       const float* b1, const float* W2, const float* dZ, int K, int tpr, float* dhid, float* dW2p,
                       float* db1p) {
     using namespace project;
-    static bool attr_done = false;
+    static unsigned long long lds_done = 0;
     constexpr size_t lds = project2_bwd_lds(D);
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC>), lds, lds_done);
     hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1, b1, W2, dZ,
                        K, tpr, dhid, dW2p, db1p);
 }
@@ -510,15 +506,10 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
         ldY = K * nhid;
     }
     {
-        static bool attr_done = false;
+        static unsigned long long lds_done_v = 0, lds_done_s = 0;
         const size_t lds = sizeof(float) * 4 * NC * LDC;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nodes_contract_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&nodes_contract_kernel<true>), lds, lds_done_v);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&nodes_contract_kernel<false>), lds, lds_done_s);
         const dim3 grid((unsigned)xcd_grid(L.sB * ceil_div(F, CT), ceil_div(L.Mb, CT) * K));
         const bool direct = L.sB == 1 && !blocked;                  // one range, one block: straight into dW1
         float* out = direct ? dW1 : w1p;

@@ -161,13 +161,9 @@ bool dense_mfma_supported(int d) { return d % 32 == 0; }
 template <int DC>
 static void launch_dense(const float* Z, const float* H, int N, int K, int d, float t, float* prob, hipStream_t st) {
     using namespace dense;
-    static bool attr_done = false;
+    static unsigned long long lds_done = 0;
     constexpr size_t lds = sizeof(float) * 4 * TT * (DC + 4);
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&score_allpairs_mfma_kernel<DC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&score_allpairs_mfma_kernel<DC>), lds, lds_done);
     const int nt = (N + TT - 1) / TT;
     const int items = nt * (nt + 1) / 2;
     hipLaunchKernelGGL(score_allpairs_mfma_kernel<DC>, dim3((unsigned)((items + 255) / 256 * 256)), dim3(DTHR), lds, st, Z, H,

@@ -9,6 +9,16 @@
 namespace dl {
 namespace project {
 
+// Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// device (the attribute lives with the device's code object): `done` is the caller's per-kernel bitmask of devices.
+inline void ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+    if (done & (1ull << dev)) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (dev != 63) done |= 1ull << dev;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
