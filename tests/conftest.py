@@ -21,6 +21,16 @@ def golden_case_names():
     return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "case_*.npz")))
 
 
+def trajectory_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "traj_*.npz")))
+
+
+def load_trajectory(name):
+    g = dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False))
+    g["meta"] = json.loads(str(g["meta"]))
+    return g
+
+
 def load_golden(name):
     g = dict(np.load(os.path.join(GOLDEN_DIR, f"case_{name}.npz"), allow_pickle=False))
     g["meta"] = json.loads(str(g["meta"]))

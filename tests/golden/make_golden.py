@@ -137,6 +137,77 @@ def run_case(model_mod, spec, seed):
           f"saturated={nsat}/{n * n} max|grad|={gmax:.3e}")
 
 
+TRAJ = [
+    # name,       N,  F, K,  d, nhid, beta, t, x_scale, p_edge, m, epochs, lr
+    ("traj_k4",  90, 12, 4, 32,  16, 0.7, 1, 0.4, 0.06, 3, 8, 1e-2),
+    ("traj_k8", 120, 16, 8,  8,   1, 0.5, 1, 0.8, 0.05, 5, 8, 5e-3),
+]
+
+
+def run_trajectory(model_mod, spec, seed):
+    """A short run of the reference MODEL under the schedule of main_disentangled.py:150,191-219 (Adam with
+    weight decay 5e-4, full-batch epochs, validation AUC from the pre-step forward, best weights kept, test AUC
+    with them): pins loss / AUC trajectories, i.e. forward + backward + optimiser together."""
+    from copy import deepcopy
+    from sklearn.metrics import roc_auc_score
+    (name, n, f, k, d, nhid, beta, t, xs, p_edge, m, epochs, lr) = spec
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    rows = make_graph(rng, n, p_edge)
+    perm = rng.permutation(rows.shape[0])
+    n_tr, n_va = int(round(0.85 * rows.shape[0])), int(round(0.05 * rows.shape[0]))
+    tr, va, te = rows[perm[:n_tr]], rows[perm[n_tr:n_tr + n_va]], rows[perm[n_tr + n_va:]]
+    ori = dense01(rows, n)
+    adj_sym = ((dense01(tr, n) + dense01(tr, n).T) != 0).astype(np.float32)
+
+    def negatives(part):
+        out = []
+        for _ in range(m):
+            for (i, _j) in part:
+                cand = np.flatnonzero(ori[i] == 0)
+                cand = cand[cand != i] if (cand != i).any() else cand
+                out.append((i, int(rng.choice(cand))))
+        return np.array(out, dtype=np.int64)
+
+    masks = {"pos_train": dense01(tr, n), "neg_train": dense01(negatives(tr), n),
+             "val": np.minimum(dense01(va, n) + dense01(negatives(va), n), 1),
+             "test": np.minimum(dense01(te, n) + dense01(negatives(te), n), 1)}
+    x = (rng.standard_normal((n, f)) * xs).astype(np.float32)
+    model = model_mod.Disentangle(f, nhid, d, nfactor=k, beta=beta, t=t)
+    init = {key: v.detach().numpy().copy() for key, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=5e-4)
+    xt, at, ot = torch.from_numpy(x), torch.from_numpy(adj_sym), torch.from_numpy(ori)
+    mk = {key: torch.from_numpy(v) == 1 for key, v in masks.items()}
+    losses, aucs, best, kept = [], [], 0.0, None
+    for _ep in range(epochs):
+        _emb, pred = model(xt, at)
+        loss = (F.binary_cross_entropy(pred[mk["pos_train"]].unsqueeze(0), ot[mk["pos_train"]].unsqueeze(0))
+                + F.binary_cross_entropy(pred[mk["neg_train"]].unsqueeze(0), ot[mk["neg_train"]].unsqueeze(0)) / m)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        auc = roc_auc_score(ot[mk["val"]].numpy(), pred[mk["val"]].detach().numpy())
+        losses.append(loss.item())
+        aucs.append(auc)
+        if auc > best:
+            best, kept = auc, deepcopy(model.state_dict())
+    model.load_state_dict(kept)
+    _emb, pred = model(xt, at)
+    test_auc = roc_auc_score(ot[mk["test"]].numpy(), pred[mk["test"]].detach().numpy(), average="weighted")
+    out = dict(x=x, adj=adj_sym, ori_adj=ori, losses=np.array(losses, dtype=np.float64),
+               val_aucs=np.array(aucs, dtype=np.float64), test_auc=np.float64(test_auc),
+               meta=np.array(json.dumps(dict(name=name, N=n, F=f, K=k, d=d, nhid=nhid, beta=beta, t=t, m=m, seed=seed,
+                                             epochs=epochs, lr=lr))))
+    for key, v in masks.items():
+        out["mask__" + key] = v.astype(np.float32)
+    for key, v in init.items():
+        out["sd__" + key] = v
+    for key, v in kept.items():
+        out["best__" + key] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}: losses {losses[0]:.5f} -> {losses[-1]:.5f}, val auc {aucs[0]:.4f} -> {max(aucs):.4f}, test auc {test_auc:.4f}")
+
+
 def auc_cases():
     from sklearn.metrics import roc_auc_score
     rng = np.random.default_rng(7)
@@ -157,9 +228,13 @@ def main():
     sys.path.insert(0, REF)
     import model as model_mod  # the reference's model.py
     torch.set_num_threads(1)
-    for idx, spec in enumerate(CASES):
-        run_case(model_mod, spec, seed=100 + idx)
-    auc_cases()
+    only_traj = "--trajectories-only" in sys.argv             # the case_* / auc_* files are already committed
+    if not only_traj:
+        for idx, spec in enumerate(CASES):
+            run_case(model_mod, spec, seed=100 + idx)
+        auc_cases()
+    for idx, spec in enumerate(TRAJ):
+        run_trajectory(model_mod, spec, seed=300 + idx)
 
 
 if __name__ == "__main__":

@@ -424,6 +424,42 @@ def test_caches_follow_tensor_identity_not_addresses():
     assert not torch.equal(z1, z2)
 
 
+@pytest.mark.parametrize("name", __import__("conftest").trajectory_names())
+def test_dropin_module_follows_the_reference_training_trajectory(name):
+    """The reference's own loop (model(x, adj_sym), dense masks, Adam, main_disentangled.py:150,191-219) around the
+    drop-in module, against trajectories recorded from the reference model: losses, validation AUCs, test AUC."""
+    import torch.nn.functional as F
+    from conftest import load_trajectory
+    from disenlink_amd.model import Disentangle
+    g = load_trajectory(name)
+    m = g["meta"]
+    model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
+    model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")})
+    model = model.to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=m["lr"], weight_decay=5e-4)
+    x, adj, ori = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "adj", "ori_adj"))
+    mk = {k[6:]: torch.from_numpy(g[k]).to(DEV) for k in g if k.startswith("mask__")}
+    best, kept = 0.0, None
+    for ep in range(m["epochs"]):
+        model.train()
+        _emb, a_pred = model(x, adj)
+        loss = (F.binary_cross_entropy(a_pred[mk["pos_train"] == 1].unsqueeze(0), ori[mk["pos_train"] == 1].unsqueeze(0))
+                + F.binary_cross_entropy(a_pred[mk["neg_train"] == 1].unsqueeze(0), ori[mk["neg_train"] == 1].unsqueeze(0)) / m["m"])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        model.eval()
+        auc = metrics_ref.auc_tie_avg(ori[mk["val"] == 1].cpu().numpy(), a_pred[mk["val"] == 1].detach().cpu().numpy())
+        assert abs(loss.item() - g["losses"][ep]) <= 2e-4 * abs(g["losses"][ep]), (ep, loss.item(), g["losses"][ep])
+        assert abs(auc - g["val_aucs"][ep]) <= 2e-3, (ep, auc, g["val_aucs"][ep])
+        if auc > best:
+            best, kept = auc, {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(kept)
+    _emb, a_pred = model(x, adj)
+    test_auc = metrics_ref.auc_tie_avg(ori[mk["test"] == 1].cpu().numpy(), a_pred[mk["test"] == 1].detach().cpu().numpy())
+    assert abs(test_auc - float(g["test_auc"])) <= 5e-3
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops

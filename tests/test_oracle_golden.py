@@ -127,3 +127,35 @@ def test_c_restatement_matches_numpy_oracle_and_reference(golden):
     uu, vv = np.divmod(np.arange(N * N), N)
     prob = c_ref.score_pairs(Z, H, uu, vv, m["t"]).reshape(N, N)
     np.testing.assert_allclose(prob, g["link_pred"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").trajectory_names())
+def test_oracle_follows_the_reference_training_trajectory(name):
+    """tests/golden/traj_*.npz: the reference model under the reference's schedule (Adam, weight decay 5e-4,
+    validation AUC from the pre-step forward, best weights, test AUC).  The dense oracle + the build's own BCE
+    and AUC restatements must reproduce losses, AUCs and the kept weights."""
+    import torch
+    from conftest import load_trajectory
+    from oracle import dense_ref, metrics_ref
+    g = load_trajectory(name)
+    m = g["meta"]
+    sd = {k[4:]: torch.nn.Parameter(torch.from_numpy(v.copy())) for k, v in g.items() if k.startswith("sd__")}
+    opt = torch.optim.Adam(list(sd.values()), lr=m["lr"], weight_decay=5e-4)
+    x, adj, ori = (torch.from_numpy(g[k]) for k in ("x", "adj", "ori_adj"))
+    mk = {k[6:]: g[k] == 1 for k in g if k.startswith("mask__")}
+    best, kept = 0.0, None
+    for ep in range(m["epochs"]):
+        _emb, P = dense_ref.forward(x, adj, sd, m["beta"], m["t"])
+        loss = dense_ref.bce_pair_loss(P, ori, torch.from_numpy(g["mask__pos_train"]), torch.from_numpy(g["mask__neg_train"]), m["m"])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        auc = metrics_ref.auc_tie_avg(g["ori_adj"][mk["val"]], P.detach().numpy()[mk["val"]])
+        assert abs(loss.item() - g["losses"][ep]) <= 2e-5 * abs(g["losses"][ep]), (ep, loss.item(), g["losses"][ep])
+        assert abs(auc - g["val_aucs"][ep]) <= 1e-6, (ep, auc, g["val_aucs"][ep])
+        if auc > best:
+            best, kept = auc, {k: v.detach().clone() for k, v in sd.items()}
+    for k, v in kept.items():
+        np.testing.assert_allclose(v.numpy(), g["best__" + k], rtol=1e-4, atol=1e-6)
+    _emb, P = dense_ref.forward(x, adj, kept, m["beta"], m["t"])
+    assert abs(metrics_ref.auc_tie_avg(g["ori_adj"][mk["test"]], P.detach().numpy()[mk["test"]]) - float(g["test_auc"])) <= 1e-6
