@@ -5,7 +5,6 @@ as the sparse CPU baseline of bench.py on graphs the dense reference form cannot
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 

@@ -2,7 +2,6 @@
 """The reference's own call, model(x, adj_sym) -> (emb, link_pred [N,N]) (main_disentangled.py:194), on the
 drop-in module at squirrel size: wall time of forward and of forward + masked-BCE backward."""
 import os, sys, time
-import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from disenlink_amd.data import synthetic_graph

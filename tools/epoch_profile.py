@@ -1,4 +1,4 @@
-import os, sys, time, cProfile, pstats, io
+import os, sys, cProfile, pstats, io
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from disenlink_amd.data import synthetic_graph
