@@ -204,8 +204,10 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
 
 /* Dense scorer: replaces model.py:109-113 as written — prob[u][v] for ALL N*N ordered pairs (row-major
  * fp32 [N][N]), the link_pred the reference's caller indexes with dense masks (main_disentangled.py:195).
- * No pair list is materialised.  Its backward is dl_score_pairs_bwd over the entries whose gradient is
- * non-zero (the masked ones).  N*N must stay below 2^31 waves' worth of work: N <= 46340. */
+ * No pair list is materialised.  fp32 tables with d % 32 == 0 go to the matrix cores (two Gram products per
+ * factor, fp32 MFMA; only the tile pairs u <= v are computed and mirrored: prob is symmetric bit for bit);
+ * other shapes use the vector kernels.  Its backward is dl_score_pairs_bwd over the entries whose gradient is
+ * non-zero (the masked ones).  N*N must stay below 2^31: N <= 46340. */
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
                           float* prob, void* stream);
 
