@@ -58,9 +58,10 @@ EXPORTS = {
     "dl_workspace_bytes": (_z, [C.POINTER(DlCsrPlan), _i, _i]),
     "dl_project_supported": (_i, [_i]),
     "dl_project_fwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
-    "dl_project_fwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_project_hidden_floats": (_z, [_i, _i, _i]),
+    "dl_project_fwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_project_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
-    "dl_project_bwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_project_bwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _z, _P]),
     "dl_aggregate_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _z, _P]),
     "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P, _P]),

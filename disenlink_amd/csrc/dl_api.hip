@@ -124,8 +124,14 @@ size_t dl_project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, int 
     return project_fwd_workspace_bytes(N, K, nhid, d, two_layer != 0);
 }
 
+size_t dl_project_hidden_floats(int N, int K, int nhid) {
+    if (N <= 0 || K < 1 || nhid < 1) return 0;
+    return (size_t)K * nhid * (size_t)((N + 3) & ~3);
+}
+
 int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                   const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, void* stream) {
+                   const float* W2, const float* b2, float* Z, float* hid_out, void* ws, size_t ws_bytes,
+                   void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
     DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
@@ -134,7 +140,8 @@ int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const f
     if (N == 0) return DL_OK;
     DL_REQUIRE(x && W1 && b1 && Z, "NULL argument");
     DL_REQUIRE((long long)N * K * d < (1LL << 40) && (long long)128 * F < (1LL << 31), "projection sizes out of range");
-    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, ws, ws_bytes, (hipStream_t)stream);
+    DL_REQUIRE(hid_out == nullptr || W2 != nullptr, "hid_out is for the two-layer form only");
+    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, ws, ws_bytes, hid_out, (hipStream_t)stream);
 }
 
 size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer) {
@@ -143,8 +150,8 @@ size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int 
 }
 
 int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                   const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
-                   size_t ws_bytes, void* stream) {
+                   const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
+                   void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
     DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
@@ -165,7 +172,8 @@ int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d, const f
     const size_t need = project_bwd_workspace_bytes(N, F, K, two ? nhid : 1, d, two);
     DL_REQUIRE(ws != nullptr && ws_bytes >= need, "workspace too small: %zu < %zu bytes (dl_project_bwd_workspace_bytes)",
                ws_bytes, need);
-    return project_bwd(x, N, F, K, two ? nhid : 1, d, W1, b1, W2, dZ, dW1, db1, dW2, db2, ws, (hipStream_t)stream);
+    DL_REQUIRE(hid == nullptr || two, "hid is for the two-layer form only");
+    return project_bwd(x, N, F, K, two ? nhid : 1, d, W1, b1, W2, dZ, hid, dW1, db1, dW2, db2, ws, (hipStream_t)stream);
 }
 
 int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float t, uint8_t* p, float* a,

@@ -56,11 +56,11 @@ int pair_bce(const float* prob, const float* y, const float* w, int n, float* lo
 bool project_supported(int d);
 size_t project_fwd_workspace_bytes(int N, int K, int nhid, int d, bool two_layer);
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, hipStream_t st);
+                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st);
 // its backward (dl_project_bwd.hip): weight / bias gradients, W2 == nullptr for the single layer
 size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer);
 int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
-                hipStream_t st);
+                const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
+                void* ws, hipStream_t st);
 
 }  // namespace dl

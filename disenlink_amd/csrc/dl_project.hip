@@ -80,7 +80,8 @@ template <int D, bool VEC>
 __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ b2,
-                                                            float* __restrict__ out, int K, int G, int chunks_per_group) {
+                                                            float* __restrict__ out, int K, int G, int chunks_per_group,
+                                                            float* __restrict__ hid_out, int ldh) {
     constexpr int DT = D / 32;
     constexpr int FC = fwd_fc(D), LDT = FC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -194,6 +195,16 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                     hacc[ht][4 * g + 2] = fmaxf(hacc[ht][4 * g + 2] + bias[ht][g].z, 0.0f);
                     hacc[ht][4 * g + 3] = fmaxf(hacc[ht][4 * g + 3] + bias[ht][g].w, 0.0f);
                 }
+            if (hid_out != nullptr) {                           // keep the hidden layer for the backward: hidT[k][h][n]
+                const int n = n0 + wn * 32 + li;
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int h = hbase + ht * 32 + acc_row(r, half);
+                        if (h < nhid && n < N) hid_out[((size_t)k * nhid + h) * ldh + n] = hacc[ht][r];
+                    }
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 float4 wv[2][4];
@@ -337,18 +348,19 @@ size_t project_fwd_workspace_bytes(int N, int K, int nhid, int d, bool two_layer
 
 template <int D, bool VEC>
 static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float* x, int F, int nhid, const float* W1,
-                      const float* b1, const float* W2, const float* b2, float* out) {
+                      const float* b1, const float* W2, const float* b2, float* out, float* hid_out, int ldh) {
     using namespace project;
     static unsigned long long lds_done = 0;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>), project2_lds(D), lds_done);
     const dim3 grid((unsigned)xcd_grid((N + TN - 1) / TN, K * G));
     hipLaunchKernelGGL((project2_fwd_kernel<D, VEC>), grid, dim3(NTHR), project2_lds(D), st, x, N, F, nhid, W1, b1, W2, b2,
-                       out, K, G, cpg);
+                       out, K, G, cpg, hid_out, ldh);
 }
 
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, hipStream_t st) {
+                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st) {
     using namespace project;
+    const int ldh = (N + 3) & ~3;
     if (W2 == nullptr) {          // single Linear(F -> d): W1 is [K][d][F], b1 is [K][d]
         const dim3 grid((unsigned)((N + 127) / 128), (unsigned)K), block(256);
         if (d == 32) hipLaunchKernelGGL(project1_fwd_kernel<32>, grid, block, 0, st, x, N, F, W1, b1, Z, K);
@@ -365,8 +377,8 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
     const float* bias2 = G > 1 ? nullptr : b2;
 #define DL_P2(DD)                                                                                       \
     if (d == DD) {                                                                                      \
-        if (vec) launch2_t<DD, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out);             \
-        else launch2_t<DD, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out);                \
+        if (vec) launch2_t<DD, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);   \
+        else launch2_t<DD, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);      \
     }
     DL_P2(32) DL_P2(64) DL_P2(128)
 #undef DL_P2

@@ -41,11 +41,14 @@ constexpr int bwd_ht(int D) { return D <= 64 ? 2 : 1; }
 //   dW2 += dZ^T . hid                           A = dZ^T from LDS (b32), B = hid registers
 //   dhid = (dZ . W2^T) masked by hid > 0        A = dZ rows, B = W2^T rows, both b128 from LDS
 // VEC: F % 4 == 0 (x and W1 rows are sequences of aligned quads).
-template <int D, bool VEC>
+// RECOMPUTE = false: the forward kept the hidden layer (hidT [K][nhid][ldh], post-ReLU); it is read straight into the
+// B-operand registers (lane = hidden unit, 4 consecutive nodes per register quad) and layer 1 is not run again.
+template <int D, bool VEC, bool RECOMPUTE>
 __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     const float* __restrict__ x, int N, int F, int nhid, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ dZ, int K, int tiles_per_range,
-    float* __restrict__ dhid, float* __restrict__ dW2p, float* __restrict__ db1p) {
+    float* __restrict__ dhid, float* __restrict__ dW2p, float* __restrict__ db1p,
+    const float* __restrict__ hidT, int ldh, int hid_cols) {
     constexpr int DT = D / 32, HT = bwd_ht(D), HB = 64 * HT;
     constexpr int LDZ = D + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     const float* W1k = W1 + (size_t)k * nhid * F;
     const float* W2k = W2 + (size_t)k * D * nhid;
     const float* dZk = dZ + (size_t)k * D;         // row n at dZk + n*K*D
-    const int nfc = (F + BFC - 1) / BFC;
+    const int nfc = RECOMPUTE ? (F + BFC - 1) / BFC : 1;
     const int steps = my_tiles * nfc;
     const int hw0 = hc * HB + wh * 32 * HT;        // first hidden unit of this wave
 
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
     for (int ht = 0; ht < HT; ++ht) b1acc[ht] = 0.0f;
 
-    if (steps > 0) {
+    if (RECOMPUTE && steps > 0) {
         fetch(0);
         stash(0);
         if (steps > 1) fetch(1);
@@ -119,6 +122,22 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
         const bool last = fc == nfc - 1;
         const int n0 = (tile0 + tl) * TILE_N;
         if (last) zt.fetch(dZk + (size_t)n0 * K * D, K * D, N - n0, D, tid);      // consumed after the MFMAs below
+        float4 hq[HT][4];                                                          // kept hidden layer, quad g = nodes 8g+4*half..+3
+        if constexpr (!RECOMPUTE) {
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) {
+                const int h = hw0 + ht * 32 + li;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 32 + 8 * g + 4 * half;
+                    const bool ok = h < nhid && n + 3 < hid_cols;
+                    const float4 q = *reinterpret_cast<const float4*>(hidT + (ok ? ((size_t)k * nhid + h) * ldh + n : 0));
+                    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+                    hq[ht][g] = make_float4(mask_bits(q.x, m), mask_bits(q.y, m), mask_bits(q.z, m), mask_bits(q.w, m));
+                }
+            }
+        }
+        if constexpr (RECOMPUTE) {
         // hid[node][hidden] += x[node][f] . W1[hidden][f]: A = x rows of this node quarter, B = W1 rows
         const float* xb = xs + (s & 1) * TILE_N * LDB + (wn * 32 + li) * LDB + half * (BFC / 2);
         const float* wb = w1s + (s & 1) * HB * LDB + (wh * 32 * HT + li) * LDB + half * (BFC / 2);
@@ -153,15 +172,27 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
                 if (s + 2 < steps) fetch(s + 2);
             }
         }
+        }   // RECOMPUTE
         if (last) {
             // every wave is past the previous tile's use of dzs (barrier at the end of that step)
             zt.template stash<LDZ>(dzs, tid);
             __syncthreads();
             float hid[HT][16];
 #pragma unroll
-            for (int ht = 0; ht < HT; ++ht)
+            for (int ht = 0; ht < HT; ++ht) {
+                if constexpr (RECOMPUTE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hid[ht][r] = fmaxf(hacc[ht][r] + b1v[ht], 0.0f);
+                    for (int r = 0; r < 16; ++r) hid[ht][r] = fmaxf(hacc[ht][r] + b1v[ht], 0.0f);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        hid[ht][4 * g + 0] = hq[ht][g].x;
+                        hid[ht][4 * g + 1] = hq[ht][g].y;
+                        hid[ht][4 * g + 2] = hq[ht][g].z;
+                        hid[ht][4 * g + 3] = hq[ht][g].w;
+                    }
+                }
+            }
             // dW2[dd][hidden] += dZ[node][dd] . hid[node][hidden]: the k-pair of register r is the node pair
             // {acc_row(r,0), acc_row(r,1)} of this quarter
 #pragma unroll
@@ -392,7 +423,8 @@ static int bwd_block_rows(int N, int K, int nhid, bool two_layer) {
     return (int)std::min<long long>(N, rows);
 }
 
-static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer, bool blocked = false) {
+static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer, bool blocked = false,
+                            bool recompute = true) {
     BwdLayout L{};
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     // Node ranges per launch: enough workgroups to cover the 256 CUs (>= 256, at most ~1536 so the partial slabs
@@ -409,7 +441,7 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
     const int n_tiles = ceil_div(N, TILE_N), n_chunks = ceil_div(N, NC);
     L.Mb = two_layer ? nhid : d;
     const long long wgA = (long long)ceil_div(nhid, 64 * bwd_ht(d)) * K;
-    L.sA = pick(n_tiles, ceil_div(F, BFC), wgA, 24);
+    L.sA = pick(n_tiles, recompute ? ceil_div(F, BFC) : 3, wgA, 24);
     L.tiles_per_range = ceil_div(n_tiles, L.sA);
     L.sA = ceil_div(n_tiles, L.tiles_per_range);
     const long long wgB = (long long)ceil_div(L.Mb, CT) * ceil_div(F, CT) * K;
@@ -437,21 +469,25 @@ size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool tw
     using namespace project;
     const int R = bwd_block_rows(N, K, nhid, two_layer);
     const bool blocked = R < N;
-    size_t bytes = bwd_layout(R, F, K, nhid, d, two_layer, blocked).bytes;
-    if (blocked && N % R != 0) bytes = std::max(bytes, bwd_layout(N % R, F, K, nhid, d, two_layer, true).bytes);
+    size_t bytes = 0;
+    for (int recompute = 0; recompute < 2; ++recompute) {       // either form of the backward fits
+        bytes = std::max(bytes, bwd_layout(R, F, K, nhid, d, two_layer, blocked, recompute != 0).bytes);
+        if (blocked && N % R != 0)
+            bytes = std::max(bytes, bwd_layout(N % R, F, K, nhid, d, two_layer, true, recompute != 0).bytes);
+    }
     return bytes;
 }
 
-template <int D, bool VEC>
+template <int D, bool VEC, bool RECOMPUTE>
 static void launchA_t(dim3 grid, hipStream_t st, const float* x, int N, int F, int nhid, const float* W1,
                       const float* b1, const float* W2, const float* dZ, int K, int tpr, float* dhid, float* dW2p,
-                      float* db1p) {
+                      float* db1p, const float* hidT, int ldh, int hid_cols) {
     using namespace project;
     static unsigned long long lds_done = 0;
     constexpr size_t lds = project2_bwd_lds(D);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC>), lds, lds_done);
-    hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1, b1, W2, dZ,
-                       K, tpr, dhid, dW2p, db1p);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC, RECOMPUTE>), lds, lds_done);
+    hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC, RECOMPUTE>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1, b1,
+                       W2, dZ, K, tpr, dhid, dW2p, db1p, hidT, ldh, hid_cols);
 }
 
 struct SlabBatch {
@@ -468,11 +504,11 @@ struct SlabBatch {
 
 // One node block [row0, row0 + N) of the backward; acc: add to the gradients instead of overwriting them.
 static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                              const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2,
-                              void* ws, bool blocked, bool acc, hipStream_t st) {
+                              const float* W2, const float* dZ, const float* hidT, int ldh, int hid_cols, float* dW1,
+                              float* db1, float* dW2, float* db2, void* ws, bool blocked, bool acc, hipStream_t st) {
     using namespace project;
     const bool two = W2 != nullptr;
-    const BwdLayout L = bwd_layout(N, F, K, nhid, d, two, blocked);
+    const BwdLayout L = bwd_layout(N, F, K, nhid, d, two, blocked, hidT == nullptr);
     char* base = static_cast<char*>(ws);
     float* dhid = reinterpret_cast<float*>(base + L.off_dhid);
     float* w1p = reinterpret_cast<float*>(base + L.off_w1p);
@@ -495,8 +531,12 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
         const dim3 grid((unsigned)xcd_grid(L.sA, ceil_div(nhid, 64 * bwd_ht(d)) * K));
 #define DL_PA(DD)                                                                                               \
     if (d == DD) {                                                                                              \
-        if (vecA) launchA_t<DD, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p);  \
-        else launchA_t<DD, false>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p);      \
+        if (hidT) launchA_t<DD, true, false>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p,  \
+                                             b1p, hidT, ldh, hid_cols);                                          \
+        else if (vecA) launchA_t<DD, true, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid,   \
+                                                 w2p, b1p, nullptr, 0, 0);                                       \
+        else launchA_t<DD, false, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p, \
+                                        nullptr, 0, 0);                                                          \
     }
         DL_PA(32) DL_PA(64) DL_PA(128)
 #undef DL_PA
@@ -523,14 +563,16 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
 }
 
 int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* dZ, float* dW1, float* db1, float* dW2, float* db2, void* ws,
-                hipStream_t st) {
+                const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
+                void* ws, hipStream_t st) {
     const bool two = W2 != nullptr;
     const int R = project::bwd_block_rows(N, K, nhid, two);
     const bool blocked = R < N;
+    const int ldh = (N + 3) & ~3;                               // row stride of the kept hidden layer hidT [K][nhid][ldh]
     for (int row0 = 0; row0 < N; row0 += R)
         project_bwd_block(x + (size_t)row0 * F, std::min(R, N - row0), F, K, nhid, d, W1, b1, W2,
-                          dZ + (size_t)row0 * K * d, dW1, db1, dW2, db2, ws, blocked, row0 > 0, st);
+                          dZ + (size_t)row0 * K * d, (two && hid) ? hid + row0 : nullptr, ldh, ldh - row0, dW1, db1, dW2,
+                          db2, ws, blocked, row0 > 0, st);
     return check_launch("project_bwd");
 }
 

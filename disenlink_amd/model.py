@@ -50,11 +50,11 @@ class Disentangle(nn.Module):
         ``table_dtype``: storage type of the gathered Z / H tables in ``forward_pairs`` — torch.float32
         (reference precision) or torch.bfloat16 (half the gather bytes, fp32 arithmetic and gradients).
         ``projection``: "mfma" = the fused fp32 MFMA kernels of libdisenlink_hip.so (forward and backward; the hidden
-        layer never reaches HBM and is recomputed in the backward), "library" = library GEMMs (rocBLAS through torch,
-        hidden layer kept for the backward), "auto" = the kernels where the epoch measured faster with them: narrow
-        features (F <= 256), where fusing bias/ReLU/layer 2 outweighs recomputing layer 1; for wide features layer 1
-        is one big plain GEMM and goes to the library (tools/epoch_time.py) — unless its [N,K,nhid]
-        activations would run to several GB, which the kernels never store."""
+        layer is written once, transposed, for the backward while it fits a few GB and recomputed beyond that),
+        "library" = library GEMMs (rocBLAS through torch), "auto" = the kernels where the epoch measured equal or
+        faster with them: F <= 1024 (squirrel epoch 2.13 vs 2.16 ms at F=512, 2.77 vs 2.75 at 1024, 3.64 vs 3.40 at
+        2089: there layer 1 is one big plain GEMM and the library's is ~10 % faster; tools/epoch_time.py, DESIGN.md
+        §3) — and whenever the library path's [N,K,nhid] activations would run to several GB."""
         super().__init__()
         if projection not in ("auto", "mfma", "library"):
             raise ValueError("projection must be 'auto', 'mfma' or 'library'")
@@ -144,7 +144,7 @@ class Disentangle(nn.Module):
             # measured: tools/epoch_time.py; past a few GB the library path's [N,K,nhid] activations
             # (kept for its backward) are what decides: the kernels never materialise them
             hidden_bytes = x.shape[0] * K * (1 if self.single_layer else fs[0].mlp1.out_features) * 4
-            use_kernel = x.shape[1] <= 256 or hidden_bytes > (4 << 30)
+            use_kernel = x.shape[1] <= 1024 or hidden_bytes > (4 << 30)
         if use_kernel:
             flat = self._stacked_params()
             if flat is not None:                                # zero-copy: the kernel reads the shared buffers

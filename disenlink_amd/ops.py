@@ -242,9 +242,21 @@ def _pad_features(x, W1):
     return hit[2], torch.nn.functional.pad(W1, (0, Fp - F))
 
 
-def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True) -> torch.Tensor:
+def keep_hidden(N: int, F: int, K: int, nhid: int) -> bool:
+    """Should the forward keep the hidden layer for the backward?  Recomputing it costs 2*F FLOP per hidden unit
+    against 8 bytes of traffic: measured faster at every width tried (F = 128: fwd+bwd 0.35 -> 0.30 ms, F = 2089:
+    2.9 -> 2.0 ms, tools/project_keep_times.py) — while the [K,nhid,N] buffer stays within a few GB (past that
+    the recompute is what keeps large graphs in memory)."""
+    mode = os.environ.get("DL_KEEP_HIDDEN", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    return N * K * nhid * 4 <= (8 << 30)
+
+
+def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True, keep_hid: bool = False):
     """Z [N,K,d] = K MLPs of x on the matrix cores.  Two-layer: W1 [K,nhid,F], b1 [K,nhid], W2 [K,d,nhid],
-    b2 [K,d]; single layer: W1 [K,d,F], b1 [K,d], W2 = b2 = None.  model.py:13-15 / 24-27 / 106."""
+    b2 [K,d]; single layer: W1 [K,d,F], b1 [K,d], W2 = b2 = None.  model.py:13-15 / 24-27 / 106.
+    keep_hid=True (two-layer): returns (Z, hid) with hid the kept hidden layer for project_bwd."""
     lib = _lib.load()
     x, W1, b1 = _f32c(x), _f32c(W1), _f32c(b1)
     _need_cuda(x, W1, b1)
@@ -264,15 +276,20 @@ def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True) -> torch.Tensor:
     if W1.shape[2] != F:
         raise ValueError("W1 does not match the feature count of x")
     Z = torch.empty((N, K, d), dtype=torch.float32, device=x.device)
+    hid = None
+    if keep_hid and W2 is not None:
+        hid = torch.empty(int(lib.dl_project_hidden_floats(N, K, nhid)), dtype=torch.float32, device=x.device)
     ws = _ws.get(int(lib.dl_project_fwd_workspace_bytes(N, F, K, nhid, d, int(W2 is not None))), x.device)
     _lib.check(lib.dl_project_fwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(), w2p, b2p,
-                                  Z.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_project_fwd")
-    return Z
+                                  Z.data_ptr(), hid.data_ptr() if hid is not None else None, ws.data_ptr(), ws.numel(),
+                                  _stream()), "dl_project_fwd")
+    return (Z, hid) if keep_hid else Z
 
 
-def project_bwd(x, W1, b1, W2, dZ, pad: bool = True):
+def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
     """Weight / bias gradients of the projection from dZ [N,K,d]: (dW1, db1, dW2, db2), shaped like the weights
-    (dW2 = db2 = None for the single layer).  autograd of model.py:13-15 / 24-27."""
+    (dW2 = db2 = None for the single layer).  autograd of model.py:13-15 / 24-27.  hid: the hidden layer kept
+    by project_fwd(keep_hid=True), else it is recomputed."""
     lib = _lib.load()
     x, W1, b1, dZ = _f32c(x), _f32c(W1), _f32c(b1), _f32c(dZ)
     _need_cuda(x, W1, b1, dZ)
@@ -296,7 +313,8 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True):
     db2 = torch.empty((K, d), dtype=torch.float32, device=x.device) if two else None
     ws = _ws.get(int(lib.dl_project_bwd_workspace_bytes(N, F, K, nhid, d, int(two))), x.device)
     _lib.check(lib.dl_project_bwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
-                                  W2.data_ptr() if two else None, dZ.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
+                                  W2.data_ptr() if two else None, dZ.data_ptr(),
+                                  hid.data_ptr() if (two and hid is not None) else None, dW1.data_ptr(), db1.data_ptr(),
                                   dW2.data_ptr() if two else None, db2.data_ptr() if two else None,
                                   ws.data_ptr(), ws.numel(), _stream()), "dl_project_bwd")
     if F != F_true:
@@ -318,12 +336,18 @@ class Project(torch.autograd.Function):
     def forward(ctx, x, W1, b1, W2, b2):
         ctx.save_for_backward(x, W1, b1, W2 if W2 is not None else x.new_empty(0))
         ctx.two_layer = W2 is not None
+        keep = ctx.two_layer and any(ctx.needs_input_grad) and keep_hidden(x.shape[0], x.shape[1], W1.shape[0], W1.shape[1])
+        if keep:
+            Z, ctx.hid = project_fwd(x, W1, b1, W2, b2, keep_hid=True)
+            return Z
+        ctx.hid = None
         return project_fwd(x, W1, b1, W2, b2)
 
     @staticmethod
     def backward(ctx, dZ):
         x, W1, b1, W2 = ctx.saved_tensors
-        dW1, db1, dW2, db2 = _project_grads(x, W1, b1, W2 if ctx.two_layer else None, dZ.contiguous())
+        dW1, db1, dW2, db2 = _project_grads(x, W1, b1, W2 if ctx.two_layer else None, dZ.contiguous(), ctx.hid)
+        ctx.hid = None
         return None, dW1, db1, dW2, db2
 
 
@@ -347,11 +371,11 @@ class RouteAggregate(torch.autograd.Function):
         return dZ, None, None, None
 
 
-def _project_grads(x, W1, b1, W2, dZ):
+def _project_grads(x, W1, b1, W2, dZ, hid=None):
     """Backward of the projection on stacked weights -> (dW1, db1, dW2, db2): the MFMA kernels of
     dl_project_bwd (env DL_PROJECT_BWD=library selects the library-GEMM form kept for timing comparisons)."""
     if os.environ.get("DL_PROJECT_BWD", "native") != "library":
-        return project_bwd(x, W1, b1, W2, dZ)
+        return project_bwd(x, W1, b1, W2, dZ, hid=hid)
     if W2 is None:                                              # Z[n,k,:] = W1[k] x[n] + b1[k]
         return torch.einsum("nkd,nf->kdf", dZ, x), dZ.sum(dim=0), None, None
     pre = torch.einsum("nf,khf->nkh", x, W1) + b1               # [N,K,nhid]
@@ -371,13 +395,18 @@ class ProjectStacked(torch.autograd.Function):
         W1, b1, W2, b2 = bufs
         ctx.bufs, ctx.K = bufs, K
         ctx.save_for_backward(x)
+        ctx.hid = None
+        if W2 is not None and any(ctx.needs_input_grad) and keep_hidden(x.shape[0], x.shape[1], K, W1.shape[1]):
+            Z, ctx.hid = project_fwd(x, W1, b1, W2, b2, keep_hid=True)
+            return Z
         return project_fwd(x, W1, b1, W2, b2)
 
     @staticmethod
     def backward(ctx, dZ):
         (x,) = ctx.saved_tensors
         W1, b1, W2, b2 = ctx.bufs
-        dW1, db1, dW2, db2 = _project_grads(x, W1, b1, W2, dZ.contiguous())
+        dW1, db1, dW2, db2 = _project_grads(x, W1, b1, W2, dZ.contiguous(), ctx.hid)
+        ctx.hid = None
         K = ctx.K
         grads = list(dW1.unbind(0)) + list(db1.unbind(0))
         if W2 is not None:

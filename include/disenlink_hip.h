@@ -157,9 +157,13 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
  * small) one workgroup walks the whole hidden layer — same result up to summation order, less parallelism. */
 int dl_project_supported(int d);
 size_t dl_project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer);
+/* hid_out (optional, two-layer form, dl_project_hidden_floats(N, K, nhid) floats): keep the hidden layer
+ * relu(W1 x + b1), laid out hidT [K][nhid][(N+3)&~3], for dl_project_bwd — worth its 8 bytes of traffic per
+ * hidden unit from F of about 150 up; NULL = the backward recomputes it (no [N,K,nhid] memory at all). */
+size_t dl_project_hidden_floats(int N, int K, int nhid);
 int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d,
                    const float* W1, const float* b1, const float* W2, const float* b2,
-                   float* Z, void* ws, size_t ws_bytes, void* stream);
+                   float* Z, float* hid_out, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of the projection: replaces autograd of model.py:13-15 / 24-27 under loss.backward()
  * (main_disentangled.py:198).  dZ fp32 [N][K][d] in; weight and bias gradients out, shaped like the weights
@@ -171,6 +175,7 @@ int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d,
 size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer);
 int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d,
                    const float* W1, const float* b1, const float* W2, const float* dZ,
+                   const float* hid /* hid_out of the forward, or NULL = recompute */,
                    float* dW1, float* db1, float* dW2, float* db2,
                    void* ws, size_t ws_bytes, void* stream);
 

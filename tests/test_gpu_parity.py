@@ -663,6 +663,13 @@ def test_projection_backward_kernels(N, F, K, nhid, d):
             scale = float(want.abs().max())
             err = float((got.cpu().double() - want).abs().max())
             assert err <= 2e-5 * scale, (name, pad, err, scale)
+    if two:                                    # backward from the KEPT hidden layer: same gradients, no recompute
+        Zk, hid = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], torch.zeros(K, d, device=DEV), keep_hid=True)
+        kept = ops.project_bwd(*dev, hid=hid)
+        for name, got, want in zip(("dW1", "db1", "dW2", "db2"), kept, ref):
+            err = float((got.cpu().double() - want).abs().max())
+            assert err <= 2e-5 * float(want.abs().max()), (name, "kept hidden layer", err)
+        assert torch.equal(Zk, ops.project_fwd(dev[0], dev[1], dev[2], dev[3], torch.zeros(K, d, device=DEV)))
     if two:                                    # forward, both load paths, against fp64
         Zref = torch.einsum("nkh,kdh->nkd", (torch.einsum("nf,khf->nkh", x.double(), W1.double()) + b1.double()).clamp_min(0),
                             W2.double())
@@ -686,6 +693,9 @@ def test_projection_backward_in_node_blocks(monkeypatch):
     whole = ops.project_bwd(*dev)
     monkeypatch.setenv("DL_BWD_BLOCK_BYTES", str(1 << 20))          # 4096-row blocks: 4096 + 4096 + 1808
     blocks = ops.project_bwd(*dev)
+    _Z, hid = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], torch.zeros(K, d, device=DEV), keep_hid=True)
+    for name, a, b in zip(("dW1", "db1", "dW2", "db2"), whole, ops.project_bwd(*dev, hid=hid)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (name, "kept hidden layer, node blocks")
     for name, a, b in zip(("dW1", "db1", "dW2", "db2"), whole, blocks):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
 
@@ -727,10 +737,10 @@ def test_projection_backward_rejects_bad_arguments():
         ops.project_bwd(x, W1, b1, None, dZ[:, :1])
     lib = _lib.load()
     out = torch.empty_like(W1)
-    rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 32, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(),
+    rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 32, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(), None,
                             out.data_ptr(), b1.data_ptr(), None, None, None, 0, None)
     assert rc != 0 and b"workspace" in lib.dl_last_error()
-    rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 48, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(),
+    rc = lib.dl_project_bwd(x.data_ptr(), 10, 8, 2, 1, 48, W1.data_ptr(), b1.data_ptr(), None, dZ.data_ptr(), None,
                             out.data_ptr(), b1.data_ptr(), None, None, None, 0, None)
     assert rc != 0 and b"32, 64, 128" in lib.dl_last_error()
 
