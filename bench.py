@@ -271,12 +271,19 @@ def main():
         Fx, nh = x.shape[1], W1.shape[1]
         t_f = ev_time(lambda: ops.project_fwd(x, W1, b1, W2, b2))
         t_b = ev_time(lambda: ops.project_bwd(x, W1, b1, W2, gZ))
+        _Zk, hid_kept = ops.project_fwd(x, W1, b1, W2, b2, keep_hid=True)
+        t_fk = ev_time(lambda: ops.project_fwd(x, W1, b1, W2, b2, keep_hid=True))
+        t_bk = ev_time(lambda: ops.project_bwd(x, W1, b1, W2, gZ, hid=hid_kept))
         fl_f = 2.0 * N * K * nh * (Fx + d)
         fl_b = 2.0 * N * K * nh * (2 * Fx + 2 * d)              # recomputed layer 1, dW1, dhid, dW2
+        fl_bk = 2.0 * N * K * nh * (Fx + 2 * d)                 # kept hidden layer: dW1, dhid, dW2
         proj = {"bound": "mfma", "dtype": "f32", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "shape": {"N": N, "F": Fx, "K": K, "nhid": nh, "d": d},
                 "fwd": {"avg_us": t_f * 1e6, "achieved": fl_f / t_f / 1e12, "frac": fl_f / t_f / 1e12 / FP32_MFMA_PEAK_TFLOPS},
-                "bwd": {"avg_us": t_b * 1e6, "achieved": fl_b / t_b / 1e12, "frac": fl_b / t_b / 1e12 / FP32_MFMA_PEAK_TFLOPS}}
+                "bwd": {"avg_us": t_b * 1e6, "achieved": fl_b / t_b / 1e12, "frac": fl_b / t_b / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+                "fwd_keeping_hidden": {"avg_us": t_fk * 1e6},
+                "bwd_from_kept_hidden": {"avg_us": t_bk * 1e6, "achieved": fl_bk / t_bk / 1e12,
+                                         "frac": fl_bk / t_bk / 1e12 / FP32_MFMA_PEAK_TFLOPS}}
 
     # extra: the dense [N,N] scorer of the drop-in forward (model.py:109-113 as written): Gram products on MFMA
     dense = None
