@@ -228,6 +228,7 @@ def main():
     kernels = {n: dict(avg_us=ktime[n] * 1e6, algorithmic_bytes=abytes[n],
                        achieved_GBs=abytes[n] / ktime[n] / 1e9, frac=abytes[n] / ktime[n] / 1e9 / HBM_PEAK_GBS)
                for n in names}
+    kernels["score"]["pairs_per_s"] = P / ktime["score"]                  # P / t_score
     dom = max(names, key=lambda n: ktime[n])
     scatter_t = ktime["route"] + ktime["aggregate"]
     scatter_b = abytes["route"] + abytes["aggregate"]
