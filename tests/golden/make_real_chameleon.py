@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Real-data parity fixture: the reference MODEL trained on the real chameleon graph (BASELINE.json config
+"chameleon, K=8, d=64, fp32") under the reference's schedule, on the split of disenlink_amd.splits.
+
+Run (this container only; needs /root/reference):  python tests/golden/make_real_chameleon.py
+
+Writes tests/golden/real_chameleon.npz: the dataset arrays of the reference's
+data_pre_false/chameleon/raw/chameleon.npz that the run uses (features fp32 [2277,128], edge rows as uint16
+[72202,2] — data, not code) and what the reference model produced: per-epoch loss and validation AUC
+(sklearn.roc_auc_score), test AUC with the best weights.  The model is initialised from torch.manual_seed(SEED)
+(same creation order in the drop-in module, so the same weights); the split comes from make_link_split(seed=0).
+"""
+import json
+import os
+import sys
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "real_chameleon.npz")
+SEED, K, D, NHID, BETA, T, M, LR, EPOCHS = 7, 8, 64, 512, 0.5, 1, 5, 1e-4, 30
+
+
+def dense(u, v, n):
+    a = np.zeros((n, n), dtype=np.float32)
+    a[u, v] = 1.0
+    return a
+
+
+def main():
+    from sklearn.metrics import roc_auc_score
+    from disenlink_amd.datasets import standardise_rows
+    from disenlink_amd.splits import make_link_split
+    sys.path.insert(0, REF)
+    import model as ref_model                                    # the reference's model.py
+    raw = np.load(os.path.join(REF, "data_pre_false/chameleon/raw/chameleon.npz"), allow_pickle=True)
+    feats, edges = np.asarray(raw["features"], np.float32), np.asarray(raw["edges"], np.int64)
+    n = feats.shape[0]
+    x = standardise_rows(feats)
+    split = make_link_split(edges[:, 0], edges[:, 1], n, m=M, seed=0)
+    ori = dense(edges[:, 0], edges[:, 1], n)
+    adj = dense(split.train_src, split.train_dst, n)
+    adj_sym = ((adj + adj.T) != 0).astype(np.float32)
+    masks = {"pos": dense(split.pos_train.u, split.pos_train.v, n) == 1, "neg": dense(split.neg_train.u, split.neg_train.v, n) == 1,
+             "val": dense(split.val.u, split.val.v, n) == 1, "test": dense(split.test.u, split.test.v, n) == 1}
+    torch.manual_seed(SEED)
+    model = ref_model.Disentangle(feats.shape[1], NHID, D, nfactor=K, beta=BETA, t=T)
+    opt = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=5e-4)
+    xt, at, ot = torch.from_numpy(x), torch.from_numpy(adj_sym), torch.from_numpy(ori)
+    mk = {k: torch.from_numpy(v) for k, v in masks.items()}
+    losses, aucs, best, kept = [], [], 0.0, None
+    for ep in range(EPOCHS):
+        t0 = time.perf_counter()
+        _emb, pred = model(xt, at)
+        loss = (F.binary_cross_entropy(pred[mk["pos"]].unsqueeze(0), ot[mk["pos"]].unsqueeze(0))
+                + F.binary_cross_entropy(pred[mk["neg"]].unsqueeze(0), ot[mk["neg"]].unsqueeze(0)) / M)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        auc = roc_auc_score(ot[mk["val"]].numpy(), pred[mk["val"]].detach().numpy())
+        losses.append(loss.item())
+        aucs.append(auc)
+        if auc > best:
+            best, kept = auc, deepcopy(model.state_dict())
+        print(f"epoch {ep}: loss {loss.item():.6f} val auc {auc:.6f} ({time.perf_counter() - t0:.1f} s)", flush=True)
+    model.load_state_dict(kept)
+    _emb, pred = model(xt, at)
+    test_auc = roc_auc_score(ot[mk["test"]].numpy(), pred[mk["test"]].detach().numpy(), average="weighted")
+    meta = dict(seed=SEED, K=K, d=D, nhid=NHID, beta=BETA, t=T, m=M, lr=LR, epochs=EPOCHS, split_seed=0, N=n,
+                n_pos=int(split.pos_train.u.size), n_neg=int(split.neg_train.u.size), n_val=int(split.val.u.size),
+                n_test=int(split.test.u.size))
+    np.savez_compressed(OUT, features=feats, edges=edges.astype(np.uint16), losses=np.array(losses), val_aucs=np.array(aucs),
+                        test_auc=np.float64(test_auc), meta=np.array(json.dumps(meta)))
+    print("test auc", test_auc, "->", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -159,3 +159,43 @@ def test_oracle_follows_the_reference_training_trajectory(name):
         np.testing.assert_allclose(v.numpy(), g["best__" + k], rtol=1e-4, atol=1e-6)
     _emb, P = dense_ref.forward(x, adj, kept, m["beta"], m["t"])
     assert abs(metrics_ref.auc_tie_avg(g["ori_adj"][mk["test"]], P.detach().numpy()[mk["test"]]) - float(g["test_auc"])) <= 1e-6
+
+
+def test_oracle_on_the_real_chameleon_fixture():
+    """tests/golden/real_chameleon.npz (real dataset arrays + the reference model's trajectory): the dense oracle,
+    the build's split, row standardisation, seeded init, BCE and AUC restatements reproduce the reference's first
+    epochs on the real graph (3 epochs here: the dense [K,N,N] form takes seconds per epoch on CPU)."""
+    import json
+    import torch
+    from disenlink_amd.datasets import standardise_rows
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from oracle import dense_ref, metrics_ref
+    g = np.load(os.path.join(GOLDEN_DIR, "real_chameleon.npz"))
+    m = json.loads(str(g["meta"]))
+    feats, edges = g["features"], g["edges"].astype(np.int64)
+    n = feats.shape[0]
+    split = make_link_split(edges[:, 0], edges[:, 1], n, m=m["m"], seed=m["split_seed"])
+
+    def dense(u, v):
+        a = np.zeros((n, n), dtype=np.float32)
+        a[u, v] = 1.0
+        return a
+    ori = dense(edges[:, 0], edges[:, 1])
+    adj = dense(split.train_src, split.train_dst)
+    adj_sym = torch.from_numpy(((adj + adj.T) != 0).astype(np.float32))
+    pos, neg = torch.from_numpy(dense(split.pos_train.u, split.pos_train.v)), torch.from_numpy(dense(split.neg_train.u, split.neg_train.v))
+    val = dense(split.val.u, split.val.v) == 1
+    torch.manual_seed(m["seed"])
+    mod = Disentangle(feats.shape[1], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])   # parameters only
+    sd = dict(mod.named_parameters())
+    opt = torch.optim.Adam(list(sd.values()), lr=m["lr"], weight_decay=5e-4)
+    x, ori_t = torch.from_numpy(standardise_rows(feats)), torch.from_numpy(ori)
+    for ep in range(3):
+        _emb, P = dense_ref.forward(x, adj_sym, sd, m["beta"], m["t"])
+        loss = dense_ref.bce_pair_loss(P, ori_t, pos, neg, m["m"])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - g["losses"][ep]) <= 2e-5 * g["losses"][ep], (ep, loss.item(), g["losses"][ep])
+        assert abs(metrics_ref.auc_tie_avg(ori[val], P.detach().numpy()[val]) - g["val_aucs"][ep]) <= 1e-6
