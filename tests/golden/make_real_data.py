@@ -2,11 +2,12 @@
 """Real-data parity fixture: the reference MODEL trained on the real chameleon graph (BASELINE.json config
 "chameleon, K=8, d=64, fp32") under the reference's schedule, on the split of disenlink_amd.splits.
 
-Run (this container only; needs /root/reference):  python tests/golden/make_real_chameleon.py
+Run (this container only; needs /root/reference):  python tests/golden/make_real_data.py
 
 Writes tests/golden/real_chameleon.npz: the dataset arrays of the reference's
 data_pre_false/chameleon/raw/chameleon.npz that the run uses (features fp32 [2277,128], edge rows as uint16
-[72202,2] — data, not code) and what the reference model produced: per-epoch loss and validation AUC
+[72202,2] — data, not code) — and tests/golden/real_cora.npz from the Planetoid files of data/cora/raw (binary
+features as index pairs, 10,556 edge rows; BASELINE.json's "Cora, K=4, d=32" config) — and what the reference model produced: per-epoch loss and validation AUC
 (sklearn.roc_auc_score), test AUC with the best weights.  The model is initialised from torch.manual_seed(SEED)
 (same creation order in the drop-in module, so the same weights); the split comes from make_link_split(seed=0).
 """
@@ -23,8 +24,9 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "real_chameleon.npz")
-SEED, K, D, NHID, BETA, T, M, LR, EPOCHS = 7, 8, 64, 512, 0.5, 1, 5, 1e-4, 30
+HERE = os.path.dirname(os.path.abspath(__file__))
+# name: (seed, K, d, nhid, beta, t, m, lr, epochs)   — BASELINE.json configs[1] (chameleon) and configs[0] (Cora)
+RUNS = {"chameleon": (7, 8, 64, 512, 0.5, 1, 5, 1e-4, 30), "cora": (11, 4, 32, 512, 0.6, 1, 5, 1e-3, 30)}
 
 
 def dense(u, v, n):
@@ -33,16 +35,25 @@ def dense(u, v, n):
     return a
 
 
-def main():
+def run(name, ref_model):
     from sklearn.metrics import roc_auc_score
-    from disenlink_amd.datasets import standardise_rows
+    from disenlink_amd.datasets import load_planetoid, standardise_rows
     from disenlink_amd.splits import make_link_split
-    sys.path.insert(0, REF)
-    import model as ref_model                                    # the reference's model.py
-    raw = np.load(os.path.join(REF, "data_pre_false/chameleon/raw/chameleon.npz"), allow_pickle=True)
-    feats, edges = np.asarray(raw["features"], np.float32), np.asarray(raw["edges"], np.int64)
+    SEED, K, D, NHID, BETA, T, M, LR, EPOCHS = RUNS[name]
+    OUT = os.path.join(HERE, f"real_{name}.npz")
+    if name == "chameleon":
+        raw = np.load(os.path.join(REF, "data_pre_false/chameleon/raw/chameleon.npz"), allow_pickle=True)
+        feats, edges = np.asarray(raw["features"], np.float32), np.asarray(raw["edges"], np.int64)
+        x = standardise_rows(feats)                              # main_disentangled.py:97-101
+        stored = dict(features=feats)
+    else:                                                        # Planetoid files, binary features, not standardised (:117-123)
+        ds = load_planetoid(os.path.join(REF, "data/cora/raw"), "cora")
+        feats, edges = ds.x, np.stack([ds.src, ds.dst], axis=1)
+        x = feats
+        r, c = np.nonzero(feats)
+        assert np.all(feats[r, c] == 1.0)
+        stored = dict(feat_row=r.astype(np.uint16), feat_col=c.astype(np.uint16), feat_shape=np.array(feats.shape))
     n = feats.shape[0]
-    x = standardise_rows(feats)
     split = make_link_split(edges[:, 0], edges[:, 1], n, m=M, seed=0)
     ori = dense(edges[:, 0], edges[:, 1], n)
     adj = dense(split.train_src, split.train_dst, n)
@@ -75,9 +86,16 @@ def main():
     meta = dict(seed=SEED, K=K, d=D, nhid=NHID, beta=BETA, t=T, m=M, lr=LR, epochs=EPOCHS, split_seed=0, N=n,
                 n_pos=int(split.pos_train.u.size), n_neg=int(split.neg_train.u.size), n_val=int(split.val.u.size),
                 n_test=int(split.test.u.size))
-    np.savez_compressed(OUT, features=feats, edges=edges.astype(np.uint16), losses=np.array(losses), val_aucs=np.array(aucs),
-                        test_auc=np.float64(test_auc), meta=np.array(json.dumps(meta)))
-    print("test auc", test_auc, "->", OUT, os.path.getsize(OUT), "bytes")
+    np.savez_compressed(OUT, edges=edges.astype(np.uint16), losses=np.array(losses), val_aucs=np.array(aucs),
+                        test_auc=np.float64(test_auc), meta=np.array(json.dumps(meta)), **stored)
+    print(name, "test auc", test_auc, "->", OUT, os.path.getsize(OUT), "bytes")
+
+
+def main():
+    sys.path.insert(0, REF)
+    import model as ref_model                                    # the reference's model.py
+    for name in (sys.argv[1:] or list(RUNS)):
+        run(name, ref_model)
 
 
 if __name__ == "__main__":

@@ -460,12 +460,14 @@ def test_dropin_module_follows_the_reference_training_trajectory(name):
     assert abs(test_auc - float(g["test_auc"])) <= 5e-3
 
 
-def test_real_chameleon_auc_parity_with_the_reference_model():
-    """BASELINE.json: "chameleon, K=8, d=64, fp32 ... AUC parity vs the CPU reference within 1e-4 on the same edge
-    splits".  tests/golden/real_chameleon.npz holds the real dataset arrays and what the reference model produced on
-    CPU (30 epochs of the reference schedule, make_real_chameleon.py).  Here: the same data, split and seeded
-    initial weights through (a) the drop-in module inside the reference's dense-mask loop and (b) the scalable
-    pair-list loop — per-epoch loss, validation AUC and the final test AUC."""
+@pytest.mark.parametrize("name", ["chameleon", "cora"])
+def test_real_data_auc_parity_with_the_reference_model(name):
+    """BASELINE.json: "chameleon, K=8, d=64, fp32" and "Cora, K=4, d=32" ... "AUC parity vs the CPU reference within
+    1e-4 on the same edge splits".  tests/golden/real_<name>.npz holds the real dataset arrays and what the reference
+    model produced on CPU (30 epochs of the reference schedule, make_real_data.py).  Here: the same data, split and
+    seeded initial weights through (a) the drop-in module inside the reference's dense-mask loop and (b) the scalable
+    pair-list loop — per-epoch loss, validation AUC and the final test AUC.  (Cora's 1,433 features take the
+    library-GEMM projection path, chameleon's 128 the MFMA kernels.)"""
     import json
     import os
     import torch.nn.functional as F
@@ -474,11 +476,17 @@ def test_real_chameleon_auc_parity_with_the_reference_model():
     from disenlink_amd.model import Disentangle
     from disenlink_amd.splits import make_link_split
     from disenlink_amd.train import prepare_run, run_link_prediction
-    g = np.load(os.path.join(GOLDEN_DIR, "real_chameleon.npz"))
+    g = np.load(os.path.join(GOLDEN_DIR, f"real_{name}.npz"))
     m = json.loads(str(g["meta"]))
-    feats, edges = g["features"], g["edges"].astype(np.int64)
+    edges = g["edges"].astype(np.int64)
+    if "features" in g:                                             # chameleon: rows standardised (main_disentangled.py:97-101)
+        feats = g["features"]
+        x = torch.from_numpy(standardise_rows(feats)).to(DEV)
+    else:                                                           # Cora: binary features as they are (:117-123)
+        feats = np.zeros(tuple(g["feat_shape"]), dtype=np.float32)
+        feats[g["feat_row"].astype(np.int64), g["feat_col"].astype(np.int64)] = 1.0
+        x = torch.from_numpy(feats).to(DEV)
     n = feats.shape[0]
-    x = torch.from_numpy(standardise_rows(feats)).to(DEV)
     split = make_link_split(edges[:, 0], edges[:, 1], n, m=m["m"], seed=m["split_seed"])
     assert (split.pos_train.u.size, split.neg_train.u.size, split.val.u.size, split.test.u.size) == \
         (m["n_pos"], m["n_neg"], m["n_val"], m["n_test"])
