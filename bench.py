@@ -28,9 +28,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 256 FLOP/clk/CU x 256 CUs x 2.4 GHz
 # kernel behind each timed phase (the name rocprofv3 reports) -> PMC summary of tools/pmc_traffic.py
-PHASE_KERNEL = {"route": "dl::fast::route_seg_kernel<8, 64, float>",
-                "aggregate": "dl::fast::aggregate_seg_kernel<8, 64, float>",
-                "score": "dl::fast::score_fwd_seg_kernel<8, 64, float, false>"}
+# kernels launched by each phase of the step (names as in the rocprofv3 traces); the combine kernels of a phase are
+# included at their per-launch average
+PHASE_KERNEL = {"route": ("dl::fast::route_seg_kernel<8, 64, float, true>", "dl::fast::s_rowsum_seg_kernel",
+                          "dl::fast::vec_combine_kernel"),
+                "aggregate": ("dl::fast::aggregate_seg_kernel<8, 64, float>", "dl::fast::row_combine_kernel<512, float, float>"),
+                "score": ("dl::fast::score_fwd_seg_kernel<8, 64, float, false>",)}
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 
 
@@ -39,7 +42,7 @@ def pmc_traffic(phase):
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; same command, same workload), or None."""
     try:
         table = json.load(open(PMC_SUMMARY))
-        return float(table[PHASE_KERNEL[phase]]["traffic_bytes"])
+        return float(sum(table[k]["traffic_bytes"] for k in PHASE_KERNEL[phase]))
     except (OSError, KeyError, ValueError):
         return None
 
@@ -229,6 +232,9 @@ def main():
                        achieved_GBs=abytes[n] / ktime[n] / 1e9, frac=abytes[n] / ktime[n] / 1e9 / HBM_PEAK_GBS)
                for n in names}
     kernels["score"]["pairs_per_s"] = P / ktime["score"]                  # P / t_score
+    default_case = args.workload == "squirrel" and K == 8 and d == 64 and args.dtype == "f32" and args.scale == 1.0
+    for n in names:                                                       # measured fabric-side bytes beside the algorithmic ones
+        kernels[n]["traffic"] = pmc_traffic(n) if default_case else None
     dom = max(names, key=lambda n: ktime[n])
     scatter_t = ktime["route"] + ktime["aggregate"]
     scatter_b = abytes["route"] + abytes["aggregate"]
@@ -321,13 +327,13 @@ def main():
                    and not args.force_generic},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": kernels[dom]["frac"],
-                     "traffic": pmc_traffic(dom) if (args.workload == "squirrel" and K == 8 and d == 64
-                                                     and args.dtype == "f32" and args.scale == 1.0) else None,
+                     "traffic": kernels[dom]["traffic"],
                      "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                        "separate passes of this command; bytes leaving the XCD L2s per launch)",
                      "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "avg_us": kernels[dom]["avg_us"]},
         "edge_scatter": {"kernels": "route+aggregate", "avg_us": scatter_t * 1e6, "algorithmic_bytes": scatter_b,
                          "achieved_GBs": scatter_b / scatter_t / 1e9, "frac": scatter_b / scatter_t / 1e9 / HBM_PEAK_GBS,
+                         "traffic": (kernels["route"]["traffic"] + kernels["aggregate"]["traffic"]) if default_case else None,
                          "edges_per_s": E / scatter_t},
         "kernels": kernels,
         "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},
