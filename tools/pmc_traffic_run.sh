@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: tools/pmc_traffic_run.sh <tag>  ->  gpurun_out/<tag>_pmc_traffic.json
+# Two separate rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE; --kernel-trace only) of the bench command,
+# summarised by tools/pmc_traffic.py.  Run from the repo root on the GPU box.
+set -u
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o out -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1 < /dev/null
+done
+f=$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -n 1)
+w=$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -n 1)
+if [ -z "$f" ] || [ -z "$w" ]; then echo "PMC output missing"; tail -n 5 /tmp/pmc_FETCH_SIZE.log; exit 1; fi
+python3 "$root/tools/pmc_traffic.py" "$f" "$w" "$root/gpurun_out/${tag}_pmc_traffic.json"
