@@ -26,7 +26,10 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 # name: (seed, K, d, nhid, beta, t, m, lr, epochs)   — BASELINE.json configs[1] (chameleon) and configs[0] (Cora)
-RUNS = {"chameleon": (7, 8, 64, 512, 0.5, 1, 5, 1e-4, 30), "cora": (11, 4, 32, 512, 0.6, 1, 5, 1e-3, 30)}
+RUNS = {"chameleon": (7, 8, 64, 512, 0.5, 1, 5, 1e-4, 30), "cora": (11, 4, 32, 512, 0.6, 1, 5, 1e-3, 30),
+        # squirrel: the real edge list (geom-gcn) with seeded N(0,1) features, F=128 — the feature blob is missing from
+        # the reference tree; BASELINE.json configs[2]
+        "squirrel": (13, 8, 64, 512, 0.5, 1, 5, 1e-4, 20)}
 
 
 def dense(u, v, n):
@@ -46,6 +49,13 @@ def run(name, ref_model):
         feats, edges = np.asarray(raw["features"], np.float32), np.asarray(raw["edges"], np.int64)
         x = standardise_rows(feats)                              # main_disentangled.py:97-101
         stored = dict(features=feats)
+    elif name == "squirrel":
+        from disenlink_amd.datasets import load_geom_gcn
+        ds = load_geom_gcn(os.path.join(REF, "data/squirrel/geom_gcn/raw/out1_graph_edges.txt"))
+        edges = np.stack([ds.src, ds.dst], axis=1)
+        feats = np.random.default_rng(SEED).standard_normal((ds.n_nodes, 128), dtype=np.float32)
+        x = standardise_rows(feats)
+        stored = dict(feat_seed=np.int64(SEED), feat_shape=np.array(feats.shape))
     else:                                                        # Planetoid files, binary features, not standardised (:117-123)
         ds = load_planetoid(os.path.join(REF, "data/cora/raw"), "cora")
         feats, edges = ds.x, np.stack([ds.src, ds.dst], axis=1)
