@@ -319,8 +319,8 @@ def main():
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.workload}-synthetic(seed 0): N={N}, edge rows={sg.src.size}, 85/5/10 split, "
+        "dtype": args.dtype, "data": "real edge rows, synthetic features" if args.workload.endswith("_real") else "synthetic",
+        "config": {"workload": f"{args.workload + ' (edge list of the parity fixture)' if args.workload.endswith('_real') else args.workload + '-synthetic'}(seed 0): N={N}, edge rows={sg.src.size}, 85/5/10 split, "
                                f"E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, beta={beta}, t={t}; "
                                "forward route+aggregate+score_pairs",
                    "K": K, "d": d, "n_nodes": N, "E_sym": E, "P": P, "fast_path": bool(lib.dl_has_fast_path(K, d))
