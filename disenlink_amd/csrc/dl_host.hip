@@ -78,7 +78,22 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
     DL_REQUIRE(n_rows >= 0 && n_total >= n_rows && seg_len >= 1 && n_col_slices >= 1, "bad plan size");
     DL_REQUIRE(n_rows == 0 || rowptr, "rowptr is NULL");
     const int32_t n_streams = std::min<int32_t>(n_col_slices, 8);
-    const int64_t width = std::max<int64_t>(1, ((int64_t)n_total + n_col_slices - 1) / n_col_slices);
+    // column slices = contiguous node ranges holding equal numbers of (kept) entries: boundaries at the quantiles of
+    // the kept columns, as graph.column_slices does (slice of c = number of boundaries <= c)
+    std::vector<int32_t> bounds;
+    if (n_col_slices > 1 && n_rows > 0) {
+        std::vector<int32_t> kept;
+        kept.reserve((size_t)rowptr[n_rows]);
+        for (int32_t e = 0; e < rowptr[n_rows]; ++e)
+            if (!keep || keep[e]) kept.push_back(col[e]);
+        std::sort(kept.begin(), kept.end());
+        const int64_t E = (int64_t)kept.size();
+        if (E > 0)
+            for (int32_t q = 1; q < n_col_slices; ++q) bounds.push_back(kept[(size_t)((int64_t)q * E / n_col_slices)]);
+    }
+    auto slice_of = [&](int32_t c) {
+        return (int32_t)(std::upper_bound(bounds.begin(), bounds.end(), c) - bounds.begin());
+    };
     struct Seg { int32_t row, beg, end, slice, idx_in_row; };
     std::vector<Seg> segs;
     std::vector<int32_t> nseg_row((size_t)n_rows, 0);
@@ -94,9 +109,9 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
         }
         int32_t pos = b, idx = 0;
         while (pos < e) {
-            const int32_t q = n_col_slices > 1 ? (int32_t)(col[pos] / width) : 0;
+            const int32_t q = n_col_slices > 1 ? slice_of(col[pos]) : 0;
             int32_t gend = pos;
-            while (gend < e && (n_col_slices == 1 || col[gend] / width == q)) {
+            while (gend < e && (n_col_slices == 1 || slice_of(col[gend]) == q)) {
                 DL_REQUIRE(gend == pos || col[gend] >= col[gend - 1] || n_col_slices == 1,
                            "sliced plans need col ascending inside every row");
                 ++gend;

@@ -132,8 +132,12 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
                     const int n = n0 + wn * 32 + 8 * g + 4 * half;
                     const bool ok = h < nhid && n + 3 < hid_cols;
                     const float4 q = *reinterpret_cast<const float4*>(hidT + (ok ? ((size_t)k * nhid + h) * ldh + n : 0));
-                    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
-                    hq[ht][g] = make_float4(mask_bits(q.x, m), mask_bits(q.y, m), mask_bits(q.z, m), mask_bits(q.w, m));
+                    // per element: the columns N .. ldh-1 of hidT are padding nobody wrote — whatever they hold
+                    // (possibly NaN bit patterns) must not meet the zero dZ rows of those nodes in an MFMA (0 * NaN)
+                    hq[ht][g] = make_float4(mask_bits(q.x, ok && n + 0 < N ? 0xFFFFFFFFu : 0u),
+                                            mask_bits(q.y, ok && n + 1 < N ? 0xFFFFFFFFu : 0u),
+                                            mask_bits(q.z, ok && n + 2 < N ? 0xFFFFFFFFu : 0u),
+                                            mask_bits(q.w, ok && n + 3 < N ? 0xFFFFFFFFu : 0u));
                 }
             }
         }

@@ -50,6 +50,23 @@ def _nkd(Z: torch.Tensor):
     return Z.shape[0], Z.shape[1], Z.shape[2]
 
 
+# DL_POISON=1 (tests): every buffer the kernels are expected to fill — outputs and the workspace — starts as
+# NaN bit patterns instead of whatever the allocator hands out, so a read of anything nobody wrote shows up as
+# a NaN in the result instead of depending on what happened to be in that memory.
+_POISON = os.environ.get("DL_POISON", "0") == "1"
+
+
+def _empty(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _POISON:
+        t.view(torch.uint8).fill_(0xFF) if t.numel() else None
+    return t
+
+
+def _empty_like(x):
+    return _empty(x.shape, x.dtype, x.device)
+
+
 class _Workspace:
     """Grow-only scratch per device; the C ABI never allocates."""
 
@@ -61,6 +78,8 @@ class _Workspace:
         if cur is None or cur.numel() < nbytes:
             cur = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=device)
             self.buf[device] = cur
+        if _POISON:
+            cur.fill_(0xFF)
         return cur
 
 
@@ -88,9 +107,9 @@ def route_fwd(g: Graph, Z: torch.Tensor, t: float, s_out: torch.Tensor | None = 
     Z, dt = _tab(Z)
     _need_cuda(Z, g.rowptr)
     N, K, d = _check_rows(g, Z)
-    p = torch.empty(g.n_edges, dtype=torch.uint8, device=Z.device)
-    a = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
-    s = torch.empty((N, K), dtype=torch.float32, device=Z.device) if s_out is None else s_out
+    p = _empty(g.n_edges, torch.uint8, Z.device)
+    a = _empty(g.n_edges, torch.float32, Z.device)
+    s = _empty((N, K), torch.float32, Z.device) if s_out is None else s_out
     ws = _workspace(g.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_route_fwd(g.c_struct(), Z.data_ptr(), K, d, dt, float(t), p.data_ptr(), a.data_ptr(),
                                 s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_route_fwd")
@@ -103,7 +122,7 @@ def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s, H_out: torch.
     Z, dt = _tab(Z)
     _need_cuda(Z, g.rowptr, p, a, s)
     N, K, d = _check_rows(g, Z)
-    H = torch.empty_like(Z) if H_out is None else H_out
+    H = _empty_like(Z) if H_out is None else H_out
     if H.dtype != Z.dtype:
         raise TypeError("H must have the storage type of Z")
     ws = _workspace(g.c_plan(), Z.device, K, d)
@@ -125,12 +144,12 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_
     if pu.dtype != torch.int32 or pv.dtype != torch.int32:
         raise TypeError("pair indices must be int32")
     P = int(pu.numel())
-    prob = torch.empty(P, dtype=torch.float32, device=Z.device)
+    prob = _empty(P, torch.float32, Z.device)
     by_u = pairs.c_struct_by_u() if pairs is not None else None
     # per-factor logit terms for the backward: only the tuned scorer produces them
     coef = None
     if want_coef and pairs is not None and lib.dl_has_fast_path_dtype(K, d, dt) and not lib.dl_set_force_generic(-1):
-        coef = torch.empty((2, P, K), dtype=torch.float32, device=Z.device)
+        coef = _empty((2, P, K), torch.float32, Z.device)
     _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), pu.data_ptr(), pv.data_ptr(),
                                       P, by_u, prob.data_ptr(), coef.data_ptr() if coef is not None else None,
                                       _stream()), "dl_score_pairs_fwd")
@@ -145,7 +164,7 @@ def score_allpairs_fwd(Z, H, t: float) -> torch.Tensor:
     N, K, d = _nkd(Z)
     if H.shape != Z.shape or dt != dth:
         raise ValueError("Z and H differ in shape or storage type")
-    prob = torch.empty((N, N), dtype=torch.float32, device=Z.device)
+    prob = _empty((N, N), torch.float32, Z.device)
     _lib.check(lib.dl_score_allpairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), prob.data_ptr(),
                                          _stream()), "dl_score_allpairs_fwd")
     return prob
@@ -159,8 +178,8 @@ def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, 
     N, K, d = _nkd(Z)
     if prob.numel() != g_prob.numel():
         raise ValueError("prob / g_prob lengths differ")
-    dZ = torch.empty(Z.shape, dtype=torch.float32, device=Z.device) if dZ_out is None else dZ_out
-    dH = torch.empty(Z.shape, dtype=torch.float32, device=Z.device) if dH_out is None else dH_out
+    dZ = _empty(Z.shape, torch.float32, Z.device) if dZ_out is None else dZ_out
+    dH = _empty(Z.shape, torch.float32, Z.device) if dH_out is None else dH_out
     inc = pairs.c_struct(int(prob.numel()))
     ws = _workspace(pairs.c_plan(), Z.device, K, d)
     if coef is not None and tuple(coef.shape) != (2, prob.numel(), K):
@@ -179,7 +198,7 @@ def route_aggregate_bwd(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_accu
     _need_cuda(Z, dH, g.rowptr, p, a, s)
     N, K, d = _check_rows(g, Z)
     if dZ_accum is None:
-        dZ, acc = torch.empty(Z.shape, dtype=torch.float32, device=Z.device), 0
+        dZ, acc = _empty(Z.shape, torch.float32, Z.device), 0
     else:
         if not dZ_accum.is_contiguous() or dZ_accum.shape != Z.shape or dZ_accum.dtype != torch.float32:
             raise ValueError("dZ_accum must be a contiguous fp32 [N,K,d] tensor")
@@ -197,8 +216,8 @@ def route_aggregate_bwd_phase1(g: Graph, Z, beta: float, p, a, s, dH, ds_out: to
     (Z, dt), dH = _tab(Z), _f32c(dH)
     _need_cuda(Z, dH, g.rowptr, p, a, s, ds_out)
     N, K, d = _check_rows(g, Z)
-    dw = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
-    dwr = torch.empty(g.n_edges, dtype=torch.float32, device=Z.device)
+    dw = _empty(g.n_edges, torch.float32, Z.device)
+    dwr = _empty(g.n_edges, torch.float32, Z.device)
     ws = _workspace(g.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_route_aggregate_bwd_phase1(g.c_struct(), Z.data_ptr(), K, d, dt, float(beta), p.data_ptr(),
                                                  a.data_ptr(), s.data_ptr(), dH.data_ptr(), dw.data_ptr(),
@@ -275,10 +294,10 @@ def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True, keep_hid: bool = 
             raise ValueError("inconsistent projection weight shapes")
     if W1.shape[2] != F:
         raise ValueError("W1 does not match the feature count of x")
-    Z = torch.empty((N, K, d), dtype=torch.float32, device=x.device)
+    Z = _empty((N, K, d), torch.float32, x.device)
     hid = None
     if keep_hid and W2 is not None:
-        hid = torch.empty(int(lib.dl_project_hidden_floats(N, K, nhid)), dtype=torch.float32, device=x.device)
+        hid = _empty(int(lib.dl_project_hidden_floats(N, K, nhid)), torch.float32, x.device)
     ws = _ws.get(int(lib.dl_project_fwd_workspace_bytes(N, F, K, nhid, d, int(W2 is not None))), x.device)
     _lib.check(lib.dl_project_fwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(), w2p, b2p,
                                   Z.data_ptr(), hid.data_ptr() if hid is not None else None, ws.data_ptr(), ws.numel(),
@@ -308,9 +327,9 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
         d, nhid = W1.shape[1], 1
     if dZ.shape != (N, K, d) or W1.shape[2] != F:
         raise ValueError("inconsistent projection shapes")
-    dW1, db1 = torch.empty_like(W1), torch.empty_like(b1)
-    dW2 = torch.empty_like(W2) if two else None
-    db2 = torch.empty((K, d), dtype=torch.float32, device=x.device) if two else None
+    dW1, db1 = _empty_like(W1), _empty_like(b1)
+    dW2 = _empty_like(W2) if two else None
+    db2 = _empty((K, d), torch.float32, x.device) if two else None
     ws = _ws.get(int(lib.dl_project_bwd_workspace_bytes(N, F, K, nhid, d, int(two))), x.device)
     _lib.check(lib.dl_project_bwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
                                   W2.data_ptr() if two else None, dZ.data_ptr(),
@@ -426,8 +445,8 @@ class PairBCE(torch.autograd.Function):
         _need_cuda(prob, label, weight)
         if not (prob.numel() == label.numel() == weight.numel()):
             raise ValueError("prob, label and weight differ in length")
-        loss = torch.empty(1, dtype=torch.float32, device=prob.device)
-        g = torch.empty_like(prob)
+        loss = _empty(1, torch.float32, prob.device)
+        g = _empty_like(prob)
         ws = _ws.get(2048, prob.device)
         _lib.check(lib.dl_pair_bce(prob.data_ptr(), label.data_ptr(), weight.data_ptr(), prob.numel(), loss.data_ptr(),
                                    g.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_pair_bce")

@@ -6,6 +6,11 @@ import sys
 import numpy as np
 import pytest
 
+# Every buffer the kernels are expected to fill (outputs, workspace) starts as NaN bit patterns in the tests
+# (disenlink_amd/ops.py, DL_POISON): a read of memory nobody wrote fails a test instead of passing or failing with
+# whatever the allocator happened to hand out.  Must be set before disenlink_amd.ops is imported.
+os.environ.setdefault("DL_POISON", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -576,8 +576,13 @@ def test_training_trajectory_matches_cpu_oracle():
     torch.manual_seed(1)
     ref_inner = Disentangle(F, nhid, d, nfactor=K, beta=0.7, t=1)
     sd = {k: v.clone() for k, v in ref_inner.state_dict().items()}
-    res_cpu = run_link_prediction(OraclePairModule(ref_inner), torch.from_numpy(x), prepare_run(split, "cpu"),
-                                  epochs=12, lr=1e-3)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                    # a reproducible CPU side: multi-threaded reductions vary run to run
+    try:
+        res_cpu = run_link_prediction(OraclePairModule(ref_inner), torch.from_numpy(x), prepare_run(split, "cpu"),
+                                      epochs=12, lr=1e-3)
+    finally:
+        torch.set_num_threads(threads)
     gpu = Disentangle(F, nhid, d, nfactor=K, beta=0.7, t=1)
     gpu.load_state_dict(sd)
     gpu = gpu.to(DEV)
@@ -586,8 +591,10 @@ def test_training_trajectory_matches_cpu_oracle():
     assert abs(res_gpu.val_aucs[0] - res_cpu.val_aucs[0]) <= 1e-4            # fixed weights: the hard gate
     for lg, lc in zip(res_gpu.losses[:4], res_cpu.losses[:4]):
         assert abs(lg - lc) <= 1e-3 * abs(lc)
-    assert abs(res_gpu.val_aucs[-1] - res_cpu.val_aucs[-1]) <= 5e-3
-    assert abs(res_gpu.test_auc - res_cpu.test_auc) <= 5e-3
+    # the end of a 12-epoch run on a tiny graph is a statistical statement (hard routing amplifies rounding); the
+    # tight end-to-end gates are the real-data trajectories recorded from the reference model (test_real_data_...)
+    assert abs(res_gpu.val_aucs[-1] - res_cpu.val_aucs[-1]) <= 1e-2
+    assert abs(res_gpu.test_auc - res_cpu.test_auc) <= 1e-2
     assert res_gpu.losses[-1] < res_gpu.losses[0]
 
 
@@ -743,6 +750,8 @@ def test_projection_backward_kernels(N, F, K, nhid, d):
             assert err <= 2e-5 * scale, (name, pad, err, scale)
     if two:                                    # backward from the KEPT hidden layer: same gradients, no recompute
         Zk, hid = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], torch.zeros(K, d, device=DEV), keep_hid=True)
+        ld = (N + 3) // 4 * 4                  # the padding columns of hidT [K][nhid][ld] belong to nobody: poison them
+        hid.view(K, nhid, ld)[:, :, N:] = float("nan")
         kept = ops.project_bwd(*dev, hid=hid)
         for name, got, want in zip(("dW1", "db1", "dW2", "db2"), kept, ref):
             err = float((got.cpu().double() - want).abs().max())

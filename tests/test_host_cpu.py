@@ -71,7 +71,14 @@ def _check_plan(plan, rowptr, seg_len, col_slices=None):
     seg_row, seg_beg, seg_end = plan.seg_row.numpy(), plan.seg_beg.numpy(), plan.seg_end.numpy()
     seg_slot, sl0 = plan.seg_slot.numpy(), plan.slice_seg0.numpy()
     col_slices = col_slices or plan.n_slices          # plan.n_slices = XCD streams; col_slices = column slices
-    width = max(1, -(-plan.n_total // col_slices))
+    # column slices hold equal numbers of the plan's entries: boundaries at the quantiles of the covered columns
+    covered = np.concatenate([col[b:e] for b, e in zip(seg_beg, seg_end)]) if plan.n_seg else np.zeros(0, col.dtype)
+    srt = np.sort(covered)
+    bounds = srt[(np.arange(1, col_slices) * srt.size) // col_slices] if srt.size and col_slices > 1 else np.zeros(0, col.dtype)
+    slice_of = lambda c: np.searchsorted(bounds, c, side="right")
+    if srt.size and col_slices > 1:
+        counts = np.bincount(slice_of(covered), minlength=col_slices)
+        assert counts.max() - srt.size / col_slices <= np.unique(srt, return_counts=True)[1].max()   # balanced up to ties
     assert sl0[0] == 0 and sl0[-1] == plan.n_seg and plan.slice_max_seg == np.diff(sl0).max()
     by_row = {i: [] for i in range(plan.n_rows)}
     for x in range(plan.n_slices):
@@ -80,8 +87,8 @@ def _check_plan(plan, rowptr, seg_len, col_slices=None):
             b, e = seg_beg[sgi], seg_end[sgi]
             assert 0 <= e - b <= seg_len
             if e > b and col_slices > 1:
-                q = col[b] // width
-                assert (col[b:e] // width == q).all()            # inside one column slice ...
+                q = slice_of(col[b])
+                assert (slice_of(col[b:e]) == q).all()            # inside one column slice ...
                 assert q % plan.n_slices == x and q >= last_q    # ... of this stream, slices in time order
                 last_q = q
             by_row[seg_row[sgi]].append((b, e, seg_slot[sgi]))
