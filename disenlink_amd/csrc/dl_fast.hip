@@ -818,7 +818,8 @@ __global__ __launch_bounds__(BLOCK) void pair_bce_kernel(const float* __restrict
     float acc = 0.0f;
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < n; q += BCE_BLOCKS * BLOCK) {
         const float p = prob[q], yy = y[q], ww = w[q];
-        // torch clamps with std::max(log, -100): a NaN probability stays NaN (fmaxf would turn it into -100)
+        // a NaN probability must stay visible as a NaN loss (fmaxf would turn its log into -100 and hide it; torch's
+        // BCE refuses such input outright)
         const float lg = logf(p), lg1 = logf(1.0f - p);
         const float lp = lg < -100.0f ? -100.0f : lg, l1p = lg1 < -100.0f ? -100.0f : lg1;
         // weight 0 = "not part of the loss" (e.g. validation pairs riding along): exactly nothing, even for a NaN p

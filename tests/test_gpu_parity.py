@@ -930,13 +930,14 @@ def test_fused_pair_bce_matches_torch_bce():
     assert abs(float(fused) - float(ref)) <= 1e-5 * abs(float(ref))
     torch.testing.assert_close(g_f, 2.0 * g_ref, rtol=1e-5, atol=0)
     assert torch.equal(fused, pair_bce_loss_fused(pf, lt, pair_bce_weights(n_pos, n_neg, m, DEV)))     # deterministic
-    # a NaN probability makes the loss NaN, as torch's BCE does (its clamp is std::max(log, -100)) — it must not be
-    # swallowed into a finite loss; a NaN at weight 0 (a pair outside the loss) is ignored
+    # a NaN probability must surface (torch's BCE refuses it: "all elements of input should be between 0 and 1") — here
+    # as a NaN loss, never swallowed into a finite one; a NaN at weight 0 (a pair outside the loss) is ignored
     w = pair_bce_weights(n_pos, n_neg, m, DEV)
     bad = prob.clone()
     bad[5] = float("nan")
     assert torch.isnan(pair_bce_loss_fused(bad.to(DEV), lt, w))
-    assert torch.isnan(pair_bce_loss(bad[:n_pos].to(DEV), lt[:n_pos], bad[n_pos:].to(DEV), lt[n_pos:], m))
+    with pytest.raises(RuntimeError):
+        pair_bce_loss(bad[:n_pos], label[:n_pos], bad[n_pos:], label[n_pos:], m)                       # torch, on the CPU
     w0 = w.clone()
     w0[5] = 0.0
     assert torch.isfinite(pair_bce_loss_fused(bad.to(DEV), lt, w0))
