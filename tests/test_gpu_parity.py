@@ -538,6 +538,50 @@ def test_real_data_auc_parity_with_the_reference_model(name):
     assert abs(test_auc - float(g["test_auc"])) <= 1e-4, (test_auc, float(g["test_auc"]))
 
 
+def test_tuned_and_generic_kernels_agree_on_random_small_problems():
+    """Fuzz: 60 random small problems (node counts around the segment / slice / tile edges, random plans) through both
+    independent implementations (tuned per-(K,d) kernels and the generic ones): forward and backward must agree."""
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph, PairList
+    lib = _lib.load()
+    rng = np.random.default_rng(2024)
+    shapes = [(8, 64), (4, 32), (5, 64), (16, 128), (3, 8), (10, 32), (8, 8)]
+    for it in range(60):
+        K, d = shapes[it % len(shapes)]
+        N = int(rng.integers(1, 200))
+        E = int(rng.integers(0, 6 * N + 1))
+        src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+        P = int(rng.integers(0, 5 * N + 1))
+        pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
+        seg_len = int(rng.choice([1, 3, 8, 32]))
+        beta, t = float(rng.choice([0.5, 0.7, 0.9])), float(rng.choice([1.0, 2.0]))
+        Z = torch.from_numpy((rng.standard_normal((N, K, d)) * 0.3).astype(np.float32)).to(DEV)
+        G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N, seg_len=seg_len).to(DEV)
+        pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N,
+                               seg_len=int(rng.choice([2, 5, 32])), n_slices=int(rng.choice([1, 8, 16])))
+        gp = torch.from_numpy(rng.standard_normal(P).astype(np.float32) * 0.1).to(DEV)
+        out = {}
+        for force in (0, 1):
+            old = lib.dl_set_force_generic(force)
+            try:
+                p, a, s = ops.route_fwd(G, Z, t)
+                H = ops.aggregate_fwd(G, Z, beta, p, a, s)
+                prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs if force == 0 else None)
+                dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp)
+                dZ = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH.clone(), dZ_accum=dZs.clone())
+                out[force] = (p, a, s, H, prob, dZs, dH, dZ)
+            finally:
+                lib.dl_set_force_generic(old)
+        tag = (it, N, E, P, K, d, seg_len)
+        same = out[0][0] == out[1][0]                                  # near-ties may route differently: skip those problems
+        if not bool(same.all()):
+            continue
+        for name, x0, x1 in zip(("a", "s", "H", "prob", "dZs", "dH", "dZ"), out[0][1:], out[1][1:]):
+            assert torch.isfinite(x0).all(), (name, tag)
+            scale = max(float(x1.abs().max()) if x1.numel() else 0.0, 1e-6)
+            assert float((x0 - x1).abs().max()) <= 2e-4 * scale if x0.numel() else True, (name, tag)
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops
