@@ -538,6 +538,41 @@ def test_real_data_auc_parity_with_the_reference_model(name):
     assert abs(test_auc - float(g["test_auc"])) <= 1e-4, (test_auc, float(g["test_auc"]))
 
 
+def test_projection_kernels_on_random_shapes():
+    """Fuzz: 40 random (N, F, K, nhid, d) incl. N, F, nhid of 1-3 and sizes around the 32 / 64 / 128 tile edges, through
+    the forward and both forms of the backward (recompute / kept hidden layer), against fp64."""
+    from disenlink_amd import ops
+    rng = np.random.default_rng(77)
+    for it in range(40):
+        d = int(rng.choice([32, 64, 128]))
+        N = int(rng.choice([1, 2, 3, 31, 33, 127, 128, 129, 200, 257, 640]))
+        F = int(rng.choice([1, 2, 3, 4, 31, 32, 33, 63, 65, 100, 129]))
+        K = int(rng.integers(1, 6))
+        nhid = int(rng.choice([2, 3, 4, 31, 33, 64, 65, 127, 128, 129, 200]))
+        g = torch.Generator().manual_seed(it)
+        x = torch.randint(-2, 3, (N, F), generator=g).float()             # exact layer-1 sums: the ReLU mask is unambiguous
+        W1 = torch.randint(-8, 9, (K, nhid, F), generator=g).float() / 64
+        b1 = torch.randint(-8, 9, (K, nhid), generator=g).float() / 64
+        W2 = torch.randn(K, d, nhid, generator=g) / nhid ** 0.5
+        b2 = torch.randn(K, d, generator=g) * 0.1
+        dZ = torch.randn(N, K, d, generator=g)
+        X, G = x.double(), dZ.double()
+        pre = torch.einsum("nf,khf->nkh", X, W1.double()) + b1.double()
+        hid = pre.clamp_min(0)
+        Zref = torch.einsum("nkh,kdh->nkd", hid, W2.double()) + b2.double()
+        dh = torch.einsum("nkd,kdh->nkh", G, W2.double()) * (pre > 0)
+        ref = (torch.einsum("nkh,nf->khf", dh, X), dh.sum(0), torch.einsum("nkd,nkh->kdh", G, hid), G.sum(0))
+        dev = [v.to(DEV) for v in (x, W1, b1, W2, dZ)]
+        tag = (it, N, F, K, nhid, d)
+        Z, kept = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2.to(DEV), keep_hid=True)
+        assert float((Z.cpu().double() - Zref).abs().max()) <= 2e-5 * max(float(Zref.abs().max()), 1e-6), tag
+        for form, hid_arg in (("recompute", None), ("kept", kept)):
+            for name, got, want in zip(("dW1", "db1", "dW2", "db2"), ops.project_bwd(*dev, hid=hid_arg), ref):
+                assert torch.isfinite(got).all(), (name, form, tag)
+                err = float((got.cpu().double() - want).abs().max())
+                assert err <= 2e-5 * max(float(want.abs().max()), 1e-6), (name, form, tag, err)
+
+
 def test_tuned_and_generic_kernels_agree_on_random_small_problems():
     """Fuzz: 60 random small problems (node counts around the segment / slice / tile edges, random plans) through both
     independent implementations (tuned per-(K,d) kernels and the generic ones): forward and backward must agree."""
