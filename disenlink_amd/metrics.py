@@ -51,3 +51,35 @@ def auc_tie_avg(label: torch.Tensor, score: torch.Tensor, check: bool = True) ->
     rank_sorted = (first + last).to(torch.float64) / 2.0 + 1.0
     r_pos = (rank_sorted * pos[order].to(torch.float64)).sum()
     return (r_pos - n_pos * (n_pos + 1.0) / 2.0) / (n_pos * n_neg)
+
+
+class AucPlan:
+    """The two index sets of a FIXED label vector (validation / test labels do not change during a run), found once.
+    ``auc(score)`` then needs no sort of the whole score vector: only the negatives are sorted, every positive is
+    located among them by two binary searches, and
+
+        AUC = ( sum_p #{n: s_n < s_p} + 1/2 #{n: s_n == s_p} ) / (n_pos * n_neg)
+
+    — the Mann-Whitney statistic with tie-averaged ranks, i.e. sklearn.roc_auc_score (main_disentangled.py:202-204,
+    :217-219), from integer counts.  No data-dependent shapes: nothing synchronises, and it can be graph-captured."""
+
+    def __init__(self, label: torch.Tensor):
+        label = label.reshape(-1)
+        pos = label > 0.5
+        self.pos_idx = torch.nonzero(pos).reshape(-1)              # the one sync, at construction
+        self.neg_idx = torch.nonzero(~pos).reshape(-1)
+        self.n_pos, self.n_neg = int(self.pos_idx.numel()), int(self.neg_idx.numel())
+
+    def auc(self, score: torch.Tensor) -> torch.Tensor:
+        """0-dim float64 tensor on score.device (nan when one class is absent)."""
+        score = score.reshape(-1).detach()
+        sp = score.index_select(0, self.pos_idx)
+        # stable=True: the merge-sort path, the one the rank-based auc_tie_avg has always used (also under HIP-graph
+        # capture); which order equal negatives end up in does not matter here
+        sn = torch.sort(score.index_select(0, self.neg_idx), stable=True).values
+        below = torch.searchsorted(sn, sp, right=False)
+        upto = torch.searchsorted(sn, sp, right=True)
+        u2 = (below + upto).sum()                                   # 2 * (below + (upto - below) / 2), in int64: exact
+        denom = float(self.n_pos) * float(self.n_neg)
+        return u2.to(torch.float64) / (2.0 * denom) if denom > 0 else torch.full((), float("nan"), dtype=torch.float64,
+                                                                                device=score.device)

@@ -19,7 +19,7 @@ import torch
 from torch.optim import Adam
 
 from .graph import Graph, PairList
-from .metrics import auc_tie_avg, pair_bce_loss, pair_bce_loss_fused, pair_bce_weights
+from .metrics import AucPlan, auc_tie_avg, pair_bce_loss, pair_bce_loss_fused, pair_bce_weights
 from .splits import LinkSplit
 
 
@@ -80,6 +80,7 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     launch-bound host time of small graphs.  Returns (replay, out) with out = [loss, auc] on the device."""
     opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=_FUSED_ADAM)
     out = torch.zeros(2, dtype=torch.float64, device=x.device)
+    val_plan = AucPlan(run.label_val)
 
     def epoch():
         _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
@@ -88,7 +89,7 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
         loss.backward()
         opt.step()
         out[0] = loss.detach().double()
-        out[1] = auc_tie_avg(run.label_val, prob[b:], check=False)
+        out[1] = val_plan.auc(prob[b:])
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -114,7 +115,11 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
         for v in st.values():
             if torch.is_tensor(v):
                 v.zero_()
-    return graph.replay, out
+    # A captured graph replays raw addresses: every tensor its kernels touch that was NOT allocated during the capture
+    # must outlive the graph.  The optimiser (moments, step counters) and the AUC index sets are created here, so they
+    # are handed back for the caller to hold for as long as it replays (dropping them frees memory the graph still
+    # reads and writes: the next allocation of that size would be corrupted, or an index set would turn to garbage).
+    return graph.replay, out, (graph, opt, val_plan, epoch, label_all, weight_all)
 
 
 def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 2000, lr: float = 1e-4,
@@ -133,6 +138,7 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
     for lab in (run.label_val, run.label_test):                     # validated once: the per-epoch AUC never syncs
         if not 0 < float(lab.sum()) < lab.numel():
             raise ValueError("AUC undefined with one class")
+    val_plan = AucPlan(run.label_val)
     fused = x.is_cuda                                               # fused loss+gradient kernel on the GPU path
     if fused:
         label_all, weight_all = _loss_vectors(run, x.device)
@@ -147,7 +153,7 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
         loss.backward()
         opt.step()
         model.eval()
-        auc_t = auc_tie_avg(run.label_val, prob[b:], check=False)   # from the pre-step forward, like :202-204
+        auc_t = val_plan.auc(prob[b:])                               # from the pre-step forward, like :202-204
         loss_v, auc = torch.stack([loss.detach().double(), auc_t]).tolist()     # ONE device->host sync per epoch
         res.losses.append(loss_v)
         res.val_aucs.append(auc)
@@ -175,7 +181,7 @@ def _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log) -> RunR
             raise ValueError("AUC undefined with one class")
     b = run.n_pos + run.n_neg
     label_all, weight_all = _loss_vectors(run, x.device)
-    replay, out = _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all)
+    replay, out, keep_alive = _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all)
     snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
     best_auc, stale, weights = 0.0, 0, snapshot()
     res = RunResult(float("nan"), 0.0, 0)
@@ -194,6 +200,8 @@ def _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log) -> RunR
             break
         if log is not None:
             log(f"epoch: {epoch} loss: {loss_v} val_auc: {best_auc}")
+    torch.cuda.synchronize()
+    del replay, keep_alive                                          # only now may the graph's external tensors go
     model.load_state_dict(weights)
     with torch.no_grad():
         _emb, prob = model.forward_pairs(x, run.graph, run.test_pairs)

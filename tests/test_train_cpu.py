@@ -24,6 +24,25 @@ def test_device_auc_matches_sklearn_vectors(path):
         auc_tie_avg(torch.ones(4), torch.rand(4))
 
 
+def test_auc_plan_matches_sklearn_vectors_and_the_rank_form():
+    """AucPlan (negatives sorted, positives located by binary search, integer counts) against the sklearn golden
+    vectors and against the rank-based auc_tie_avg on random scores with heavy ties."""
+    import glob
+    from disenlink_amd.metrics import AucPlan, auc_tie_avg
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "auc_*.npz"))):
+        g = np.load(path)
+        assert abs(float(AucPlan(torch.from_numpy(g["y"])).auc(torch.from_numpy(g["score"]))) - float(g["auc"])) <= 1e-12
+    rng = np.random.default_rng(0)
+    for n, levels in ((1000, 7), (5000, 100000), (300, 2)):
+        y = torch.from_numpy((rng.random(n) < 0.3).astype(np.float32))
+        sc = torch.from_numpy((rng.integers(0, levels, n) / levels).astype(np.float32))
+        sc[rng.random(n) < 0.2] = 1.0
+        plan = AucPlan(y)
+        assert abs(float(plan.auc(sc)) - float(auc_tie_avg(y, sc))) <= 1e-12
+        assert abs(float(plan.auc(sc * 0 + 0.5)) - 0.5) <= 1e-15                     # all tied
+    assert torch.isnan(AucPlan(torch.ones(5)).auc(torch.rand(5)))                   # one class only
+
+
 @pytest.mark.parametrize("name", golden_case_names())
 def test_pair_loss_equals_the_references_masked_loss(name):
     from disenlink_amd.metrics import pair_bce_loss
