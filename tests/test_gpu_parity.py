@@ -911,22 +911,28 @@ def test_projection_backward_rejects_bad_arguments():
     assert rc != 0 and b"32, 64, 128" in lib.dl_last_error()
 
 
-def test_graph_replayed_epochs_follow_the_eager_trajectory():
+@pytest.mark.parametrize("name,K,d,nhid,epochs", [("cora", 4, 32, 64, 10), ("chameleon", 8, 64, 512, 40)])
+def test_graph_replayed_epochs_follow_the_eager_trajectory(name, K, d, nhid, epochs):
     """use_graph=True replays the epoch (forward, fused loss, backward, Adam, AUC) from a captured HIP graph: the
-    loss / AUC sequence must follow the eager loop's (Adam's moments and step counter live across replays)."""
+    loss / AUC sequence must follow the eager loop's (Adam's moments and step counter live across replays, and
+    everything the graph touches outlives it — the chameleon case has a validation set large enough for the radix /
+    merge sort paths, the MFMA projection with its kept hidden layer, and 40 epochs of best-weight snapshots
+    allocating between replays)."""
     from disenlink_amd.data import synthetic_graph
     from disenlink_amd.model import Disentangle
     from disenlink_amd.splits import make_link_split
     from disenlink_amd.train import prepare_run, run_link_prediction
-    sg = synthetic_graph("cora", seed=3)
+    sg = synthetic_graph(name, seed=3)
     split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=3)
-    run = prepare_run(split, torch.device(DEV))
+    run = prepare_run(split, torch.device(DEV), row_bytes=K * d * 4)
     x = torch.from_numpy(sg.features()).to(DEV)
     out = {}
     for use_graph in (False, True):
         torch.manual_seed(0)
-        model = Disentangle(sg.n_feat, 64, 32, nfactor=4, beta=0.6, t=1).to(DEV)
-        out[use_graph] = run_link_prediction(model, x, run, epochs=10, lr=1e-3, use_graph=use_graph)
+        model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.6, t=1).to(DEV)
+        out[use_graph] = run_link_prediction(model, x, run, epochs=epochs, lr=1e-3, use_graph=use_graph)
+        junk = [torch.randn(1 << 18, device=DEV) for _ in range(8)]      # churn the allocator between the two runs
+        del junk
     np.testing.assert_allclose(out[True].losses, out[False].losses, rtol=2e-3)
     np.testing.assert_allclose(out[True].val_aucs, out[False].val_aucs, atol=2e-3)
     assert abs(out[True].test_auc - out[False].test_auc) <= 2e-3
