@@ -252,10 +252,11 @@ def test_exp_overflow_propagates_like_the_reference():
     np.testing.assert_allclose(a.cpu().numpy()[fin], a_o[fin], rtol=1e-6)
 
 
+@pytest.mark.parametrize("ways", [0, 2, 4, 8])
 @pytest.mark.parametrize("force_generic", [0, 1])
-def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic):
-    """Three row shards on one GPU, sharing the node-indexed arrays the way all-gathers would:
-    forward and both backward phases must equal the unsharded run bit for bit."""
+def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic, ways):
+    """Row shards on one GPU (three uneven ones, or the 2 / 4 / 8 equal blocks dist.py cuts), sharing the node-indexed
+    arrays the way all-gathers would: forward and both backward phases must equal the unsharded run bit for bit."""
     from disenlink_amd import _lib, ops
     from disenlink_amd.graph import Graph, PairList
     K, d, N, beta, t = 8, 64, 700, 0.7, 1.0
@@ -276,7 +277,11 @@ def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic):
         dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp)
         dZ = ops.route_aggregate_bwd(G, Z, beta, t, p, a, s, dH, dZ_accum=dZs.clone())
 
-        bounds = [0, 230, 231, N]                      # uneven shards, one of a single row
+        if ways == 0:
+            bounds = [0, 230, 231, N]                  # uneven shards, one of a single row
+        else:
+            blk = -(-N // ways)                        # dist.block_size: equal blocks, the last one short
+            bounds = [min(i * blk, N) for i in range(ways + 1)]
         shards = [Graph.from_edge_rows(ts, td, N, row_range=(lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
         s2 = torch.full_like(s, float("nan"))
         H2 = torch.full_like(H, float("nan"))
@@ -286,7 +291,7 @@ def test_row_sharded_plans_reproduce_the_unsharded_result(force_generic):
         assert torch.equal(s, s2) and torch.equal(H, H2)
         assert torch.equal(torch.cat([r[0] for r in routed]), p) and torch.equal(torch.cat([r[1] for r in routed]), a)
         # scorer: each shard scores a slice of the pairs and owns the incidence rows of its nodes
-        cut = [0, 1700, 1701, P]
+        cut = [0, 1700, 1701, P] if ways == 0 else [int(np.searchsorted(pu, b)) for b in bounds[:-1]] + [P]
         prob2 = torch.cat([ops.score_pairs_fwd(Z, H2, pairs.pu[b:e].contiguous(), pairs.pv[b:e].contiguous(), t, None)
                            for b, e in zip(cut[:-1], cut[1:])])
         np.testing.assert_allclose(prob2.cpu().numpy(), prob.cpu().numpy(), rtol=1e-6, atol=1e-7)
