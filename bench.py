@@ -307,7 +307,9 @@ def main():
         t_d = float(np.mean([evd[i].elapsed_time(evd[i + 1]) for i in range(5)])) * 1e-3
         nt = (N + 127) // 128                                   # 128x128 tiles; only u tile <= v tile is computed
         fl_d = 4.0 * K * d * 128 * 128 * (nt * (nt + 1) // 2)   # MFMA flops executed (P is symmetric: half mirrored)
-        dense = {"bound": "mfma", "dtype": "f32", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "pairs": N * N,
+        dense = {"bound": "mfma", "dtype": "f32 results from three bf16 planes per operand (six exact products per term)"
+                 if not os.environ.get("DL_DENSE_FP32_MFMA") else "f32", "peak": FP32_MFMA_PEAK_TFLOPS,
+                 "unit": "TFLOP/s (fp32-equivalent, against the fp32 matrix peak)", "pairs": N * N,
                  "avg_us": t_d * 1e6, "achieved": fl_d / t_d / 1e12, "frac": fl_d / t_d / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                  "effective": 4.0 * N * N * K * d / t_d / 1e12, "pairs_per_s": N * N / t_d}
 

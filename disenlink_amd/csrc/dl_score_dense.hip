@@ -154,6 +154,174 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The same scorer with the Gram products on the bf16 matrix path at fp32-grade accuracy: every fp32 operand is
+// split, while it is staged, into three bf16 planes x = hi + mid + lo (to ~2^-25 relative); each bf16 x bf16
+// product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the six products hi*hi, hi*mid,
+// mid*hi, hi*lo, lo*hi, mid*mid (smallest first) carry the full fp32 product — six 32-cycle MFMAs per K = 16 block
+// instead of eight 64-cycle fp32 ones.  Measured on a standalone Gram product (tools/experiments/split_bf16_gram.hip):
+// 1.87x at the same error against fp64 (2.2e-7 vs 1.9e-7 of the sum of |terms|).
+// LDS image per operand and buffer: [3 planes][128 rows][32 + 8] bf16 (row pitch 80 bytes: conflict-free b128 reads).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int SDC = 32, SLD = SDC + 8;
+
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+__global__ __launch_bounds__(DTHR) void score_allpairs_split_kernel(const float* __restrict__ Z, const float* __restrict__ H,
+                                                                    int N, int K, int D, float t, float* __restrict__ prob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16* us = reinterpret_cast<__bf16*>(lds);               // [2][3][TT][SLD]
+    __bf16* vs = us + 2 * 3 * TT * SLD;
+    const int nt = (N + TT - 1) / TT;
+    const int hb = blockIdx.x;
+    const int i = ((hb >> 3) >> 5) * 256 + (hb & 7) * 32 + ((hb >> 3) & 31);     // runs of 32 items per XCD
+    if (i >= nt * (nt + 1) / 2) return;
+    int ta = (int)((2.0f * nt + 1.0f - sqrtf((2.0f * nt + 1.0f) * (2.0f * nt + 1.0f) - 8.0f * (float)i)) * 0.5f);
+    ta = max(0, min(nt - 1, ta));
+    while (ta > 0 && i < ta * nt - ta * (ta - 1) / 2) --ta;
+    while (i >= (ta + 1) * nt - (ta + 1) * ta / 2) ++ta;
+    const int tb = ta + (i - (ta * nt - ta * (ta - 1) / 2));
+    const int u0 = ta * TT, v0 = tb * TT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, half = lane >> 5;
+    const int wu = wave >> 1, wv = wave & 1;
+    const int nd = D / SDC;
+    const int steps = K * 2 * nd;
+    const int ld = K * D;
+
+    TileStage<TT, SDC, true, DTHR> ut, vt;                     // raw fp32 quads in flight; split when written to LDS
+    auto fetch = [&](int s) {
+        const int k = s / (2 * nd), r = s - k * 2 * nd;
+        const float* src = r < nd ? Z : H;
+        const int dc = r < nd ? r : r - nd;
+        ut.fetch(src + ((size_t)u0 * K + k) * D + dc * SDC, ld, N - u0, SDC, tid);
+        vt.fetch(src + ((size_t)v0 * K + k) * D + dc * SDC, ld, N - v0, SDC, tid);
+    };
+    auto stash_split = [&](const TileStage<TT, SDC, true, DTHR>& tile, __bf16* base) {
+#pragma unroll
+        for (int j = 0; j < tile.NV / 4; ++j) {
+            const int q = tid + DTHR * j, r = q / (SDC / 4), c = 4 * (q % (SDC / 4));
+            const unsigned m = r < tile.rows_valid ? 0xFFFFFFFFu : 0u;          // rows past N read as zero
+            bf16x4 p0, p1, p2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h, md, l;
+                split3(mask_bits(tile.v[4 * j + e], m), h, md, l);
+                p0[e] = h; p1[e] = md; p2[e] = l;
+            }
+            *reinterpret_cast<bf16x4*>(base + (0 * TT + r) * SLD + c) = p0;
+            *reinterpret_cast<bf16x4*>(base + (1 * TT + r) * SLD + c) = p1;
+            *reinterpret_cast<bf16x4*>(base + (2 * TT + r) * SLD + c) = p2;
+        }
+    };
+    auto stash = [&](int s) {
+        stash_split(ut, us + (s & 1) * 3 * TT * SLD);
+        stash_split(vt, vs + (s & 1) * 3 * TT * SLD);
+    };
+
+    f32x16 acc[2], term[2];
+    float e[2][16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        zero_acc(acc[b]);
+        zero_acc(term[b]);
+    }
+    fetch(0);
+    stash(0);
+    if (steps > 1) fetch(1);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int r = s % (2 * nd);
+        // lane half h supplies k = 8h .. 8h+7 of each 16-wide block; A = u rows of this quarter, B = v rows
+        const __bf16* ub = us + (s & 1) * 3 * TT * SLD + (wu * 32 + li) * SLD + half * 8;
+        const __bf16* vb = vs + (s & 1) * 3 * TT * SLD + (wv * 64 + li) * SLD + half * 8;
+#pragma unroll
+        for (int kb = 0; kb < SDC / 16; ++kb) {
+            bf16x8 a[3], b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(ub + p * TT * SLD + kb * 16);
+                b[p][0] = *reinterpret_cast<const bf16x8*>(vb + p * TT * SLD + kb * 16);
+                b[p][1] = *reinterpret_cast<const bf16x8*>(vb + (p * TT + 32) * SLD + kb * 16);
+            }
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                f32x16 c = acc[bb];                             // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][bb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][bb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][bb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][bb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][bb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][bb], c, 0, 0, 0);
+                acc[bb] = c;
+            }
+            if (kb == 0) {
+                if (s + 1 < steps) stash(s + 1);
+                if (s + 2 < steps) fetch(s + 2);
+            }
+        }
+        if (r == nd - 1) {                                      // S complete: e = exp(S / t)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) e[bb][q] = expf(div_t(acc[bb][q], t));
+                zero_acc(acc[bb]);
+            }
+        } else if (r == 2 * nd - 1) {                           // Q complete: term += Q * e
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) term[bb][q] += acc[bb][q] * e[bb][q];
+                zero_acc(acc[bb]);
+            }
+        }
+        __syncthreads();
+    }
+    // Stores.  The two products of a swapped pair are accumulated in a different order here (hi*lo before lo*hi), so
+    // (u,v) and (v,u) computed independently may differ in the last bit: a diagonal tile therefore writes only its
+    // upper triangle directly and mirrors the strict upper triangle — every entry of P is written exactly once, from
+    // the (min, max) ordering of its pair, and P stays symmetric bit for bit.
+    const bool diag = ta == tb;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int v = v0 + wv * 64 + bb * 32 + li;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            term[bb][q] = sigmoid_ref(term[bb][q]);
+            const int u = u0 + wu * 32 + acc_row(q, half);
+            if (u < N && v < N && (!diag || u <= v)) prob[(size_t)u * N + v] = term[bb][q];
+        }
+        if (v < N && diag) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int u = u0 + wu * 32 + acc_row(q, half);
+                if (u < v) prob[(size_t)v * N + u] = term[bb][q];           // u < v < N
+            }
+        } else if (v < N) {                                     // off-diagonal tile: registers 4g..4g+3 = 4 consecutive u
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = u0 + wu * 32 + 8 * g + 4 * half;
+                float* dst = prob + (size_t)v * N + u;
+                if (u + 3 < N && (N & 3) == 0) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(term[bb][4 * g], term[bb][4 * g + 1], term[bb][4 * g + 2],
+                                                                  term[bb][4 * g + 3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (u + j < N) dst[j] = term[bb][4 * g + j];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dense
 
 bool dense_mfma_supported(int d) { return d % 32 == 0; }
@@ -172,6 +340,17 @@ static void launch_dense(const float* Z, const float* H, int N, int K, int d, fl
 
 int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
                                   hipStream_t st) {
+    if (!getenv("DL_DENSE_FP32_MFMA")) {                        // default: three-plane bf16 products (fp32-grade accuracy)
+        using namespace dense;
+        static unsigned long long lds_done = 0;
+        constexpr size_t lds = (size_t)2 * 2 * 3 * TT * SLD * 2;
+        project::ensure_dynamic_lds(reinterpret_cast<const void*>(&score_allpairs_split_kernel), lds, lds_done);
+        const int nt = (N + TT - 1) / TT;
+        const int items = nt * (nt + 1) / 2;
+        hipLaunchKernelGGL(score_allpairs_split_kernel, dim3((unsigned)((items + 255) / 256 * 256)), dim3(DTHR), lds, st, Z, H,
+                           N, K, d, t, prob);
+        return check_launch("score_allpairs_fwd(split bf16)");
+    }
     if (d % 64 == 0 && !getenv("DL_DENSE_DC32")) launch_dense<64>(Z, H, N, K, d, t, prob, st);
     else launch_dense<32>(Z, H, N, K, d, t, prob, st);
     return check_launch("score_allpairs_fwd(mfma)");
