@@ -72,3 +72,46 @@ def test_pair_plans_on_random_pairs(n, P, seed):
     assert sorted(ids.tolist()) == list(range(P))
     row_of = np.repeat(np.arange(n), np.diff(pl.by_u.rowptr.numpy()))
     assert np.array_equal(pu[ids], row_of) and np.array_equal(pv[ids], pl.by_u.col.numpy())
+
+
+@st.composite
+def tiny_problem(draw):
+    n = draw(st.integers(2, 14))
+    k = draw(st.sampled_from([1, 2, 3, 5]))
+    d = draw(st.sampled_from([1, 2, 4]))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    dens = draw(st.sampled_from([0.0, 0.15, 0.5, 1.0]))
+    return n, k, d, seed, dens, draw(st.sampled_from([0.5, 0.7, 0.9])), draw(st.sampled_from([1.0, 2.0]))
+
+
+@settings(max_examples=40, deadline=None)
+@given(tiny_problem())
+def test_sparse_oracle_equals_autograd_of_the_dense_oracle(prob):
+    """The CSR + pair-list restatement (forward and the analytic backward of SURVEY.md Appendix A.3) against
+    torch autograd of the dense restatement, on random tiny graphs: empty graphs, full graphs, self-loops, K = 1."""
+    from oracle import dense_ref, sparse_ref
+    n, k, d, seed, dens, beta, t = prob
+    rng = np.random.default_rng(seed)
+    adj = (rng.random((n, n)) < dens).astype(np.float32)
+    adj = ((adj + adj.T) > 0).astype(np.float32)                   # symmetric, diagonal may be 1
+    Z = (rng.standard_normal((n, k, d)) * 0.7).astype(np.float32)
+    Zt = torch.from_numpy(Z).permute(1, 0, 2).contiguous().requires_grad_(True)      # dense oracle wants [K,N,d]
+    H_d, e_d, _att, _p, _s = dense_ref.route_aggregate(Zt, torch.from_numpy(adj), beta, t)
+    P_d = dense_ref.score_allpairs(H_d, e_d)
+    w = torch.from_numpy(rng.standard_normal((n, n)).astype(np.float32))
+    (P_d * w).sum().backward()
+    rowptr, col, rev = sparse_ref.csr_from_dense(adj)
+    alpha = (e_d / e_d.sum(0)).detach().numpy()
+    if k > 1:                                                      # skip problems with a routing near-tie on an edge
+        top = np.sort(alpha, axis=0)
+        if ((top[-1] - top[-2])[adj > 0] < 1e-4).any():
+            return
+    H, p, a, s_raw = sparse_ref.forward(Z, rowptr, col, beta, t)
+    np.testing.assert_allclose(H, H_d.detach().permute(1, 0, 2).numpy(), rtol=2e-5, atol=2e-6)
+    uu, vv = np.divmod(np.arange(n * n), n)
+    P = sparse_ref.score_pairs(Z, H, uu, vv, t)
+    np.testing.assert_allclose(P.reshape(n, n), P_d.detach().numpy(), rtol=2e-5, atol=2e-6)
+    dZ_s, dH = sparse_ref.score_pairs_bwd(Z, H, uu, vv, t, w.numpy().reshape(-1))
+    dZ = dZ_s + sparse_ref.route_aggregate_bwd(Z, rowptr, col, rev, p, a, s_raw, beta, t, dH)
+    want = Zt.grad.permute(1, 0, 2).numpy()
+    assert np.abs(dZ - want).max() <= 5e-4 * max(np.abs(want).max(), 1e-6)
