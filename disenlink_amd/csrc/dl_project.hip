@@ -76,17 +76,22 @@ __device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
 // Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D].
 // VEC: F % 4 == 0 and nhid % 4 == 0.  1-D grid of xcd_grid(node tiles of 128, K * G hidden-chunk groups).
 // out: Z [N][K][D] with b2 != nullptr (G == 1), or slab [G][N][K][D] of partial sums with b2 == nullptr.
-template <int D, bool VEC>
+// SPLIT (needs VEC): layer 1 on the bf16 matrix path from three bf16 planes per operand (dl_tiles.h: fp32-grade
+// accuracy, ~1.9x the fp32 MFMA rate); the tiles are [128][32] then, split while they are written to LDS.
+template <int D, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ b2,
                                                             float* __restrict__ out, int K, int G, int chunks_per_group,
                                                             float* __restrict__ hid_out, int ldh) {
     constexpr int DT = D / 32;
-    constexpr int FC = fwd_fc(D), LDT = FC + 4;
+    static_assert(VEC || !SPLIT, "the split form stages aligned quads");
+    constexpr int FC = SPLIT ? SPLIT_COLS : fwd_fc(D), LDT = FC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                               // [2][TN][LDT]
     float* w1s = xs + 2 * TN * LDT;                // [2][TH][LDT]
+    __bf16* xp = reinterpret_cast<__bf16*>(lds);   // SPLIT: [2][3][TN][SPLIT_PITCH]
+    __bf16* wp = xp + 2 * 3 * TN * SPLIT_PITCH;    //        [2][3][TH][SPLIT_PITCH]
     const XcdItem item = xcd_item(blockIdx.x, (N + TN - 1) / TN, K * G);
     if (!item.valid) return;
     const int k = item.b % K, grp = item.b / K;
@@ -109,8 +114,13 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
         wt.fetch(W1k + (size_t)hc * TH * F + fc * FC, F, nhid - hc * TH, F - fc * FC, tid);
     };
     auto stash = [&](int s) {
-        xt.template stash<LDT>(xs + (s & 1) * TN * LDT, tid);
-        wt.template stash<LDT>(w1s + (s & 1) * TH * LDT, tid);
+        if constexpr (SPLIT) {
+            stash_planes(xt, xp + (s & 1) * 3 * TN * SPLIT_PITCH, tid);
+            stash_planes(wt, wp + (s & 1) * 3 * TH * SPLIT_PITCH, tid);
+        } else {
+            xt.template stash<LDT>(xs + (s & 1) * TN * LDT, tid);
+            wt.template stash<LDT>(w1s + (s & 1) * TH * LDT, tid);
+        }
     };
     // W2_k[dt*32 + li][hidden quad g of tile ht]: the A operand of layer 2 for d-tile dt
     auto load_w2 = [&](float4 (&wv)[2][4], int dt, int hbase) {
@@ -149,6 +159,27 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                 for (int g = 0; g < 4; ++g) bias[ht][g] = load4_raw<VEC>(b1k, hbase + ht * 32 + 8 * g + 4 * half, nhid);
             load_w2(wnext, 0, hbase);
         }
+        if constexpr (SPLIT) {
+            // lane half h supplies features 8h .. 8h+7 of each 16-wide block: A = W1 rows (two hidden tiles), B = x rows
+            const __bf16* xb = xp + (s & 1) * 3 * TN * SPLIT_PITCH + (wn * 32 + li) * SPLIT_PITCH + half * 8;
+            const __bf16* wb = wp + (s & 1) * 3 * TH * SPLIT_PITCH + (wh * 64 + li) * SPLIT_PITCH + half * 8;
+#pragma unroll
+            for (int kb = 0; kb < SPLIT_COLS / 16; ++kb) {
+                bf16x8 a0[3], a1[3], b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    b[p] = *reinterpret_cast<const bf16x8*>(xb + p * TN * SPLIT_PITCH + kb * 16);
+                    a0[p] = *reinterpret_cast<const bf16x8*>(wb + p * TH * SPLIT_PITCH + kb * 16);
+                    a1[p] = *reinterpret_cast<const bf16x8*>(wb + (p * TH + 32) * SPLIT_PITCH + kb * 16);
+                }
+                mfma_split6(hacc[0], a0, b);
+                mfma_split6(hacc[1], a1, b);
+                if (kb == 0) {
+                    if (s + 1 < steps) stash(s + 1);
+                    if (s + 2 < steps) fetch(s + 2);
+                }
+            }
+        } else {
         // lane half h owns features h*FC/2 .. h*FC/2 + FC/2-1 of the chunk; MFMA block j takes 2 quads of them
         // per operand row (3 ds_read_b128, 16 MFMAs), block j+1's reads are issued ahead of block j's MFMAs
         const float* xb = xs + (s & 1) * TN * LDT + (wn * 32 + li) * LDT + half * (FC / 2);
@@ -183,6 +214,7 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                 if (s + 2 < steps) fetch(s + 2);
             }
         }
+        }   // !SPLIT
         if (last) {
             // bias + ReLU on hidT (row = hidden unit, column = node), then layer 2 straight from the registers
 #pragma unroll
@@ -257,7 +289,11 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     }
 }
 
-constexpr size_t project2_lds(int D) { return sizeof(float) * (2 * TN + 2 * TH) * (fwd_fc(D) + 4); }
+constexpr size_t project2_lds(int D, bool split) {
+    const size_t red = sizeof(float) * 4 * (D / 32) * 16 * 64;                 // the Z hand-over at the end
+    const size_t stage = split ? sizeof(__bf16) * 2 * 3 * (TN + TH) * SPLIT_PITCH : sizeof(float) * (2 * TN + 2 * TH) * (fwd_fc(D) + 4);
+    return stage > red ? stage : red;
+}
 
 // Z[n][c] = b2[c] + sum_g slab[g][n][c] (g ascending), c over K*D; 4 columns per thread.
 __global__ __launch_bounds__(256) void z_slab_sum_kernel(const float* __restrict__ slab, int G, size_t NC, int C,
@@ -327,6 +363,11 @@ __global__ __launch_bounds__(256) void project1_fwd_kernel(const float* __restri
 
 }  // namespace project
 
+// Layer-1 products from three bf16 planes per operand (default) or plain fp32 MFMA (DL_PROJECT_FP32_MFMA=1).
+bool split_products() {
+    return getenv("DL_PROJECT_FP32_MFMA") == nullptr;
+}
+
 bool project_supported(int d) { return d == 32 || d == 64 || d == 128; }
 
 // Hidden-chunk groups per (node tile, factor): 1 when the grid already covers the 256 CUs twice over, else
@@ -346,14 +387,15 @@ size_t project_fwd_workspace_bytes(int N, int K, int nhid, int d, bool two_layer
     return G > 1 ? sizeof(float) * (size_t)G * N * K * d : 0;
 }
 
-template <int D, bool VEC>
+template <int D, bool VEC, bool SPLIT>
 static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float* x, int F, int nhid, const float* W1,
                       const float* b1, const float* W2, const float* b2, float* out, float* hid_out, int ldh) {
     using namespace project;
     static unsigned long long lds_done = 0;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC>), project2_lds(D), lds_done);
+    constexpr size_t lds = project2_lds(D, SPLIT);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC, SPLIT>), lds, lds_done);
     const dim3 grid((unsigned)xcd_grid((N + TN - 1) / TN, K * G));
-    hipLaunchKernelGGL((project2_fwd_kernel<D, VEC>), grid, dim3(NTHR), project2_lds(D), st, x, N, F, nhid, W1, b1, W2, b2,
+    hipLaunchKernelGGL((project2_fwd_kernel<D, VEC, SPLIT>), grid, dim3(NTHR), lds, st, x, N, F, nhid, W1, b1, W2, b2,
                        out, K, G, cpg, hid_out, ldh);
 }
 
@@ -375,10 +417,12 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
     const int cpg = (nhc + G - 1) / G;
     float* out = G > 1 ? static_cast<float*>(ws) : Z;
     const float* bias2 = G > 1 ? nullptr : b2;
+    const bool split = split_products();
 #define DL_P2(DD)                                                                                       \
     if (d == DD) {                                                                                      \
-        if (vec) launch2_t<DD, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);   \
-        else launch2_t<DD, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);      \
+        if (vec && split) launch2_t<DD, true, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);   \
+        else if (vec) launch2_t<DD, true, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);      \
+        else launch2_t<DD, false, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);              \
     }
     DL_P2(32) DL_P2(64) DL_P2(128)
 #undef DL_P2

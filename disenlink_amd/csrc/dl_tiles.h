@@ -123,5 +123,57 @@ struct TileStage {
     }
 };
 
+// ---- fp32 products on the bf16 matrix path ------------------------------------------------------------------
+// An fp32 operand is split, while it is staged, into three bf16 planes x = hi + mid + lo (to ~2^-25 relative); each
+// bf16 x bf16 product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the six products
+// mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi (smallest first) carry the full fp32 product — six 32-cycle MFMAs per
+// K = 16 block instead of eight 64-cycle fp32 ones (tools/experiments/split_bf16_gram.hip: 1.87x at the same error
+// against fp64).  LDS image of a tile: [3 planes][ROWS][PITCH] bf16, PITCH = 32 + 8 (80-byte rows: conflict-free
+// b128 reads); lane half h of a wave supplies k = 8h .. 8h+7 of each 16-wide block.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int SPLIT_COLS = 32, SPLIT_PITCH = SPLIT_COLS + 8;
+
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+// acc += A . B^T for one K = 16 block from the three planes of each operand (8 bf16 per lane and plane)
+__device__ __forceinline__ void mfma_split6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    f32x16 c = acc;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    acc = c;
+}
+
+// Write a fetched [ROWS][32] tile (TileStage<ROWS, 32, true, THREADS>) to LDS as three bf16 planes; what lies outside
+// the matrix is written as zero.
+template <int ROWS, int THREADS>
+__device__ __forceinline__ void stash_planes(const TileStage<ROWS, SPLIT_COLS, true, THREADS>& tile, __bf16* base, int tid) {
+    const bool full = tile.rows_valid >= ROWS && tile.cols_valid >= SPLIT_COLS;
+#pragma unroll
+    for (int j = 0; j < tile.NV / 4; ++j) {
+        const int q = tid + THREADS * j, r = q / (SPLIT_COLS / 4), c = 4 * (q % (SPLIT_COLS / 4));
+        const unsigned m = (full || (r < tile.rows_valid && c < tile.cols_valid)) ? 0xFFFFFFFFu : 0u;
+        bf16x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, md, l;
+            split3(mask_bits(tile.v[4 * j + e], m), h, md, l);
+            p0[e] = h; p1[e] = md; p2[e] = l;
+        }
+        *reinterpret_cast<bf16x4*>(base + (0 * ROWS + r) * SPLIT_PITCH + c) = p0;
+        *reinterpret_cast<bf16x4*>(base + (1 * ROWS + r) * SPLIT_PITCH + c) = p1;
+        *reinterpret_cast<bf16x4*>(base + (2 * ROWS + r) * SPLIT_PITCH + c) = p2;
+    }
+}
+
 }  // namespace project
 }  // namespace dl
