@@ -121,7 +121,7 @@ int dl_project_supported(int d) { return project_supported(d) ? 1 : 0; }
 size_t dl_project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer) {
     (void)F;
     if (N <= 0 || K < 1 || nhid < 1 || d < 1) return 0;
-    return project_fwd_workspace_bytes(N, K, nhid, d, two_layer != 0);
+    return project_fwd_workspace_bytes(N, F, K, nhid, d, two_layer != 0);
 }
 
 size_t dl_project_hidden_floats(int N, int K, int nhid) {

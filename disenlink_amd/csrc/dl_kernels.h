@@ -54,7 +54,8 @@ int pair_bce(const float* prob, const float* y, const float* w, int n, float* lo
 
 // factor projection on the matrix cores (dl_project.hip)
 bool project_supported(int d);
-size_t project_fwd_workspace_bytes(int N, int K, int nhid, int d, bool two_layer);
+size_t project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer);
+bool split_products();   // layer-1 / dW1 products from three bf16 planes per operand (off: DL_PROJECT_FP32_MFMA=1)
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
                 const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st);
 // its backward (dl_project_bwd.hip): weight / bias gradients, W2 == nullptr for the single layer

@@ -1,0 +1,84 @@
+// fp32 matrix -> three bf16 planes (x = hi + mid + lo, dl_tiles.h) in global memory, tile-major and zero-filled out
+// to the padded extents, for the projection kernels that run fp32-grade products on the bf16 matrix path.
+#include "dl_common.h"
+#include "dl_kernels.h"
+#include "dl_tiles.h"
+
+namespace dl {
+namespace project {
+
+// One thread per 16-byte piece (8 consecutive columns of a row); consecutive threads walk a tile in storage order,
+// so the writes are contiguous and the reads are whole 128-byte row segments.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int R, int C, int ld, size_t sb,
+                                                         __bf16* __restrict__ dst, int nrb, int ncb, size_t db) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;           // piece index within the matrix
+    constexpr int PLANE_TILE = PLANE_ROWS * SPLIT_COLS, PIECES = PLANE_TILE / 8;
+    if (g >= (size_t)nrb * ncb * PIECES) return;
+    const int t = (int)(g / PIECES), q = (int)(g % PIECES);
+    const int rb = t / ncb, cb = t % ncb;
+    const int r = rb * PLANE_ROWS + (q >> 2), c0 = cb * SPLIT_COLS + (q & 3) * 8;
+    const float* s = src + (size_t)blockIdx.y * sb + (size_t)r * ld;
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool ok = r < R && c0 + e < C;
+        const float x = ok ? s[c0 + e] : 0.0f;
+        __bf16 h, m, l;
+        split3(x, h, m, l);
+        p0[e] = h; p1[e] = m; p2[e] = l;
+    }
+    __bf16* o = dst + (size_t)blockIdx.y * db + plane_tile<SPLIT_COLS>(rb, cb, ncb) + q * 8;
+    *reinterpret_cast<bf16x8*>(o) = p0;
+    *reinterpret_cast<bf16x8*>(o + PLANE_TILE) = p1;
+    *reinterpret_cast<bf16x8*>(o + 2 * PLANE_TILE) = p2;
+}
+
+// Planes of the transpose: rows = c (columns of src), columns = r.  Block = a 64 x 64 tile of src through LDS:
+// coalesced reads along c, 16-byte pieces along r on the way out.  grid (ceil(Rp/64), ceil(Cp/64)) over the PADDED extents.
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ src, int R, int C, int ld,
+                                                              __bf16* __restrict__ dst, int ncb) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + 4 * i + tr, c = c0 + tc;
+        tile[4 * i + tr][tc] = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.0f;
+    }
+    __syncthreads();
+    const int r8 = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = (threadIdx.x >> 3) + 32 * j;
+        bf16x8 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 h, m, l;
+            split3(tile[r8 + e][c], h, m, l);
+            p0[e] = h; p1[e] = m; p2[e] = l;
+        }
+        const int row = c0 + c, col = r0 + r8;                          // of the transposed matrix
+        constexpr int TC = 16;                                          // tile width of the transposed arrays
+        __bf16* o = dst + plane_tile<TC>(row / PLANE_ROWS, col / TC, ncb) + (row % PLANE_ROWS) * TC + col % TC;
+        *reinterpret_cast<bf16x8*>(o) = p0;
+        *reinterpret_cast<bf16x8*>(o + PLANE_ROWS * TC) = p1;
+        *reinterpret_cast<bf16x8*>(o + 2 * PLANE_ROWS * TC) = p2;
+    }
+}
+
+void split_rows(const float* src, int B, int R, int C, int ld, size_t sb, __bf16* dst, hipStream_t st) {
+    const int nrb = (int)(round_up(R, PLANE_ROWS) / PLANE_ROWS), ncb = plane_chunks<SPLIT_COLS>(C, SPLIT_COLS);
+    const size_t items = (size_t)nrb * ncb * (PLANE_ROWS * SPLIT_COLS / 8);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((items + 255) / 256), (unsigned)B), dim3(256), 0, st, src, R, C, ld,
+                       sb, dst, nrb, ncb, plane_array_elems(R, C, SPLIT_COLS));
+}
+
+void split_transposed(const float* src, int R, int C, int ld, __bf16* dst, hipStream_t st) {
+    // transposed matrix: C rows, R columns, both padded to 128
+    const int rows_p = (int)round_up(C, PLANE_ROWS), cols_p = (int)round_up(R, PLANE_ROWS);
+    hipLaunchKernelGGL(split_transpose_kernel, dim3((unsigned)(cols_p / 64), (unsigned)(rows_p / 64)), dim3(256), 0, st, src, R,
+                       C, ld, dst, cols_p / 16);
+}
+
+}  // namespace project
+}  // namespace dl

@@ -76,16 +76,18 @@ __device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
 // Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D].
 // VEC: F % 4 == 0 and nhid % 4 == 0.  1-D grid of xcd_grid(node tiles of 128, K * G hidden-chunk groups).
 // out: Z [N][K][D] with b2 != nullptr (G == 1), or slab [G][N][K][D] of partial sums with b2 == nullptr.
-// SPLIT (needs VEC): layer 1 on the bf16 matrix path from three bf16 planes per operand (dl_tiles.h: fp32-grade
-// accuracy, ~1.9x the fp32 MFMA rate); the tiles are [128][32] then, split while they are written to LDS.
+// SPLIT: layer 1 on the bf16 matrix path from three bf16 planes per operand (dl_tiles.h: fp32-grade accuracy at a
+// multiple of the fp32 MFMA rate); x and W1 arrive as padded plane arrays (dl_planes.hip) and the [128][32] tiles are
+// copied without masks.  VEC then only says nhid % 4 == 0 (W2 / b1 quads).
+struct FwdPlanes { const __bf16* x; const __bf16* w; size_t w_batch; int ncb; };   // tile-major planes of x and of the K matrices W1_k
+
 template <int D, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ b2,
                                                             float* __restrict__ out, int K, int G, int chunks_per_group,
-                                                            float* __restrict__ hid_out, int ldh) {
+                                                            float* __restrict__ hid_out, int ldh, FwdPlanes P) {
     constexpr int DT = D / 32;
-    static_assert(VEC || !SPLIT, "the split form stages aligned quads");
     constexpr int FC = SPLIT ? SPLIT_COLS : fwd_fc(D), LDT = FC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                               // [2][TN][LDT]
@@ -102,21 +104,28 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     const float* W1k = W1 + (size_t)k * nhid * F;
     const float* W2k = W2 + (size_t)k * D * nhid;
     const float* b1k = b1 + (size_t)k * nhid;
-    const int nfc = (F + FC - 1) / FC, nhc = (nhid + TH - 1) / TH;
+    const int nfc = SPLIT ? P.ncb : (F + FC - 1) / FC, nhc = (nhid + TH - 1) / TH;
     const int hc0 = grp * chunks_per_group;
     const int steps = nfc * max(0, min(chunks_per_group, nhc - hc0));
 
     TileStage<TN, FC, VEC, NTHR> xt;
     TileStage<TH, FC, VEC, NTHR> wt;
+    static_assert(TN == PLANE_ROWS && TH == PLANE_ROWS, "tiles of the plane arrays");
+    PlaneStage<NTHR, SPLIT_COLS> xq, wq;
     auto fetch = [&](int s) {
         const int hc = hc0 + s / nfc, fc = s % nfc;
-        xt.fetch(x + (size_t)n0 * F + fc * FC, F, N - n0, F - fc * FC, tid);
-        wt.fetch(W1k + (size_t)hc * TH * F + fc * FC, F, nhid - hc * TH, F - fc * FC, tid);
+        if constexpr (SPLIT) {
+            xq.fetch(P.x + plane_tile<SPLIT_COLS>(item.a, fc, P.ncb), tid);
+            wq.fetch(P.w + (size_t)k * P.w_batch + plane_tile<SPLIT_COLS>(hc, fc, P.ncb), tid);
+        } else {
+            xt.fetch(x + (size_t)n0 * F + fc * FC, F, N - n0, F - fc * FC, tid);
+            wt.fetch(W1k + (size_t)hc * TH * F + fc * FC, F, nhid - hc * TH, F - fc * FC, tid);
+        }
     };
     auto stash = [&](int s) {
         if constexpr (SPLIT) {
-            stash_planes(xt, xp + (s & 1) * 3 * TN * SPLIT_PITCH, tid);
-            stash_planes(wt, wp + (s & 1) * 3 * TH * SPLIT_PITCH, tid);
+            xq.stash(xp + (s & 1) * 3 * TN * SPLIT_PITCH, tid);
+            wq.stash(wp + (s & 1) * 3 * TH * SPLIT_PITCH, tid);
         } else {
             xt.template stash<LDT>(xs + (s & 1) * TN * LDT, tid);
             wt.template stash<LDT>(w1s + (s & 1) * TH * LDT, tid);
@@ -176,7 +185,9 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                 mfma_split6(hacc[1], a1, b);
                 if (kb == 0) {
                     if (s + 1 < steps) stash(s + 1);
-                    if (s + 2 < steps) fetch(s + 2);
+                    // unconditional (the last steps fetch the last tile again): a fetch under a condition makes the
+                    // registers a merge of old and new values, and hipcc then waits for the loads right here to copy them
+                    fetch(min(s + 2, steps - 1));
                 }
             }
         } else {
@@ -381,22 +392,39 @@ static int project2_groups(int N, int K, int nhid) {
     return (nhc + cpg - 1) / cpg;
 }
 
-size_t project_fwd_workspace_bytes(int N, int K, int nhid, int d, bool two_layer) {
+// Workspace of the two-layer forward: [Z slabs of the G groups][x planes][W1 planes]
+struct FwdLayout { int G; size_t off_xp, off_wp, bytes; };
+static FwdLayout fwd_layout(int N, int F, int K, int nhid, int d) {
+    FwdLayout L{};
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    L.G = project2_groups(N, K, nhid);
+    size_t off = L.G > 1 ? al(sizeof(float) * (size_t)L.G * N * K * d) : 0;
+    L.off_xp = off;
+    if (split_products()) {
+        off += al(sizeof(__bf16) * project::plane_array_elems(N, F, project::SPLIT_COLS));
+        L.off_wp = off;
+        off += al(sizeof(__bf16) * K * project::plane_array_elems(nhid, F, project::SPLIT_COLS));
+    }
+    L.bytes = off;
+    return L;
+}
+
+size_t project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer) {
     if (!two_layer || N <= 0) return 0;
-    const int G = project2_groups(N, K, nhid);
-    return G > 1 ? sizeof(float) * (size_t)G * N * K * d : 0;
+    return fwd_layout(N, F, K, nhid, d).bytes;
 }
 
 template <int D, bool VEC, bool SPLIT>
 static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float* x, int F, int nhid, const float* W1,
-                      const float* b1, const float* W2, const float* b2, float* out, float* hid_out, int ldh) {
+                      const float* b1, const float* W2, const float* b2, float* out, float* hid_out, int ldh,
+                      project::FwdPlanes P) {
     using namespace project;
     static unsigned long long lds_done = 0;
     constexpr size_t lds = project2_lds(D, SPLIT);
     ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_fwd_kernel<D, VEC, SPLIT>), lds, lds_done);
     const dim3 grid((unsigned)xcd_grid((N + TN - 1) / TN, K * G));
     hipLaunchKernelGGL((project2_fwd_kernel<D, VEC, SPLIT>), grid, dim3(NTHR), lds, st, x, N, F, nhid, W1, b1, W2, b2,
-                       out, K, G, cpg, hid_out, ldh);
+                       out, K, G, cpg, hid_out, ldh, P);
 }
 
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
@@ -410,19 +438,30 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         else hipLaunchKernelGGL(project1_fwd_kernel<128>, grid, block, 0, st, x, N, F, W1, b1, Z, K);
         return check_launch("project_fwd");
     }
-    const bool vec = (F % 4 == 0) && (nhid % 4 == 0);      // quads never straddle a row end
-    int G = project2_groups(N, K, nhid);
-    if (G > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)G * N * K * d)) G = 1;   // no workspace: one group
+    const FwdLayout L = fwd_layout(N, F, K, nhid, d);
+    const bool fits = ws != nullptr && ws_bytes >= L.bytes;
+    const bool split = split_products() && fits;            // no workspace: fp32 MFMA straight from x and W1
+    const bool vec = (split || F % 4 == 0) && (nhid % 4 == 0);      // quads never straddle a row end
+    const int G = fits ? L.G : 1;                           // no workspace: one group
+    FwdPlanes P{};
+    if (split) {
+        char* base = static_cast<char*>(ws);
+        __bf16* xP = reinterpret_cast<__bf16*>(base + L.off_xp);
+        __bf16* wP = reinterpret_cast<__bf16*>(base + L.off_wp);
+        split_rows(x, 1, N, F, F, 0, xP, st);
+        split_rows(W1, K, nhid, F, F, (size_t)nhid * F, wP, st);
+        P = FwdPlanes{xP, wP, plane_array_elems(nhid, F, SPLIT_COLS), plane_chunks<SPLIT_COLS>(F, SPLIT_COLS)};
+    }
     const int nhc = (nhid + TH - 1) / TH;
     const int cpg = (nhc + G - 1) / G;
     float* out = G > 1 ? static_cast<float*>(ws) : Z;
     const float* bias2 = G > 1 ? nullptr : b2;
-    const bool split = split_products();
 #define DL_P2(DD)                                                                                       \
     if (d == DD) {                                                                                      \
-        if (vec && split) launch2_t<DD, true, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);   \
-        else if (vec) launch2_t<DD, true, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);      \
-        else launch2_t<DD, false, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh);              \
+        if (split && vec) launch2_t<DD, true, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);   \
+        else if (split) launch2_t<DD, false, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);    \
+        else if (vec) launch2_t<DD, true, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);      \
+        else launch2_t<DD, false, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);              \
     }
     DL_P2(32) DL_P2(64) DL_P2(128)
 #undef DL_P2

@@ -43,12 +43,17 @@ constexpr int bwd_ht(int D) { return D <= 64 ? 2 : 1; }
 // VEC: F % 4 == 0 (x and W1 rows are sequences of aligned quads).
 // RECOMPUTE = false: the forward kept the hidden layer (hidT [K][nhid][ldh], post-ReLU); it is read straight into the
 // B-operand registers (lane = hidden unit, 4 consecutive nodes per register quad) and layer 1 is not run again.
-template <int D, bool VEC, bool RECOMPUTE>
+// PLANES: dhid leaves as the tile-major bf16 planes of dhid_k^T ([hidden][node], 16-node tiles: the A operand of
+// nodes_contract_planes_kernel) instead of fp32 [node][K][hidden]; every element of the padded array that kernel
+// reads along the node axis is written (zeros past N and past nhid).
+struct DhidPlanes { __bf16* base; size_t batch; int ncb; };       // factor k at base + k * batch; ncb 16-node chunks per row block
+
+template <int D, bool VEC, bool RECOMPUTE, bool PLANES>
 __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     const float* __restrict__ x, int N, int F, int nhid, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ dZ, int K, int tiles_per_range,
     float* __restrict__ dhid, float* __restrict__ dW2p, float* __restrict__ db1p,
-    const float* __restrict__ hidT, int ldh, int hid_cols) {
+    const float* __restrict__ hidT, int ldh, int hid_cols, DhidPlanes dhp) {
     constexpr int DT = D / 32, HT = bwd_ht(D), HB = 64 * HT;
     constexpr int LDZ = D + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -237,8 +242,29 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const float g = hid[ht][r] > 0.0f ? hacc[ht][r] : 0.0f;
                     const int n = n0 + wn * 32 + acc_row(r, half);
-                    if (n < N && h < nhid) dhid[((size_t)n * K + k) * nhid + h] = g;
+                    if constexpr (!PLANES) {
+                        if (n < N && h < nhid) dhid[((size_t)n * K + k) * nhid + h] = g;
+                    }
                     colsum += g;
+                    hacc[ht][r] = g;
+                }
+                if constexpr (PLANES) {                         // registers 4q..4q+3 = 4 consecutive nodes of row h
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * 32 + 8 * q + 4 * half;
+                        bf16x4 p0, p1, p2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            __bf16 hi, mid, lo;
+                            split3(hacc[ht][4 * q + e], hi, mid, lo);
+                            p0[e] = hi; p1[e] = mid; p2[e] = lo;
+                        }
+                        __bf16* o = dhp.base + (size_t)k * dhp.batch + plane_tile<16>(h / PLANE_ROWS, n / 16, dhp.ncb) +
+                                    (h % PLANE_ROWS) * 16 + n % 16;
+                        *reinterpret_cast<bf16x4*>(o) = p0;
+                        *reinterpret_cast<bf16x4*>(o + PLANE_ROWS * 16) = p1;
+                        *reinterpret_cast<bf16x4*>(o + 2 * PLANE_ROWS * 16) = p2;
+                    }
                 }
                 b1acc[ht] += colsum;
                 zero_acc(hacc[ht]);
@@ -372,6 +398,86 @@ __global__ __launch_bounds__(256, 2) void nodes_contract_kernel(const float* __r
         }
 }
 
+// Kernel B on the bf16 matrix path: the same contraction from tile-major plane arrays (dl_tiles.h) — Yp = planes of
+// dhid_k^T ([hidden][node], written by kernel A), Xp = planes of x^T ([feature][node], dl_planes.hip), both in
+// 16-node tiles.  Six exact bf16 products per term (fp32-grade accuracy) at a multiple of the fp32 MFMA rate; the
+// tiles are straight copies (no masks: the arrays are zero-filled along the node axis, and rows past M / F only
+// reach output rows / columns that are not stored).  Node chunk of 16 per step, double-buffered, 2 workgroups per CU.
+constexpr int PC = 16, PPITCH = PC + 8;
+
+__global__ __launch_bounds__(256, 2) void nodes_contract_planes_kernel(const __bf16* __restrict__ Yp, size_t y_batch,
+                                                                       const __bf16* __restrict__ Xp, int ncb, int n_chunks,
+                                                                       int M, int F, int K, int chunks_per_range,
+                                                                       float* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16* ys = reinterpret_cast<__bf16*>(lds);        // [2][3][128][PPITCH]
+    __bf16* xs = ys + 2 * 3 * PLANE_ROWS * PPITCH;
+    const int nf = (F + CT - 1) / CT, nm = (M + CT - 1) / CT;
+    const XcdItem item = xcd_item(blockIdx.x, ((n_chunks + chunks_per_range - 1) / chunks_per_range) * nf, nm * K);
+    if (!item.valid) return;
+    const int fb = item.a % nf, rng = item.a / nf;
+    const int mb = item.b % nm, k = item.b / nm;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wf = wave & 1;
+    const int chunk0 = rng * chunks_per_range;
+    const int my_chunks = max(0, min(chunks_per_range, n_chunks - chunk0));
+    const __bf16* Yk = Yp + (size_t)k * y_batch;
+
+    PlaneStage<256, PC> yq, xq;
+    auto fetch = [&](int c) {
+        yq.fetch(Yk + plane_tile<PC>(mb, chunk0 + c, ncb), tid);
+        xq.fetch(Xp + plane_tile<PC>(fb, chunk0 + c, ncb), tid);
+    };
+    auto stash = [&](int c) {
+        yq.stash(ys + (c & 1) * 3 * PLANE_ROWS * PPITCH, tid);
+        xq.stash(xs + (c & 1) * 3 * PLANE_ROWS * PPITCH, tid);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) zero_acc(acc[a][b]);
+    if (my_chunks > 0) {
+        fetch(0);
+        stash(0);
+        fetch(min(1, my_chunks - 1));
+    }
+    __syncthreads();
+    for (int c = 0; c < my_chunks; ++c) {
+        // lane half h supplies nodes 8h .. 8h+7 of the chunk: A = hidden rows of this wave (2 tiles), B = feature rows
+        const __bf16* yb = ys + (c & 1) * 3 * PLANE_ROWS * PPITCH + (wm * 64 + li) * PPITCH + half * 8;
+        const __bf16* xb = xs + (c & 1) * 3 * PLANE_ROWS * PPITCH + (wf * 64 + li) * PPITCH + half * 8;
+        bf16x8 a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a0[p] = *reinterpret_cast<const bf16x8*>(yb + p * PLANE_ROWS * PPITCH);
+            a1[p] = *reinterpret_cast<const bf16x8*>(yb + (p * PLANE_ROWS + 32) * PPITCH);
+            b0[p] = *reinterpret_cast<const bf16x8*>(xb + p * PLANE_ROWS * PPITCH);
+            b1[p] = *reinterpret_cast<const bf16x8*>(xb + (p * PLANE_ROWS + 32) * PPITCH);
+        }
+        mfma_split6(acc[0][0], a0, b0);
+        mfma_split6(acc[0][1], a0, b1);
+        if (c + 1 < my_chunks) stash(c + 1);                    // staging in the shadow of the MFMAs
+        fetch(min(c + 2, my_chunks - 1));                       // unconditional: see project2_fwd_kernel
+        mfma_split6(acc[1][0], a1, b0);
+        mfma_split6(acc[1][1], a1, b1);
+        __syncthreads();
+    }
+    float* out = C + ((size_t)rng * K + k) * M * F;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int f = fb * CT + wf * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb * CT + wm * 64 + a * 32 + acc_row(r, half);
+                if (m < M && f < F) out[(size_t)m * F + f] = acc[a][b][r];
+            }
+        }
+}
+
 // out[i] (+)= sum_s slabs[s][i], s ascending (fixed order), for up to 4 independent (slabs, out) jobs in one
 // launch (the four gradients of a backward); accumulate: on top of what out holds (node blocks).
 struct SlabJob { const float* slabs; float* out; size_t n; int S; unsigned block0; };
@@ -410,7 +516,9 @@ struct BwdLayout {
     int sB, chunks_per_range;      // kernel B node ranges
     int sC, rows_per_range;        // colsum ranges
     int Mb;                        // rows of the kernel-B output per factor (nhid, or d for one layer)
-    size_t off_dhid, off_w1p, off_w2p, off_b1p, off_b2p, bytes;
+    size_t off_dhid, off_xT, off_w1p, off_w2p, off_b1p, off_b2p, bytes;
+    bool planes;                   // dhid and x^T as bf16 plane arrays (kernel B on the bf16 matrix path)
+    int ncb, n_chunks16;           // 16-node chunks per row block of the plane arrays / chunks that hold nodes
 };
 
 static int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -422,7 +530,7 @@ static int bwd_block_rows(int N, int K, int nhid, bool two_layer) {
     if (!two_layer) return N;
     long long cap_bytes = 1LL << 30;
     if (const char* e = getenv("DL_BWD_BLOCK_BYTES")) cap_bytes = std::max(1LL, atoll(e));   // tests: force blocking
-    const long long cap = cap_bytes / ((long long)K * nhid * 4);
+    const long long cap = cap_bytes / ((long long)K * nhid * (split_products() ? 6 : 4));
     const long long rows = std::max<long long>(4096, cap / TILE_N * TILE_N);
     return (int)std::min<long long>(N, rows);
 }
@@ -442,14 +550,17 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
         const long long by_steps = n_units / std::max(1, ceil_div(min_steps, steps_per_unit));
         return (int)std::max(1LL, std::min<long long>(n_units, std::min(hi, std::max(lo, by_steps))));
     };
-    const int n_tiles = ceil_div(N, TILE_N), n_chunks = ceil_div(N, NC);
+    L.planes = two_layer && split_products();
+    L.ncb = plane_chunks<PC>(N, PLANE_ROWS);
+    L.n_chunks16 = ceil_div(N, PC);
+    const int n_tiles = ceil_div(N, TILE_N), n_chunks = L.planes ? L.n_chunks16 : ceil_div(N, NC);
     L.Mb = two_layer ? nhid : d;
     const long long wgA = (long long)ceil_div(nhid, 64 * bwd_ht(d)) * K;
     L.sA = pick(n_tiles, recompute ? ceil_div(F, BFC) : 3, wgA, 24);
     L.tiles_per_range = ceil_div(n_tiles, L.sA);
     L.sA = ceil_div(n_tiles, L.tiles_per_range);
     const long long wgB = (long long)ceil_div(L.Mb, CT) * ceil_div(F, CT) * K;
-    L.sB = pick(n_chunks, 1, wgB, 20);
+    L.sB = pick(n_chunks, 1, wgB, L.planes ? 40 : 20);
     L.chunks_per_range = ceil_div(n_chunks, L.sB);
     L.sB = ceil_div(n_chunks, L.chunks_per_range);
     const int colblocks = ceil_div((long long)K * d, 64);
@@ -457,7 +568,14 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
     L.rows_per_range = ceil_div(N, L.sC);
     L.sC = ceil_div(N, L.rows_per_range);
     size_t off = 0;
-    L.off_dhid = off; off += two_layer ? al(sizeof(float) * (size_t)N * K * nhid) : 0;
+    L.off_dhid = off;
+    if (L.planes) {
+        off += al(sizeof(__bf16) * K * plane_array_elems(nhid, N, PLANE_ROWS));
+        L.off_xT = off;
+        off += al(sizeof(__bf16) * plane_array_elems(F, N, PLANE_ROWS));
+    } else {
+        off += two_layer ? al(sizeof(float) * (size_t)N * K * nhid) : 0;
+    }
     L.off_w1p = off;  off += (L.sB > 1 || blocked) ? al(sizeof(float) * (size_t)L.sB * K * L.Mb * F) : 0;
     L.off_w2p = off;  off += two_layer ? al(sizeof(float) * (size_t)L.sA * K * d * nhid) : 0;
     L.off_b1p = off;  off += two_layer ? al(sizeof(float) * (size_t)L.sA * K * nhid) : 0;
@@ -482,16 +600,26 @@ size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool tw
     return bytes;
 }
 
-template <int D, bool VEC, bool RECOMPUTE>
+template <int D, bool VEC, bool RECOMPUTE, bool PLANES>
 static void launchA_t(dim3 grid, hipStream_t st, const float* x, int N, int F, int nhid, const float* W1,
                       const float* b1, const float* W2, const float* dZ, int K, int tpr, float* dhid, float* dW2p,
-                      float* db1p, const float* hidT, int ldh, int hid_cols) {
+                      float* db1p, const float* hidT, int ldh, int hid_cols, project::DhidPlanes dhp) {
     using namespace project;
     static unsigned long long lds_done = 0;
     constexpr size_t lds = project2_bwd_lds(D);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC, RECOMPUTE>), lds, lds_done);
-    hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC, RECOMPUTE>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1, b1,
-                       W2, dZ, K, tpr, dhid, dW2p, db1p, hidT, ldh, hid_cols);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&project2_bwd_hidden_kernel<D, VEC, RECOMPUTE, PLANES>), lds, lds_done);
+    hipLaunchKernelGGL((project2_bwd_hidden_kernel<D, VEC, RECOMPUTE, PLANES>), grid, dim3(BTHR), lds, st, x, N, F, nhid, W1,
+                       b1, W2, dZ, K, tpr, dhid, dW2p, db1p, hidT, ldh, hid_cols, dhp);
+}
+
+template <int D, bool VEC, bool RECOMPUTE>
+static void launchA_p(bool planes, dim3 grid, hipStream_t st, const float* x, int N, int F, int nhid, const float* W1,
+                      const float* b1, const float* W2, const float* dZ, int K, int tpr, float* dhid, float* dW2p,
+                      float* db1p, const float* hidT, int ldh, int hid_cols, project::DhidPlanes dhp) {
+    if (planes) launchA_t<D, VEC, RECOMPUTE, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, tpr, dhid, dW2p, db1p, hidT, ldh,
+                                                   hid_cols, dhp);
+    else launchA_t<D, VEC, RECOMPUTE, false>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, tpr, dhid, dW2p, db1p, hidT, ldh,
+                                             hid_cols, dhp);
 }
 
 struct SlabBatch {
@@ -531,16 +659,19 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
 
     const float* Y = dZ;
     int ldY = K * d;
+    __bf16* dhP = reinterpret_cast<__bf16*>(base + L.off_dhid);
+    __bf16* xTP = reinterpret_cast<__bf16*>(base + L.off_xT);
+    const DhidPlanes dhp{dhP, plane_array_elems(nhid, N, PLANE_ROWS), L.ncb};
     if (two) {
         const dim3 grid((unsigned)xcd_grid(L.sA, ceil_div(nhid, 64 * bwd_ht(d)) * K));
 #define DL_PA(DD)                                                                                               \
     if (d == DD) {                                                                                              \
-        if (hidT) launchA_t<DD, true, false>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p,  \
-                                             b1p, hidT, ldh, hid_cols);                                          \
-        else if (vecA) launchA_t<DD, true, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid,   \
-                                                 w2p, b1p, nullptr, 0, 0);                                       \
-        else launchA_t<DD, false, true>(grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p, b1p, \
-                                        nullptr, 0, 0);                                                          \
+        if (hidT) launchA_p<DD, true, false>(L.planes, grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid,   \
+                                             w2p, b1p, hidT, ldh, hid_cols, dhp);                                       \
+        else if (vecA) launchA_p<DD, true, true>(L.planes, grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range,    \
+                                                 dhid, w2p, b1p, nullptr, 0, 0, dhp);                                   \
+        else launchA_p<DD, false, true>(L.planes, grid, st, x, N, F, nhid, W1, b1, W2, dZ, K, L.tiles_per_range, dhid, w2p,  \
+                                        b1p, nullptr, 0, 0, dhp);                                                       \
     }
         DL_PA(32) DL_PA(64) DL_PA(128)
 #undef DL_PA
@@ -549,7 +680,18 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
         Y = dhid;
         ldY = K * nhid;
     }
-    {
+    if (L.planes) {
+        static unsigned long long lds_done_p = 0;
+        const size_t lds = sizeof(__bf16) * 2 * 2 * 3 * PLANE_ROWS * PPITCH;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&nodes_contract_planes_kernel), lds, lds_done_p);
+        split_transposed(x, N, F, F, xTP, st);
+        const dim3 grid((unsigned)xcd_grid(L.sB * ceil_div(F, CT), ceil_div(L.Mb, CT) * K));
+        const bool direct = L.sB == 1 && !blocked;
+        float* out = direct ? dW1 : w1p;
+        hipLaunchKernelGGL(nodes_contract_planes_kernel, grid, dim3(256), lds, st, dhP, dhp.batch, xTP, L.ncb, L.n_chunks16,
+                           L.Mb, F, K, L.chunks_per_range, out);
+        if (!direct) sums.add(w1p, L.sB, (size_t)K * L.Mb * F, dW1);
+    } else {
         static unsigned long long lds_done_v = 0, lds_done_s = 0;
         const size_t lds = sizeof(float) * 4 * NC * LDC;
         ensure_dynamic_lds(reinterpret_cast<const void*>(&nodes_contract_kernel<true>), lds, lds_done_v);

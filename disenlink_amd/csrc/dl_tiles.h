@@ -175,5 +175,47 @@ __device__ __forceinline__ void stash_planes(const TileStage<ROWS, SPLIT_COLS, t
     }
 }
 
+// The same three planes kept in global memory (dl_planes.hip: split once per call instead of once per workgroup
+// that stages the tile), TILE-MAJOR: the matrix is cut into [128 rows][COLS cols] tiles (COLS = 32 or 16 = the K
+// extent one pipeline step of the consuming kernel contracts), each stored as one contiguous block
+// [3 planes][128][COLS] bf16 — the order the kernels consume it in, so a tile is a straight, fully coalesced copy
+// global -> registers -> LDS image [3][128][COLS + 8] without masks (rows and columns are zero-filled out to
+// multiples of 128 rows and of the array's column padding).  Tile (rb, cb) of a matrix with ncb column chunks starts at plane_tile<COLS>(rb, cb, ncb).
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+constexpr int PLANE_ROWS = 128;
+template <int COLS>
+__host__ __device__ inline size_t plane_tile(int rb, int cb, int ncb) { return ((size_t)rb * ncb + cb) * 3 * PLANE_ROWS * COLS; }
+// elements of the plane array of a [rows][cols] matrix whose columns are padded to a multiple of col_pad
+inline size_t plane_array_elems(size_t rows, size_t cols, int col_pad) { return 3 * round_up(rows, PLANE_ROWS) * round_up(cols, col_pad); }
+template <int COLS>
+inline int plane_chunks(size_t cols, int col_pad) { return (int)(round_up(cols, col_pad) / COLS); }
+
+template <int THREADS, int COLS>
+struct PlaneStage {
+    static constexpr int PIECES = PLANE_ROWS * COLS / 8;       // 16-byte pieces per plane of the tile
+    static constexpr int PITCH = COLS + 8;                     // LDS row pitch (bf16): conflict-free b128 reads
+    static_assert(PIECES % THREADS == 0, "a plane of the tile divides over the workgroup");
+    static constexpr int PER = PIECES / THREADS;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));    // (HIP's uint4 class kept the array in scratch)
+    u32x4 v[3 * PER];
+    __device__ __forceinline__ void fetch(const __bf16* __restrict__ tile, int tid) {
+#pragma unroll
+        for (int j = 0; j < 3 * PER; ++j) v[j] = *reinterpret_cast<const u32x4*>(tile + (unsigned)((tid + THREADS * j) * 8));
+    }
+    __device__ __forceinline__ void stash(__bf16* lds, int tid) const {
+#pragma unroll
+        for (int j = 0; j < 3 * PER; ++j) {
+            const int q = tid + THREADS * j, p = q / PIECES, r = (q % PIECES) / (COLS / 8), c = (q % (COLS / 8)) * 8;
+            *reinterpret_cast<u32x4*>(lds + (p * PLANE_ROWS + r) * PITCH + c) = v[j];
+        }
+    }
+};
+
+// dl_planes.hip: tile-major planes of B matrices src [B][R][C] (row stride ld, batch stride sb; matrix b starts at
+// dst + b * plane_array_elems(R, C)), and of the TRANSPOSE of src [R][C] (rows = c, columns = r); everything out to
+// the padded extents is written.
+void split_rows(const float* src, int B, int R, int C, int ld, size_t sb, __bf16* dst, hipStream_t st);      // 32-column tiles, columns padded to 32
+void split_transposed(const float* src, int R, int C, int ld, __bf16* dst, hipStream_t st);                 // 16-column tiles, columns (= R) padded to 128
+
 }  // namespace project
 }  // namespace dl
