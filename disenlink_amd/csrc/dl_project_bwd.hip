@@ -248,22 +248,38 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
                     colsum += g;
                     hacc[ht][r] = g;
                 }
-                if constexpr (PLANES) {                         // registers 4q..4q+3 = 4 consecutive nodes of row h
+                if constexpr (PLANES) {
+                    // Registers 4q..4q+3 of lane half t are the nodes 8q + 4t .. +3 of row h.  A 16-node tile row
+                    // (32 bytes per plane) is [t=0,q=0][t=1,q=0][t=0,q=1][t=1,q=1]: the halves swap one quad (half 0
+                    // gives its q=1, half 1 its q=0) and each writes 16 contiguous bytes — whole 32-byte sectors.
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + wn * 32 + 8 * q + 4 * half;
-                        bf16x4 p0, p1, p2;
+                    for (int qq = 0; qq < 2; ++qq) {
+                        bf16x4 pl[2][3];                                    // [q - 2qq][plane]
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            __bf16 hi, mid, lo;
-                            split3(hacc[ht][4 * q + e], hi, mid, lo);
-                            p0[e] = hi; p1[e] = mid; p2[e] = lo;
-                        }
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                __bf16 hi, mid, lo;
+                                split3(hacc[ht][4 * (2 * qq + j) + e], hi, mid, lo);
+                                pl[j][0][e] = hi; pl[j][1][e] = mid; pl[j][2][e] = lo;
+                            }
+                        const int n = n0 + wn * 32 + 16 * qq;
                         __bf16* o = dhp.base + (size_t)k * dhp.batch + plane_tile<16>(h / PLANE_ROWS, n / 16, dhp.ncb) +
-                                    (h % PLANE_ROWS) * 16 + n % 16;
-                        *reinterpret_cast<bf16x4*>(o) = p0;
-                        *reinterpret_cast<bf16x4*>(o + PLANE_ROWS * 16) = p1;
-                        *reinterpret_cast<bf16x4*>(o + 2 * PLANE_ROWS * 16) = p2;
+                                    (h % PLANE_ROWS) * 16 + half * 8;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 mine0 = __builtin_bit_cast(u32x2, pl[0][p]), mine1 = __builtin_bit_cast(u32x2, pl[1][p]);
+                            const u32x2 give = half ? mine0 : mine1;
+                            u32x2 got;
+                            got.x = __shfl_xor(give.x, 32);
+                            got.y = __shfl_xor(give.y, 32);
+                            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                            u32x4 outv;
+                            if (half) { outv.x = got.x; outv.y = got.y; outv.z = mine1.x; outv.w = mine1.y; }
+                            else { outv.x = mine0.x; outv.y = mine0.y; outv.z = got.x; outv.w = got.y; }
+                            *reinterpret_cast<u32x4*>(o + p * PLANE_ROWS * 16) = outv;
+                        }
                     }
                 }
                 b1acc[ht] += colsum;

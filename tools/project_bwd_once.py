@@ -15,7 +15,12 @@ x, dZ = torch.randn(N, F, device=dev), torch.randn(N, K, d, device=dev)
 W1 = torch.randn(K, nhid if two else d, F, device=dev) / F ** 0.5
 b1 = torch.randn(K, nhid if two else d, device=dev) * 0.1
 W2 = torch.randn(K, d, nhid, device=dev) / nhid ** 0.5 if two else None
+b2 = torch.zeros(K, d, device=dev) if two else None
 for _ in range(10):
-    ops.project_bwd(x, W1, b1, W2, dZ)
-    ops.project_fwd(x, W1, b1, W2, torch.zeros(K, d, device=dev) if two else None)
+    ops.project_bwd(x, W1, b1, W2, dZ)                      # recompute form
+    if two:
+        Z, hid = ops.project_fwd(x, W1, b1, W2, b2, keep_hid=True)
+        ops.project_bwd(x, W1, b1, W2, dZ, hid=hid)         # kept-hidden form
+    else:
+        ops.project_fwd(x, W1, b1)
 torch.cuda.synchronize()
