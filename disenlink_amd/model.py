@@ -49,12 +49,13 @@ class Disentangle(nn.Module):
         """Extensions (the reference has neither):
         ``table_dtype``: storage type of the gathered Z / H tables in ``forward_pairs`` — torch.float32
         (reference precision) or torch.bfloat16 (half the gather bytes, fp32 arithmetic and gradients).
-        ``projection``: "mfma" = the fused fp32 MFMA kernels of libdisenlink_hip.so (forward and backward; the hidden
+        ``projection``: "mfma" = the fused matrix-core kernels of libdisenlink_hip.so (forward and backward; fp32
+        results — layer 1 and the dW1 contraction run as six exact bf16 products per term; the hidden
         layer is written once, transposed, for the backward while it fits a few GB and recomputed beyond that),
-        "library" = library GEMMs (rocBLAS through torch), "auto" = the kernels where the epoch measured equal or
-        faster with them: F <= 1024 (squirrel epoch 2.13 vs 2.16 ms at F=512, 2.77 vs 2.75 at 1024, 3.64 vs 3.40 at
-        2089: there layer 1 is one big plain GEMM and the library's is ~10 % faster; tools/epoch_time.py, DESIGN.md
-        §3) — and whenever the library path's [N,K,nhid] activations would run to several GB."""
+        "library" = library GEMMs (rocBLAS through torch), "auto" = the kernels wherever they support the factor width
+        (d in {32, 64, 128}): measured equal or faster than the library path at every feature width (squirrel epoch
+        1.64 vs 1.75 ms at F=128, 1.93 vs 2.06 at 512, 2.17 vs 2.36 at 1024, 2.74 vs 3.20 at 2089; real Cora
+        (F=1433) 1.32 vs 1.60; tools/epoch_time.py), and they never materialise the [N,K,nhid] activations."""
         super().__init__()
         if projection not in ("auto", "mfma", "library"):
             raise ValueError("projection must be 'auto', 'mfma' or 'library'")
@@ -135,16 +136,11 @@ class Disentangle(nn.Module):
     # ------------------------------------------------------------------ projection (model.py:106)
     def project(self, x: torch.Tensor) -> torch.Tensor:
         """Z [N,K,d] = K independent MLPs of x.  On the GPU (d in {32,64,128}, see ``projection``): the fused MFMA
-        kernels of libdisenlink_hip.so.  Otherwise (wide features, CPU tests of the host logic, odd d): one wide
-        library GEMM + one K-batched GEMM — plain torch plumbing, the reference's own ops."""
+        kernels of libdisenlink_hip.so.  Otherwise (CPU tests of the host logic, odd d, projection="library"): one
+        wide library GEMM + one K-batched GEMM — plain torch plumbing, the reference's own ops."""
         fs = self.factors
         K, d = self.nfactor, self.nebed
         use_kernel = x.is_cuda and x.dtype == torch.float32 and self.projection != "library" and ops.project_supported(d)
-        if use_kernel and self.projection == "auto":
-            # measured: tools/epoch_time.py, DESIGN.md §3; past a few GB the library path's [N,K,nhid] activations
-            # (kept for its backward) are what decides: the kernels never materialise them
-            hidden_bytes = x.shape[0] * K * (1 if self.single_layer else fs[0].mlp1.out_features) * 4
-            use_kernel = x.shape[1] <= 1024 or hidden_bytes > (4 << 30)
         if use_kernel:
             flat = self._stacked_params()
             if flat is not None:                                # zero-copy: the kernel reads the shared buffers

@@ -471,9 +471,9 @@ def test_real_data_auc_parity_with_the_reference_model(name):
     1e-4 on the same edge splits".  tests/golden/real_<name>.npz holds the real dataset arrays and what the reference
     model produced on CPU (30 epochs of the reference schedule, make_real_data.py).  Here: the same data, split and
     seeded initial weights through (a) the drop-in module inside the reference's dense-mask loop and (b) the scalable
-    pair-list loop — per-epoch loss, validation AUC and the final test AUC.  (Cora's 1,433 features take the
-    library-GEMM projection path, chameleon's 128 the MFMA kernels; squirrel = the real 217k-row edge list with
-    seeded features, the configuration the benchmark is quoted on.)"""
+    pair-list loop — per-epoch loss, validation AUC and the final test AUC.  (All three run the projection kernels:
+    Cora's 1,433 features exercise the padded feature tails of the plane arrays; squirrel = the real 217k-row edge
+    list with seeded features, the configuration the benchmark is quoted on.)"""
     import json
     import os
     import torch.nn.functional as F
@@ -1030,4 +1030,45 @@ def test_fused_pair_bce_matches_torch_bce():
         pair_bce_loss(bad[:n_pos], label[:n_pos], bad[n_pos:], label[n_pos:], m)                       # torch, on the CPU
     w0 = w.clone()
     w0[5] = 0.0
-    assert torch.isfinite(pair_bce_loss_fused(bad.to(DEV), lt, w0))
+    assert torch.isfinite(pair_bce_loss_fused(bad.to(DEV), lt, w0))@pytest.mark.gpu
+def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
+    """Layer 1 and the dW1 contraction run as six exact bf16 products per term from three bf16 planes per operand
+    (dl_tiles.h).  Full-mantissa random operands, odd sizes (feature / node / hidden tails of the padded plane arrays):
+    the error against fp64 stays within 2x that of the plain fp32 MFMA form (DL_PROJECT_FP32_MFMA=1) and within fp32
+    summation noise — and a wide dynamic range inside one row (1e-6 .. 1e+3) loses nothing."""
+    from disenlink_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (N, F, K, nhid, d) in [(1000, 333, 3, 200, 64), (517, 1436, 2, 96, 32), (300, 100, 2, 130, 128)]:
+        x = torch.randn(N, F, generator=g) * torch.logspace(-6, 3, F)[torch.randperm(F, generator=g)]
+        W1 = torch.randn(K, nhid, F, generator=g) / F ** 0.5
+        b1 = torch.randn(K, nhid, generator=g) * 0.1
+        W2 = torch.randn(K, d, nhid, generator=g) / nhid ** 0.5
+        b2 = torch.randn(K, d, generator=g) * 0.1
+        dZ = torch.randn(N, K, d, generator=g)
+        X = x.double()
+        pre = torch.einsum("nf,khf->nkh", X, W1.double()) + b1.double()
+        hid = pre.clamp_min(0)
+        Zref = torch.einsum("nkh,kdh->nkd", hid, W2.double()) + b2.double()
+        dev = [v.to(DEV) for v in (x, W1, b1, W2, dZ)]
+        errs = {}
+        for form in ("planes", "fp32"):
+            if form == "fp32":
+                monkeypatch.setenv("DL_PROJECT_FP32_MFMA", "1")
+            else:
+                monkeypatch.delenv("DL_PROJECT_FP32_MFMA", raising=False)
+            Z, kept = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2.to(DEV), keep_hid=True)
+            dW1 = ops.project_bwd(*dev, hid=kept)[0]
+            # reference gradient with the ReLU mask this run actually used (near-zero pre-activations may flip in fp32)
+            ldh = (N + 3) // 4 * 4
+            mask = (kept.view(K, nhid, ldh)[:, :, :N] > 0).permute(2, 0, 1).cpu()
+            dh = torch.einsum("nkd,kdh->nkh", dZ.double(), W2.double()) * mask
+            dW1ref = torch.einsum("nkh,nf->khf", dh, X)
+            errs[form] = (float((Z.cpu().double() - Zref).abs().max() / Zref.abs().max()),
+                          float((dW1.cpu().double() - dW1ref).abs().max() / dW1ref.abs().max()))
+        monkeypatch.delenv("DL_PROJECT_FP32_MFMA", raising=False)
+        for i, what in enumerate(("Z", "dW1")):
+            assert errs["planes"][i] <= max(2.0 * errs["fp32"][i], 2e-7), (what, errs, (N, F, K, nhid, d))
+            assert errs["planes"][i] <= 5e-6, (what, errs)
+
+
+
