@@ -392,16 +392,25 @@ static int project2_groups(int N, int K, int nhid) {
     return (nhc + cpg - 1) / cpg;
 }
 
-// Workspace of the two-layer forward: [Z slabs of the G groups][x planes][W1 planes]
-struct FwdLayout { int G; size_t off_xp, off_wp, bytes; };
+// Node block of the two-layer forward: the x planes are made per block of rows, so the workspace does not grow with
+// the graph (2.9M nodes x 288 features would be 5 GB of planes).  Large graphs only — they never use the group split.
+static int fwd_block_rows(int N) {
+    long long rows = 1 << 17;
+    if (const char* e = getenv("DL_FWD_BLOCK_ROWS")) rows = std::max(1LL, atoll(e)) * project::TN;   // tests: force blocking
+    return N <= 2 * rows ? N : (int)rows;
+}
+
+// Workspace of the two-layer forward: [Z slabs of the G groups][x planes of one node block][W1 planes]
+struct FwdLayout { int G, R; size_t off_xp, off_wp, bytes; };
 static FwdLayout fwd_layout(int N, int F, int K, int nhid, int d) {
     FwdLayout L{};
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    L.G = project2_groups(N, K, nhid);
+    L.R = fwd_block_rows(N);
+    L.G = L.R < N ? 1 : project2_groups(N, K, nhid);
     size_t off = L.G > 1 ? al(sizeof(float) * (size_t)L.G * N * K * d) : 0;
     L.off_xp = off;
     if (split_products()) {
-        off += al(sizeof(__bf16) * project::plane_array_elems(N, F, project::SPLIT_COLS));
+        off += al(sizeof(__bf16) * project::plane_array_elems(L.R, F, project::SPLIT_COLS));
         L.off_wp = off;
         off += al(sizeof(__bf16) * K * project::plane_array_elems(nhid, F, project::SPLIT_COLS));
     }
@@ -448,7 +457,6 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         char* base = static_cast<char*>(ws);
         __bf16* xP = reinterpret_cast<__bf16*>(base + L.off_xp);
         __bf16* wP = reinterpret_cast<__bf16*>(base + L.off_wp);
-        split_rows(x, 1, N, F, F, 0, xP, st);
         split_rows(W1, K, nhid, F, F, (size_t)nhid * F, wP, st);
         P = FwdPlanes{xP, wP, plane_array_elems(nhid, F, SPLIT_COLS), plane_chunks<SPLIT_COLS>(F, SPLIT_COLS)};
     }
@@ -456,15 +464,23 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
     const int cpg = (nhc + G - 1) / G;
     float* out = G > 1 ? static_cast<float*>(ws) : Z;
     const float* bias2 = G > 1 ? nullptr : b2;
+    const int R = fits ? L.R : N;                           // rows per launch (G == 1 whenever R < N)
+    for (int row0 = 0; row0 < N; row0 += R) {
+        const int rows = std::min(R, N - row0);
+        const float* xb = x + (size_t)row0 * F;
+        float* ob = out + (size_t)row0 * K * d;
+        float* hb = hid_out ? hid_out + row0 : nullptr;
+        if (split) split_rows(xb, 1, rows, F, F, 0, const_cast<__bf16*>(P.x), st);
 #define DL_P2(DD)                                                                                       \
     if (d == DD) {                                                                                      \
-        if (split && vec) launch2_t<DD, true, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);   \
-        else if (split) launch2_t<DD, false, true>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);    \
-        else if (vec) launch2_t<DD, true, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);      \
-        else launch2_t<DD, false, false>(N, K, G, cpg, st, x, F, nhid, W1, b1, W2, bias2, out, hid_out, ldh, P);              \
+        if (split && vec) launch2_t<DD, true, true>(rows, K, G, cpg, st, xb, F, nhid, W1, b1, W2, bias2, ob, hb, ldh, P);   \
+        else if (split) launch2_t<DD, false, true>(rows, K, G, cpg, st, xb, F, nhid, W1, b1, W2, bias2, ob, hb, ldh, P);    \
+        else if (vec) launch2_t<DD, true, false>(rows, K, G, cpg, st, xb, F, nhid, W1, b1, W2, bias2, ob, hb, ldh, P);      \
+        else launch2_t<DD, false, false>(rows, K, G, cpg, st, xb, F, nhid, W1, b1, W2, bias2, ob, hb, ldh, P);              \
     }
-    DL_P2(32) DL_P2(64) DL_P2(128)
+        DL_P2(32) DL_P2(64) DL_P2(128)
 #undef DL_P2
+    }
     if (G > 1) {
         const size_t NC = (size_t)N * K * d;
         hipLaunchKernelGGL(z_slab_sum_kernel, dim3((unsigned)((NC / 4 + 255) / 256)), dim3(256), 0, st, out, G, NC, K * d, b2, Z);

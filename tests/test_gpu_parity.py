@@ -869,6 +869,14 @@ def test_projection_backward_in_node_blocks(monkeypatch):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (name, "kept hidden layer, node blocks")
     for name, a, b in zip(("dW1", "db1", "dW2", "db2"), whole, blocks):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
+    # the forward makes its x planes per node block on large graphs (block forced down here): same bits
+    monkeypatch.delenv("DL_BWD_BLOCK_BYTES")
+    b2 = torch.randn(K, d, generator=g).to(DEV)
+    Z1, hid1 = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2, keep_hid=True)
+    monkeypatch.setenv("DL_FWD_BLOCK_ROWS", "8")                     # 1024-row blocks
+    Z2, hid2 = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2, keep_hid=True)
+    ldh = (N + 3) // 4 * 4
+    assert torch.equal(Z1, Z2) and torch.equal(hid1.view(K, nhid, ldh)[:, :, :N], hid2.view(K, nhid, ldh)[:, :, :N])
 
 
 def test_projection_kernels_at_snap_patents_scale():
