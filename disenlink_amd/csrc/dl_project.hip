@@ -1,7 +1,8 @@
 // Factor projection Z[n][k][:] = MLP_k(x[n]) on the matrix cores (model.py:13-15, 24-27, 106) — the
-// only dense contraction of the path.  fp32 in / fp32 accumulate with v_mfma_f32_32x32x2_f32, which
-// is bit-for-bit a k-ordered fmaf chain (no reduced precision), so the result keeps the
-// reference's fp32 semantics up to summation order.
+// only dense contraction of the path.  fp32 in / fp32 results: layer 1 as six exact bf16 products per term
+// from three bf16 planes per operand (dl_tiles.h; fp32-grade accuracy), or — without a workspace, with
+// DL_PROJECT_FP32_MFMA=1, and always for layer 2 — v_mfma_f32_32x32x2_f32, which is bit-for-bit a k-ordered
+// fmaf chain; either way the result keeps the reference's fp32 semantics up to rounding / summation order.
 //
 // Two-layer form (Factor2): one workgroup = 8 waves = 128 nodes x ONE factor k, looping over (a group
 // of) 128-unit chunks of the hidden layer.  Waves are 4 x 2: node quarter wn, hidden half wh; each wave
@@ -14,8 +15,8 @@
 // the B-operand shape of the next MFMA when that product sums over the accumulator's ROW index
 // (register r supplies the k-pair {acc_row(r,0), acc_row(r,1)}); so the hidden activations never leave
 // the register file — no [N, K*nhid] tensor is written to HBM and re-read, unlike two library GEMMs.
-// The layer-1 operand tiles ([128 rows][32 features], row pitch 36 floats: aligned, conflict-free b128
-// reads) are double-buffered in LDS and the next step's tiles are fetched into registers behind the
+// The layer-1 operand tiles ([128 rows][32 features]: three bf16 planes at an 80-byte row pitch, or fp32 at
+// 36 / 68 floats: aligned, conflict-free b128 reads) are double-buffered in LDS and the next step's tiles are fetched into registers behind the
 // current step's MFMAs; the W2 operand (A[i = d][k = hidden], 4 consecutive hidden units per register
 // quad) is read straight from global memory, one d-tile ahead of its use.  The two hidden halves of a
 // node's Z are added through LDS at the end (fixed order).
@@ -172,24 +173,24 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
             // lane half h supplies features 8h .. 8h+7 of each 16-wide block: A = W1 rows (two hidden tiles), B = x rows
             const __bf16* xb = xp + (s & 1) * 3 * TN * SPLIT_PITCH + (wn * 32 + li) * SPLIT_PITCH + half * 8;
             const __bf16* wb = wp + (s & 1) * 3 * TH * SPLIT_PITCH + (wh * 64 + li) * SPLIT_PITCH + half * 8;
+            // both K = 16 blocks of the chunk are read up front: block 1's LDS latency hides behind block 0's MFMAs
+            bf16x8 a0[2][3], a1[2][3], b[2][3];
 #pragma unroll
-            for (int kb = 0; kb < SPLIT_COLS / 16; ++kb) {
-                bf16x8 a0[3], a1[3], b[3];
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    b[p] = *reinterpret_cast<const bf16x8*>(xb + p * TN * SPLIT_PITCH + kb * 16);
-                    a0[p] = *reinterpret_cast<const bf16x8*>(wb + p * TH * SPLIT_PITCH + kb * 16);
-                    a1[p] = *reinterpret_cast<const bf16x8*>(wb + (p * TH + 32) * SPLIT_PITCH + kb * 16);
+                    b[kb][p] = *reinterpret_cast<const bf16x8*>(xb + p * TN * SPLIT_PITCH + kb * 16);
+                    a0[kb][p] = *reinterpret_cast<const bf16x8*>(wb + p * TH * SPLIT_PITCH + kb * 16);
+                    a1[kb][p] = *reinterpret_cast<const bf16x8*>(wb + (p * TH + 32) * SPLIT_PITCH + kb * 16);
                 }
-                mfma_split6(hacc[0], a0, b);
-                mfma_split6(hacc[1], a1, b);
-                if (kb == 0) {
-                    if (s + 1 < steps) stash(s + 1);
-                    // unconditional (the last steps fetch the last tile again): a fetch under a condition makes the
-                    // registers a merge of old and new values, and hipcc then waits for the loads right here to copy them
-                    fetch(min(s + 2, steps - 1));
-                }
-            }
+            mfma_split6(hacc[0], a0[0], b[0]);
+            mfma_split6(hacc[1], a1[0], b[0]);
+            if (s + 1 < steps) stash(s + 1);
+            // unconditional (the last steps fetch the last tile again): a fetch under a condition makes the
+            // registers a merge of old and new values, and hipcc then waits for the loads right here to copy them
+            fetch(min(s + 2, steps - 1));
+            mfma_split6(hacc[0], a0[1], b[1]);
+            mfma_split6(hacc[1], a1[1], b[1]);
         } else {
         // lane half h owns features h*FC/2 .. h*FC/2 + FC/2-1 of the chunk; MFMA block j takes 2 quads of them
         // per operand row (3 ds_read_b128, 16 MFMAs), block j+1's reads are issued ahead of block j's MFMAs

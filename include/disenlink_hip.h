@@ -151,10 +151,13 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
  *                          W1 [K][nhid][F], b1 [K][nhid], W2 [K][d][nhid], b2 [K][d]
  *   single layer (Factor): pass W2 = b2 = NULL, nhid = 1:  Z[n][k][:] = W1[k] . x[n] + b1[k],  W1 [K][d][F], b1 [K][d]
  * x is fp32 [N][F] row-major, Z fp32 [N][K][d].  d must be 32, 64 or 128 (dl_project_supported).
- * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain).
- * ws (optional, dl_project_fwd_workspace_bytes): on small graphs the hidden layer is split over several
- * workgroups per node tile whose partial sums meet in ws (added in a fixed order); without it (NULL / too
- * small) one workgroup walks the whole hidden layer — same result up to summation order, less parallelism. */
+ * fp32 in, fp32 results.  With the workspace, layer 1 runs on the bf16 matrix path at fp32-grade accuracy: x and W1
+ * are split once per call into three bf16 planes each (x = hi + mid + lo) and every term is the sum of six exact
+ * bf16 products in an fp32 accumulator; layer 2, and everything when ws is NULL / too small or
+ * DL_PROJECT_FP32_MFMA=1 is set, is plain fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain).
+ * ws (optional, dl_project_fwd_workspace_bytes): the plane arrays, and on small graphs the partial sums of the
+ * several workgroups per node tile that share the hidden layer (added in a fixed order); without it one workgroup
+ * walks the whole hidden layer with fp32 MFMA — same result up to rounding / summation order, slower. */
 int dl_project_supported(int d);
 size_t dl_project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer);
 /* hid_out (optional, two-layer form, dl_project_hidden_floats(N, K, nhid) floats): keep the hidden layer
@@ -169,8 +172,9 @@ int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d,
  * (main_disentangled.py:198).  dZ fp32 [N][K][d] in; weight and bias gradients out, shaped like the weights
  * (dW1 like W1, db1 like b1, dW2 like W2, db2 like b2; single layer: W2 = dW2 = db2 = NULL, nhid = 1).
  * x is data and gets no gradient.  The hidden layer is recomputed on the matrix cores (never read from HBM);
- * ws needs dl_project_bwd_workspace_bytes(...) bytes (the masked hidden gradient [N][K][nhid] plus the
- * per-node-range partial slabs).  Sums over nodes are taken range by range in a fixed order (no float
+ * ws needs dl_project_bwd_workspace_bytes(...) bytes (the masked hidden gradient of one node block — kept as the
+ * three bf16 planes of its transpose, the operand of the dW1 contraction on the bf16 matrix path, fp32-grade like
+ * the forward's layer 1 — the planes of x^T for that block, and the per-node-range partial slabs).  Sums over nodes are taken range by range in a fixed order (no float
  * atomics): the gradients are bitwise reproducible. */
 size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer);
 int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d,
@@ -210,7 +214,7 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
 /* Dense scorer: replaces model.py:109-113 as written — prob[u][v] for ALL N*N ordered pairs (row-major
  * fp32 [N][N]), the link_pred the reference's caller indexes with dense masks (main_disentangled.py:195).
  * No pair list is materialised.  fp32 tables with d % 32 == 0 go to the matrix cores (two Gram products per
- * factor, fp32 MFMA; only the tile pairs u <= v are computed and mirrored: prob is symmetric bit for bit);
+ * factor, six exact bf16 products per term from three bf16 planes per operand; only the tile pairs u <= v are computed and mirrored: prob is symmetric bit for bit);
  * other shapes use the vector kernels.  Its backward is dl_score_pairs_bwd over the entries whose gradient is
  * non-zero (the masked ones).  N*N must stay below 2^31: N <= 46340. */
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,

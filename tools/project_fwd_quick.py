@@ -6,6 +6,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disenlink_amd import ops
 shapes = [(5201, 2088, 8, 512, 64), (5201, 2089, 8, 512, 64), (41554, 128, 16, 256, 128), (5201, 128, 8, 512, 64)]
+if len(sys.argv) > 5:
+    v = [int(a) for a in sys.argv[1:]]
+    shapes = [tuple(v[i:i + 5]) for i in range(0, len(v) - 4, 5)]
 for (N, F, K, nhid, d) in shapes:
     x = torch.randn(N, F, device="cuda")
     W1 = torch.randn(K, nhid, F, device="cuda") / F ** 0.5
