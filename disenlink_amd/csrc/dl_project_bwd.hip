@@ -116,36 +116,37 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
     for (int ht = 0; ht < HT; ++ht) b1acc[ht] = 0.0f;
 
+    // Kept hidden layer: hidT rows of this wave's hidden units, quad g = nodes 8g + 4*half .. +3 of its node quarter.
+    // Raw loads from clamped addresses; the masking happens at the use (hq_masked), so a tile's loads can be issued
+    // one tile ahead, behind the MFMAs of the current one.
+    float4 hraw[HT][4];
+    auto load_hq = [&](int n0t) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+            const int h = hw0 + ht * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0t + wn * 32 + 8 * g + 4 * half;
+                const bool ok = h < nhid && n + 3 < hid_cols;
+                hraw[ht][g] = *reinterpret_cast<const float4*>(hidT + (ok ? ((size_t)k * nhid + h) * ldh + n : 0));
+            }
+        }
+    };
     if (RECOMPUTE && steps > 0) {
         fetch(0);
         stash(0);
         if (steps > 1) fetch(1);
+    }
+    if (!RECOMPUTE && steps > 0) {
+        zt.fetch(dZk + (size_t)tile0 * TILE_N * K * D, K * D, N - tile0 * TILE_N, D, tid);
+        load_hq(tile0 * TILE_N);
     }
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
         const int tl = s / nfc, fc = s % nfc;
         const bool last = fc == nfc - 1;
         const int n0 = (tile0 + tl) * TILE_N;
-        if (last) zt.fetch(dZk + (size_t)n0 * K * D, K * D, N - n0, D, tid);      // consumed after the MFMAs below
-        float4 hq[HT][4];                                                          // kept hidden layer, quad g = nodes 8g+4*half..+3
-        if constexpr (!RECOMPUTE) {
-#pragma unroll
-            for (int ht = 0; ht < HT; ++ht) {
-                const int h = hw0 + ht * 32 + li;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * 32 + 8 * g + 4 * half;
-                    const bool ok = h < nhid && n + 3 < hid_cols;
-                    const float4 q = *reinterpret_cast<const float4*>(hidT + (ok ? ((size_t)k * nhid + h) * ldh + n : 0));
-                    // per element: the columns N .. ldh-1 of hidT are padding nobody wrote — whatever they hold
-                    // (possibly NaN bit patterns) must not meet the zero dZ rows of those nodes in an MFMA (0 * NaN)
-                    hq[ht][g] = make_float4(mask_bits(q.x, ok && n + 0 < N ? 0xFFFFFFFFu : 0u),
-                                            mask_bits(q.y, ok && n + 1 < N ? 0xFFFFFFFFu : 0u),
-                                            mask_bits(q.z, ok && n + 2 < N ? 0xFFFFFFFFu : 0u),
-                                            mask_bits(q.w, ok && n + 3 < N ? 0xFFFFFFFFu : 0u));
-                }
-            }
-        }
+        if (RECOMPUTE && last) zt.fetch(dZk + (size_t)n0 * K * D, K * D, N - n0, D, tid);   // consumed after the MFMAs below
         if constexpr (RECOMPUTE) {
         // hid[node][hidden] += x[node][f] . W1[hidden][f]: A = x rows of this node quarter, B = W1 rows
         const float* xb = xs + (s & 1) * TILE_N * LDB + (wn * 32 + li) * LDB + half * (BFC / 2);
@@ -187,21 +188,34 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
             zt.template stash<LDZ>(dzs, tid);
             __syncthreads();
             float hid[HT][16];
+            unsigned relu_bits[HT];                             // bit r: hid[ht][r] > 0 (the mask of the dhid epilogue)
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht) {
                 if constexpr (RECOMPUTE) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hid[ht][r] = fmaxf(hacc[ht][r] + b1v[ht], 0.0f);
                 } else {
+                    const int h = hw0 + ht * 32 + li;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        hid[ht][4 * g + 0] = hq[ht][g].x;
-                        hid[ht][4 * g + 1] = hq[ht][g].y;
-                        hid[ht][4 * g + 2] = hq[ht][g].z;
-                        hid[ht][4 * g + 3] = hq[ht][g].w;
+                        // per element: the columns N .. ldh-1 of hidT are padding nobody wrote — whatever they hold
+                        // (possibly NaN bit patterns) must not meet the zero dZ rows of those nodes in an MFMA (0 * NaN)
+                        const int n = n0 + wn * 32 + 8 * g + 4 * half;
+                        const bool ok = h < nhid && n + 3 < hid_cols;
+                        hid[ht][4 * g + 0] = mask_bits(hraw[ht][g].x, ok && n + 0 < N ? 0xFFFFFFFFu : 0u);
+                        hid[ht][4 * g + 1] = mask_bits(hraw[ht][g].y, ok && n + 1 < N ? 0xFFFFFFFFu : 0u);
+                        hid[ht][4 * g + 2] = mask_bits(hraw[ht][g].z, ok && n + 2 < N ? 0xFFFFFFFFu : 0u);
+                        hid[ht][4 * g + 3] = mask_bits(hraw[ht][g].w, ok && n + 3 < N ? 0xFFFFFFFFu : 0u);
                     }
                 }
+                relu_bits[ht] = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) relu_bits[ht] |= (hid[ht][r] > 0.0f ? 1u : 0u) << r;
             }
+            // kept form: the next tile's dZ rows and hidden quads are fetched behind this tile's MFMAs (unconditional —
+            // the last tile is fetched twice — see project2_fwd_kernel)
+            const int n0n = (tile0 + min(tl + 1, my_tiles - 1)) * TILE_N;
+            if constexpr (!RECOMPUTE) zt.fetch(dZk + (size_t)n0n * K * D, K * D, N - n0n, D, tid);
             // dW2[dd][hidden] += dZ[node][dd] . hid[node][hidden]: the k-pair of register r is the node pair
             // {acc_row(r,0), acc_row(r,1)} of this quarter
 #pragma unroll
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
                     for (int ht = 0; ht < HT; ++ht) DL_MFMA(w2acc[dt][ht], zv[r], hid[ht][r]);
             }
+            if constexpr (!RECOMPUTE) load_hq(n0n);             // hid has been consumed by the MFMAs above
             // dhid[node][hidden] = dZ[node][dd] . W2^T[hidden][dd], masked by the ReLU
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht) zero_acc(hacc[ht]);
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
                 float colsum = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float g = hid[ht][r] > 0.0f ? hacc[ht][r] : 0.0f;
+                    const float g = (relu_bits[ht] >> r) & 1u ? hacc[ht][r] : 0.0f;
                     const int n = n0 + wn * 32 + acc_row(r, half);
                     if constexpr (!PLANES) {
                         if (n < N && h < nhid) dhid[((size_t)n * K + k) * nhid + h] = g;
