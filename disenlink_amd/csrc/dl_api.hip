@@ -244,8 +244,13 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
                                    (hipStream_t)stream);
 }
 
+size_t dl_score_allpairs_workspace_bytes(int N, int K, int d, dl_dtype dtype) {
+    if (N <= 0 || K < 1 || d < 1 || dtype != DL_F32 || g_force_generic) return 0;
+    return dense_score_workspace_bytes(N, K, d);
+}
+
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t, float* prob,
-                          void* stream) {
+                          void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(dtype == DL_F32 || dtype == DL_BF16, "unknown dtype %d", dtype);
     DL_REQUIRE(N >= 0 && N <= 46340, "dense [N,N] scoring needs 0 <= N <= 46340, got %d", N);
@@ -253,7 +258,8 @@ int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_
     if (N == 0) return DL_OK;
     DL_REQUIRE(Z && H && prob, "NULL argument");
     if (!g_force_generic && dtype == DL_F32 && dense_mfma_supported(d))      // Gram products on the matrix cores
-        return dense_mfma_score_allpairs_fwd((const float*)Z, (const float*)H, N, K, d, t, prob, (hipStream_t)stream);
+        return dense_mfma_score_allpairs_fwd((const float*)Z, (const float*)H, N, K, d, t, prob, ws, ws_bytes,
+                                             (hipStream_t)stream);
     if (!g_force_generic && fast_supported(K, d, dtype))
         return fast_score_allpairs_fwd(Z, H, N, K, d, dtype, t, prob, (hipStream_t)stream);
     DL_REQUIRE(dtype == DL_F32, "bf16 tables need a tuned kernel for K=%d d=%d", K, d);

@@ -46,7 +46,8 @@ int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int
 
 // dense scorer on the matrix cores (dl_score_dense.hip): fp32 tables, d % 32 == 0
 bool dense_mfma_supported(int d);
-int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
+size_t dense_score_workspace_bytes(int N, int K, int d);
+int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob, void* ws, size_t ws_bytes,
                                   hipStream_t st);
 
 int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,

@@ -163,19 +163,18 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_mfma_kernel(const float* 
 // instead of eight 64-cycle fp32 ones.  Measured on a standalone Gram product (tools/experiments/split_bf16_gram.hip):
 // 1.87x at the same error against fp64 (2.2e-7 vs 1.9e-7 of the sum of |terms|).
 // LDS image per operand and buffer: [3 planes][128 rows][32 + 8] bf16 (row pitch 80 bytes: conflict-free b128 reads).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int SDC = 32, SLD = SDC + 8;
+// (split3 / stash_planes / mfma_split6 and the LDS image are the shared ones of dl_tiles.h)
+constexpr int SDC = SPLIT_COLS, SLD = SPLIT_PITCH;
 
-__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-    hi = (__bf16)x;
-    const float r1 = x - (float)hi;
-    mid = (__bf16)r1;
-    lo = (__bf16)(r1 - (float)mid);
-}
+// PLANES: Z and H arrive pre-split as tile-major plane arrays (dl_planes.hip: per factor k the planes of the [N][D]
+// matrix Z[:, k, :], 32-column tiles; batch = elements per factor), split once per call instead of once per tile pair
+// that stages them (each node tile is staged by ~nt workgroups); the staging is then a straight copy.
+struct DensePlanes { const __bf16* z; const __bf16* h; size_t batch; };
 
+template <bool PLANES>
 __global__ __launch_bounds__(DTHR) void score_allpairs_split_kernel(const float* __restrict__ Z, const float* __restrict__ H,
-                                                                    int N, int K, int D, float t, float* __restrict__ prob) {
+                                                                    int N, int K, int D, float t, float* __restrict__ prob,
+                                                                    DensePlanes P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16* us = reinterpret_cast<__bf16*>(lds);               // [2][3][TT][SLD]
     __bf16* vs = us + 2 * 3 * TT * SLD;
@@ -197,33 +196,29 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_split_kernel(const float*
     const int ld = K * D;
 
     TileStage<TT, SDC, true, DTHR> ut, vt;                     // raw fp32 quads in flight; split when written to LDS
+    PlaneStage<DTHR, SDC> uq, vq;                              // PLANES: 16-byte pieces of the pre-split tiles
+    static_assert(TT == PLANE_ROWS, "tiles of the plane arrays");
     auto fetch = [&](int s) {
         const int k = s / (2 * nd), r = s - k * 2 * nd;
-        const float* src = r < nd ? Z : H;
         const int dc = r < nd ? r : r - nd;
-        ut.fetch(src + ((size_t)u0 * K + k) * D + dc * SDC, ld, N - u0, SDC, tid);
-        vt.fetch(src + ((size_t)v0 * K + k) * D + dc * SDC, ld, N - v0, SDC, tid);
-    };
-    auto stash_split = [&](const TileStage<TT, SDC, true, DTHR>& tile, __bf16* base) {
-#pragma unroll
-        for (int j = 0; j < tile.NV / 4; ++j) {
-            const int q = tid + DTHR * j, r = q / (SDC / 4), c = 4 * (q % (SDC / 4));
-            const unsigned m = r < tile.rows_valid ? 0xFFFFFFFFu : 0u;          // rows past N read as zero
-            bf16x4 p0, p1, p2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 h, md, l;
-                split3(mask_bits(tile.v[4 * j + e], m), h, md, l);
-                p0[e] = h; p1[e] = md; p2[e] = l;
-            }
-            *reinterpret_cast<bf16x4*>(base + (0 * TT + r) * SLD + c) = p0;
-            *reinterpret_cast<bf16x4*>(base + (1 * TT + r) * SLD + c) = p1;
-            *reinterpret_cast<bf16x4*>(base + (2 * TT + r) * SLD + c) = p2;
+        if constexpr (PLANES) {
+            const __bf16* src = (r < nd ? P.z : P.h) + (size_t)k * P.batch;
+            uq.fetch(src + plane_tile<SDC>(ta, dc, nd), tid);
+            vq.fetch(src + plane_tile<SDC>(tb, dc, nd), tid);
+        } else {
+            const float* src = r < nd ? Z : H;
+            ut.fetch(src + ((size_t)u0 * K + k) * D + dc * SDC, ld, N - u0, SDC, tid);
+            vt.fetch(src + ((size_t)v0 * K + k) * D + dc * SDC, ld, N - v0, SDC, tid);
         }
     };
     auto stash = [&](int s) {
-        stash_split(ut, us + (s & 1) * 3 * TT * SLD);
-        stash_split(vt, vs + (s & 1) * 3 * TT * SLD);
+        if constexpr (PLANES) {
+            uq.stash(us + (s & 1) * 3 * TT * SLD, tid);
+            vq.stash(vs + (s & 1) * 3 * TT * SLD, tid);
+        } else {
+            stash_planes(ut, us + (s & 1) * 3 * TT * SLD, tid);   // rows past N are written as zero
+            stash_planes(vt, vs + (s & 1) * 3 * TT * SLD, tid);
+        }
     };
 
     f32x16 acc[2], term[2];
@@ -235,7 +230,7 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_split_kernel(const float*
     }
     fetch(0);
     stash(0);
-    if (steps > 1) fetch(1);
+    fetch(min(1, steps - 1));
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
         const int r = s % (2 * nd);
@@ -244,27 +239,18 @@ __global__ __launch_bounds__(DTHR) void score_allpairs_split_kernel(const float*
         const __bf16* vb = vs + (s & 1) * 3 * TT * SLD + (wv * 64 + li) * SLD + half * 8;
 #pragma unroll
         for (int kb = 0; kb < SDC / 16; ++kb) {
-            bf16x8 a[3], b[3][2];
+            bf16x8 a[3], b0[3], b1[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 a[p] = *reinterpret_cast<const bf16x8*>(ub + p * TT * SLD + kb * 16);
-                b[p][0] = *reinterpret_cast<const bf16x8*>(vb + p * TT * SLD + kb * 16);
-                b[p][1] = *reinterpret_cast<const bf16x8*>(vb + (p * TT + 32) * SLD + kb * 16);
+                b0[p] = *reinterpret_cast<const bf16x8*>(vb + p * TT * SLD + kb * 16);
+                b1[p] = *reinterpret_cast<const bf16x8*>(vb + (p * TT + 32) * SLD + kb * 16);
             }
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                f32x16 c = acc[bb];                             // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][bb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][bb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][bb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][bb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][bb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][bb], c, 0, 0, 0);
-                acc[bb] = c;
-            }
+            mfma_split6(acc[0], a, b0);                         // six products, smallest terms first
+            mfma_split6(acc[1], a, b1);
             if (kb == 0) {
                 if (s + 1 < steps) stash(s + 1);
-                if (s + 2 < steps) fetch(s + 2);
+                fetch(min(s + 2, steps - 1));                   // unconditional: see project2_fwd_kernel
             }
         }
         if (r == nd - 1) {                                      // S complete: e = exp(S / t)
@@ -338,17 +324,35 @@ static void launch_dense(const float* Z, const float* H, int N, int K, int d, fl
                        N, K, d, t, prob);
 }
 
-int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,
-                                  hipStream_t st) {
+size_t dense_score_workspace_bytes(int N, int K, int d) {
+    if (!dense_mfma_supported(d) || getenv("DL_DENSE_FP32_MFMA")) return 0;
+    return 2 * sizeof(__bf16) * (size_t)K * project::plane_array_elems(N, d, project::SPLIT_COLS);
+}
+
+int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob, void* ws,
+                                  size_t ws_bytes, hipStream_t st) {
     if (!getenv("DL_DENSE_FP32_MFMA")) {                        // default: three-plane bf16 products (fp32-grade accuracy)
         using namespace dense;
-        static unsigned long long lds_done = 0;
+        static unsigned long long lds_done_p = 0, lds_done_s = 0;
         constexpr size_t lds = (size_t)2 * 2 * 3 * TT * SLD * 2;
-        project::ensure_dynamic_lds(reinterpret_cast<const void*>(&score_allpairs_split_kernel), lds, lds_done);
         const int nt = (N + TT - 1) / TT;
         const int items = nt * (nt + 1) / 2;
-        hipLaunchKernelGGL(score_allpairs_split_kernel, dim3((unsigned)((items + 255) / 256 * 256)), dim3(DTHR), lds, st, Z, H,
-                           N, K, d, t, prob);
+        const dim3 grid((unsigned)((items + 255) / 256 * 256));
+        const size_t need = dense_score_workspace_bytes(N, K, d);
+        if (ws != nullptr && ws_bytes >= need) {                // planes made once per call
+            const size_t batch = project::plane_array_elems(N, d, project::SPLIT_COLS);
+            __bf16* zp = static_cast<__bf16*>(ws);
+            __bf16* hp = zp + (size_t)K * batch;
+            project::split_rows(Z, K, N, d, K * d, (size_t)d, zp, st);
+            project::split_rows(H, K, N, d, K * d, (size_t)d, hp, st);
+            project::ensure_dynamic_lds(reinterpret_cast<const void*>(&score_allpairs_split_kernel<true>), lds, lds_done_p);
+            hipLaunchKernelGGL(score_allpairs_split_kernel<true>, grid, dim3(DTHR), lds, st, Z, H, N, K, d, t, prob,
+                               DensePlanes{zp, hp, batch});
+        } else {                                                // no workspace: every tile pair splits what it stages
+            project::ensure_dynamic_lds(reinterpret_cast<const void*>(&score_allpairs_split_kernel<false>), lds, lds_done_s);
+            hipLaunchKernelGGL(score_allpairs_split_kernel<false>, grid, dim3(DTHR), lds, st, Z, H, N, K, d, t, prob,
+                               DensePlanes{nullptr, nullptr, 0});
+        }
         return check_launch("score_allpairs_fwd(split bf16)");
     }
     if (d % 64 == 0 && !getenv("DL_DENSE_DC32")) launch_dense<64>(Z, H, N, K, d, t, prob, st);

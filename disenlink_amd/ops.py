@@ -165,8 +165,9 @@ def score_allpairs_fwd(Z, H, t: float) -> torch.Tensor:
     if H.shape != Z.shape or dt != dth:
         raise ValueError("Z and H differ in shape or storage type")
     prob = _empty((N, N), torch.float32, Z.device)
+    ws = _ws.get(int(lib.dl_score_allpairs_workspace_bytes(N, K, d, dt)), Z.device)
     _lib.check(lib.dl_score_allpairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), prob.data_ptr(),
-                                         _stream()), "dl_score_allpairs_fwd")
+                                         ws.data_ptr(), ws.numel(), _stream()), "dl_score_allpairs_fwd")
     return prob
 
 

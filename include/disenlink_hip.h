@@ -216,9 +216,12 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
  * No pair list is materialised.  fp32 tables with d % 32 == 0 go to the matrix cores (two Gram products per
  * factor, six exact bf16 products per term from three bf16 planes per operand; only the tile pairs u <= v are computed and mirrored: prob is symmetric bit for bit);
  * other shapes use the vector kernels.  Its backward is dl_score_pairs_bwd over the entries whose gradient is
- * non-zero (the masked ones).  N*N must stay below 2^31: N <= 46340. */
+ * non-zero (the masked ones).  N*N must stay below 2^31: N <= 46340.
+ * ws (optional, dl_score_allpairs_workspace_bytes): the bf16 planes of Z and H, split once per call; without it
+ * (NULL / too small) every tile pair splits the rows it stages — same result bit for bit, slower. */
+size_t dl_score_allpairs_workspace_bytes(int N, int K, int d, dl_dtype dtype);
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
-                          float* prob, void* stream);
+                          float* prob, void* ws, size_t ws_bytes, void* stream);
 
 /* Pair-list loss of main_disentangled.py:195 and its gradient in one pass:
  *   loss[0] = sum_q w[q] * BCE(prob[q], y[q])       (log clamped at -100, like F.binary_cross_entropy)

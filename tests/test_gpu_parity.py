@@ -383,6 +383,14 @@ def test_dense_scorer_on_the_matrix_cores_matches_the_pair_scorer(K, d, N):
     np.testing.assert_allclose(P.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(P, ops.score_allpairs_fwd(Z, H, t))                    # reproducible
     assert torch.equal(P, P.t())                                              # mirrored tiles: exactly symmetric
+    if d % 32 == 0:                  # without the workspace every tile pair splits what it stages: the same bits
+        from disenlink_amd import _lib
+        lib = _lib.load()
+        assert lib.dl_score_allpairs_workspace_bytes(N, K, d, _lib.DL_F32) > 0
+        P0 = torch.full_like(P, float("nan"))
+        _lib.check(lib.dl_score_allpairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, _lib.DL_F32, float(t), P0.data_ptr(), None, 0,
+                                             torch.cuda.current_stream().cuda_stream), "dl_score_allpairs_fwd")
+        assert torch.equal(P, P0)
     Zb = Z.clone()
     Zb[1, 0] = 12.0                                                           # exp(z.z) overflows for (1,1)
     Pb = ops.score_allpairs_fwd(Zb, H, t)
