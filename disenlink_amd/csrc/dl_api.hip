@@ -266,6 +266,20 @@ int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_
     return generic_score_allpairs_fwd((const float*)Z, (const float*)H, N, K, d, t, prob, (hipStream_t)stream);
 }
 
+int dl_auc_pair_counts_supported(int n_pos, int n_neg) {
+    return n_pos >= 0 && n_neg >= 0 && auc_counts_supported(n_pos, n_neg) ? 1 : 0;
+}
+
+int dl_auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
+                       unsigned long long* u2, void* stream) {
+    DL_REQUIRE(n_pos >= 0 && n_neg >= 0, "negative size");
+    DL_REQUIRE(u2 != nullptr, "u2 is NULL");
+    DL_REQUIRE(auc_counts_supported(n_pos, n_neg), "n_pos * n_neg too large for the slice-and-search form (%d x %d)",
+               n_pos, n_neg);
+    if (n_pos > 0 && n_neg > 0) DL_REQUIRE(score && pos_idx && neg_idx, "NULL argument");
+    return auc_pair_counts(score, pos_idx, n_pos, neg_idx, n_neg, u2, (hipStream_t)stream);
+}
+
 int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g, void* ws,
                 size_t ws_bytes, void* stream) {
     DL_REQUIRE(n_pairs >= 0, "negative size");

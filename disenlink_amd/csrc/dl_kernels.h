@@ -50,6 +50,11 @@ size_t dense_score_workspace_bytes(int N, int K, int d);
 int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob, void* ws, size_t ws_bytes,
                                   hipStream_t st);
 
+// tie-averaged AUC counts (dl_metrics.hip)
+bool auc_counts_supported(int n_pos, int n_neg);           // the smaller class fits the LDS
+int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
+                    unsigned long long* u2, hipStream_t st);
+
 int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,
              hipStream_t st);
 

@@ -223,6 +223,19 @@ size_t dl_score_allpairs_workspace_bytes(int N, int K, int d, dl_dtype dtype);
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
                           float* prob, void* ws, size_t ws_bytes, void* stream);
 
+/* Tie-averaged AUC of a score vector against FIXED labels: replaces sklearn.metrics.roc_auc_score at
+ * main_disentangled.py:202-204 / 217-219 (validation AUC every epoch, test AUC at the end).  pos_idx / neg_idx
+ * (int64, device) are the positions of the positive and negative labels in score, found once per run; the call
+ * writes u2[0] = sum over positives p of ( 2 * #{negatives n: s_n < s_p} + #{n: s_n == s_p} ) as an exact 64-bit
+ * integer, so AUC = u2 / (2 * n_pos * n_neg) — the Mann-Whitney statistic with tie-averaged ranks.  One launch:
+ * the smaller class is cut into slices of 1,024 scores, a workgroup sorts its slice (bitonic network, shuffles +
+ * LDS) and binary-searches its chunk of the other class in it; the counts of the slices add up.  Work grows as
+ * ceil(min/1024) * max: dl_auc_pair_counts_supported says whether the sizes are in range (n_pos * n_neg <= 4e11;
+ * beyond that a device sort on the caller's side is the better tool).  Scores are expected to be finite. */
+int dl_auc_pair_counts_supported(int n_pos, int n_neg);
+int dl_auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
+                       unsigned long long* u2, void* stream);
+
 /* Pair-list loss of main_disentangled.py:195 and its gradient in one pass:
  *   loss[0] = sum_q w[q] * BCE(prob[q], y[q])       (log clamped at -100, like F.binary_cross_entropy)
  *   g[q]    = w[q] * (prob[q] - y[q]) / max(prob[q] (1 - prob[q]), 1e-12)       = dloss / dprob[q]

@@ -1046,7 +1046,41 @@ def test_fused_pair_bce_matches_torch_bce():
         pair_bce_loss(bad[:n_pos], label[:n_pos], bad[n_pos:], label[n_pos:], m)                       # torch, on the CPU
     w0 = w.clone()
     w0[5] = 0.0
-    assert torch.isfinite(pair_bce_loss_fused(bad.to(DEV), lt, w0))@pytest.mark.gpu
+    assert torch.isfinite(pair_bce_loss_fused(bad.to(DEV), lt, w0))
+
+
+@pytest.mark.gpu
+def test_auc_counting_kernel_equals_the_sort_form_and_sklearn_vectors():
+    """dl_auc_pair_counts (slices of 1,024 scores of the smaller class sorted by a workgroup each, the other class located
+    in them by binary searches, integer counts that add up over the slices) behind AucPlan.auc on the GPU: the sklearn
+    golden vectors, and the CPU sort form on random scores with heavy ties — either class the smaller one, slice counts
+    of 1 .. 69 with ragged last slices — the same integer count."""
+    import glob
+    import os
+    from conftest import GOLDEN_DIR
+    from disenlink_amd.metrics import AucPlan
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "auc_*.npz"))):
+        g = np.load(path)
+        y, sc = torch.from_numpy(g["y"]), torch.from_numpy(g["score"]).float()
+        assert abs(float(AucPlan(y.to(DEV)).auc(sc.to(DEV))) - float(g["auc"])) <= 1e-12, path
+    rng = np.random.default_rng(11)
+    for n, frac, levels in ((2, 0.5, 2), (65, 0.5, 3), (1023, 0.1, 50), (4097, 0.9, 7), (9000, 0.5, 100000), (70000, 0.17, 1000),
+                            (140000, 0.03, 1 << 20), (66000, 0.496, 1 << 16), (140000, 0.5, 1 << 12)):
+        yb = rng.random(n) < frac
+        yb[0], yb[1] = True, False                                                  # both classes present
+        y = torch.from_numpy(yb.astype(np.float32))
+        sc = torch.from_numpy((rng.integers(0, levels, n) / levels).astype(np.float32))
+        sc[rng.random(n) < 0.1] = 1.0
+        want = AucPlan(y).auc(sc)                                                   # CPU: sort + binary searches
+        plan = AucPlan(y.to(DEV))
+        got = plan.auc(sc.to(DEV))
+        assert got.is_cuda and float(got) == float(want), (n, frac, levels, float(got), float(want))   # the same integer count
+        assert float(plan.auc(sc.to(DEV) * 0 + 0.25)) == 0.5                        # all tied
+        big = torch.cat([sc, sc]).to(DEV)[n:]                                       # an offset view, like prob[b:]
+        assert float(plan.auc(big)) == float(want)
+
+
+@pytest.mark.gpu
 def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
     """Layer 1 and the dW1 contraction run as six exact bf16 products per term from three bf16 planes per operand
     (dl_tiles.h).  Full-mantissa random operands, odd sizes (feature / node / hidden tails of the padded plane arrays):
