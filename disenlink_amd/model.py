@@ -51,7 +51,8 @@ class Disentangle(nn.Module):
         (reference precision) or torch.bfloat16 (half the gather bytes, fp32 arithmetic and gradients).
         ``projection``: "mfma" = the fused matrix-core kernels of libdisenlink_hip.so (forward and backward; fp32
         results — layer 1 and the dW1 contraction run as six exact bf16 products per term; the hidden
-        layer is written once, transposed, for the backward while it fits a few GB and recomputed beyond that),
+        layer is written once, transposed, for the backward while it fits a quarter of the device memory (at most
+        64 GiB) and recomputed beyond that),
         "library" = library GEMMs (rocBLAS through torch), "auto" = the kernels wherever they support the factor width
         (d in {32, 64, 128}): measured equal or faster than the library path at every feature width (squirrel epoch
         1.64 vs 1.75 ms at F=128, 1.93 vs 2.06 at 512, 2.17 vs 2.36 at 1024, 2.74 vs 3.20 at 2089; real Cora

@@ -265,12 +265,24 @@ def _pad_features(x, W1):
 def keep_hidden(N: int, F: int, K: int, nhid: int) -> bool:
     """Should the forward keep the hidden layer for the backward?  Recomputing it costs 2*F FLOP per hidden unit
     against 8 bytes of traffic: measured faster at every width tried (F = 128: fwd+bwd 0.35 -> 0.30 ms, F = 2089:
-    2.9 -> 2.0 ms, tools/project_keep_times.py) — while the [K,nhid,N] buffer stays within a few GB (past that
-    the recompute is what keeps large graphs in memory)."""
+    2.9 -> 2.0 ms, tools/project_keep_times.py; snap-patents-sized, 45 GiB of hidden layer: epoch 445 -> 397 ms) — while
+    the [K,nhid,N] buffer stays within a quarter of the device's memory, at most 64 GiB (of 288 GB on an MI355X); past
+    that the recompute is what keeps large graphs in memory."""
     mode = os.environ.get("DL_KEEP_HIDDEN", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    return N * K * nhid * 4 <= (8 << 30)
+    return N * K * nhid * 4 <= _keep_hidden_limit()
+
+
+_KEEP_LIMIT = None
+
+
+def _keep_hidden_limit() -> int:
+    global _KEEP_LIMIT
+    if _KEEP_LIMIT is None:
+        total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory if torch.cuda.is_available() else 0
+        _KEEP_LIMIT = min(64 << 30, total // 4)
+    return _KEEP_LIMIT
 
 
 def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True, keep_hid: bool = False):
