@@ -1,5 +1,5 @@
 """One-off: a few training epochs at a large synthetic shape (does it run, how long, how much memory).
-usage: epoch_scale.py <workload> <K> <d> <nhid> <f32|bf16> [epochs]"""
+usage: epoch_scale.py <workload> <K> <d> <nhid> <f32|bf16> [epochs] [eager]   (eager: skip the graph-replay arm)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ x = torch.from_numpy(sg.features()).to(dev)
 print(f"{name}: N={sg.n_nodes} F={sg.n_feat} train pairs {run.n_pos + run.n_neg} prep {time.perf_counter() - t0:.1f} s", flush=True)
 torch.manual_seed(0)
 model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.5, t=1, table_dtype=torch.bfloat16 if dt == "bf16" else torch.float32).to(dev)
-for use_graph in (False, True):
+for use_graph in ((False,) if len(sys.argv) > 7 and sys.argv[7] == "eager" else (False, True)):
     run_link_prediction(model, x, run, epochs=2, lr=1e-4, use_graph=use_graph)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = run_link_prediction(model, x, run, epochs=epochs, lr=1e-4, use_graph=use_graph)
