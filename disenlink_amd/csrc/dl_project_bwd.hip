@@ -522,7 +522,14 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(SlabJobs jobs, int accumu
     const size_t i = (size_t)(blockIdx.x - job.block0) * 256 + threadIdx.x;
     if (i >= job.n) return;
     float v = accumulate ? job.out[i] : 0.0f;
-    for (int s = 0; s < job.S; ++s) v += job.slabs[(size_t)s * job.n + i];
+    const float* p = job.slabs + i;
+    int s = 0;
+    for (; s + 4 <= job.S; s += 4) {                            // four loads in flight, the same order of additions
+        const float a0 = p[(size_t)s * job.n], a1 = p[(size_t)(s + 1) * job.n], a2 = p[(size_t)(s + 2) * job.n],
+                    a3 = p[(size_t)(s + 3) * job.n];
+        v = (((v + a0) + a1) + a2) + a3;
+    }
+    for (; s < job.S; ++s) v += p[(size_t)s * job.n];
     job.out[i] = v;
 }
 
