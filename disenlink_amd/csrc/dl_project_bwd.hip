@@ -541,8 +541,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
     const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * rows_per_range, r1 = min(N, r0 + rows_per_range);
     float v = 0.0f;
-    if (c < C)
-        for (int r = r0 + rl; r < r1; r += 4) v += A[(size_t)r * C + c];
+    if (c < C) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {                          // four loads in flight, the same order of additions
+            const float a0 = A[(size_t)r * C + c], a1 = A[(size_t)(r + 4) * C + c], a2 = A[(size_t)(r + 8) * C + c],
+                        a3 = A[(size_t)(r + 12) * C + c];
+            v = (((v + a0) + a1) + a2) + a3;
+        }
+        for (; r < r1; r += 4) v += A[(size_t)r * C + c];
+    }
     red[rl][cl] = v;
     __syncthreads();
     if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
