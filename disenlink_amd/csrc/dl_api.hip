@@ -284,7 +284,7 @@ int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, 
                 size_t ws_bytes, void* stream) {
     DL_REQUIRE(n_pairs >= 0, "negative size");
     DL_REQUIRE(loss != nullptr, "loss is NULL");
-    DL_REQUIRE(ws != nullptr && ws_bytes >= 1024 + 256, "dl_pair_bce needs >= 1280 bytes of workspace");
+    DL_REQUIRE(ws != nullptr && ws_bytes >= 4096 + 256, "dl_pair_bce needs >= 4352 bytes of workspace");
     if (n_pairs > 0) DL_REQUIRE(prob && y && w && g, "NULL argument");
     float* partial = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     return pair_bce(prob, y, w, n_pairs, loss, g, partial, (hipStream_t)stream);

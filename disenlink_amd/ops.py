@@ -460,7 +460,7 @@ class PairBCE(torch.autograd.Function):
             raise ValueError("prob, label and weight differ in length")
         loss = _empty(1, torch.float32, prob.device)
         g = _empty_like(prob)
-        ws = _ws.get(2048, prob.device)
+        ws = _ws.get(8192, prob.device)
         _lib.check(lib.dl_pair_bce(prob.data_ptr(), label.data_ptr(), weight.data_ptr(), prob.numel(), loss.data_ptr(),
                                    g.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_pair_bce")
         ctx.save_for_backward(g)

@@ -240,7 +240,7 @@ int dl_auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, co
  *   loss[0] = sum_q w[q] * BCE(prob[q], y[q])       (log clamped at -100, like F.binary_cross_entropy)
  *   g[q]    = w[q] * (prob[q] - y[q]) / max(prob[q] (1 - prob[q]), 1e-12)       = dloss / dprob[q]
  * With w = 1/n_pos on the positive pairs and 1/(m n_neg) on the negative ones this is the reference's
- * BCE(pos) + BCE(neg)/m.  ws: at least 1 KiB of scratch (256 partial sums). */
+ * BCE(pos) + BCE(neg)/m.  ws: at least 4352 bytes of scratch (1,024 partial sums, added in a fixed order). */
 int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g,
                 void* ws, size_t ws_bytes, void* stream);
 
