@@ -221,6 +221,39 @@ __global__ __launch_bounds__(BLOCK) void s_rowsum_seg_kernel(dl_csr_plan g, int 
     }
 }
 
+// The same sums with one THREAD per segment (a segment of the sliced adjacency plan holds ~9 entries on squirrel: a
+// wavefront per segment leaves 55 lanes idle and spends 48 shuffles on the K all-reduces): the thread walks its entries
+// in order and keeps the K sums in registers.  KP = K rounded up to 4 / 8 / 16 / 32.
+template <int KP>
+__global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, int K, const uint8_t* __restrict__ p,
+                                                                const float* __restrict__ a, float* __restrict__ s,
+                                                                float* __restrict__ s_part) {
+    const int seg = blockIdx.x * BLOCK + threadIdx.x;
+    if (seg >= g.n_seg) return;
+    const SegInfo si = load_seg(g, seg);
+    float acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.0f;
+    for (int e = si.beg; e < si.end; e += 4) {                  // four entries in flight (clamped loads), added in order
+        int k[4];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min(e + j, si.end - 1);
+            k[j] = e + j < si.end ? (int)p[i] : 255;
+            v[j] = a[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) acc[kk] += k[j] == kk ? v[j] : 0.0f;
+    }
+    float* dst = si.slot < 0 ? s + (size_t)si.grow * K : s_part + (size_t)si.slot * K;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)
+        if (kk < K) dst[kk] = acc[kk];
+}
+
 // Per multi-segment row: out[grow][k] = f(sum of the K-vectors of its slots, in slot order).
 // One wave per row: lane handles factor k = lane % KP of slot (lane / KP), stride 64/KP.
 // mode 0: plain sum (s);  mode 1: ds_from_acc(sum, s_raw[grow][k]) (normaliser gradient).
@@ -851,6 +884,17 @@ static inline int pow2_at_least(int k) {
     return p;
 }
 
+static void launch_s_rowsum(const dl_csr_plan* g, int K, const uint8_t* p, const float* a, float* s, float* s_part,
+                            hipStream_t st) {
+    if (g->n_seg <= 0) return;
+    const dim3 grid((unsigned)((g->n_seg + BLOCK - 1) / BLOCK)), block(BLOCK);
+    if (K <= 4) hipLaunchKernelGGL(s_rowsum_thread_kernel<4>, grid, block, 0, st, *g, K, p, a, s, s_part);
+    else if (K <= 8) hipLaunchKernelGGL(s_rowsum_thread_kernel<8>, grid, block, 0, st, *g, K, p, a, s, s_part);
+    else if (K <= 16) hipLaunchKernelGGL(s_rowsum_thread_kernel<16>, grid, block, 0, st, *g, K, p, a, s, s_part);
+    else if (K <= 32) hipLaunchKernelGGL(s_rowsum_thread_kernel<32>, grid, block, 0, st, *g, K, p, a, s, s_part);
+    else hipLaunchKernelGGL(s_rowsum_seg_kernel, dim3(seg_blocks(g)), block, 0, st, *g, K, p, a, s, s_part);
+}
+
 static void launch_vec_combine(const dl_csr_plan* g, int K, const float* part, int mode, const float* s_raw,
                                float* out, hipStream_t st) {
     if (g->n_multi <= 0) return;
@@ -873,7 +917,7 @@ struct Ops {
         else
             hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
                                (const T*)Z, t, p, a);
-        hipLaunchKernelGGL(s_rowsum_seg_kernel, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, K, p, a, s, s_part);
+        launch_s_rowsum(g, K, p, a, s, s_part, st);
         launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
         return check_launch("route_fwd(fast)");
     }
