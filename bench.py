@@ -30,7 +30,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 
 # kernel behind each timed phase (the name rocprofv3 reports) -> PMC summary of tools/pmc_traffic.py
 # kernels launched by each phase of the step (names as in the rocprofv3 traces); the combine kernels of a phase are
 # included at their per-launch average
-PHASE_KERNEL = {"route": ("dl::fast::route_seg_kernel<8, 64, float, true>", "dl::fast::s_rowsum_seg_kernel",
+PHASE_KERNEL = {"route": ("dl::fast::route_seg_kernel<8, 64, float, true>", "dl::fast::s_rowsum_thread_kernel<8>",
                           "dl::fast::vec_combine_kernel"),
                 "aggregate": ("dl::fast::aggregate_seg_kernel<8, 64, float>", "dl::fast::row_combine_kernel<512, float, float>"),
                 "score": ("dl::fast::score_fwd_seg_kernel<8, 64, float, false>",)}
@@ -339,7 +339,8 @@ def main():
                      "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "avg_us": kernels[dom]["avg_us"]},
         "edge_scatter": {"kernels": "route+aggregate", "avg_us": scatter_t * 1e6, "algorithmic_bytes": scatter_b,
                          "achieved_GBs": scatter_b / scatter_t / 1e9, "frac": scatter_b / scatter_t / 1e9 / HBM_PEAK_GBS,
-                         "traffic": (kernels["route"]["traffic"] + kernels["aggregate"]["traffic"]) if default_case else None,
+                         "traffic": (kernels["route"]["traffic"] + kernels["aggregate"]["traffic"])
+                         if default_case and None not in (kernels["route"]["traffic"], kernels["aggregate"]["traffic"]) else None,
                          "edges_per_s": E / scatter_t},
         "kernels": kernels,
         "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},

@@ -11,6 +11,7 @@ plumbing, done once per adjacency / pair list — it is not on the per-epoch pat
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from dataclasses import dataclass, field
 
@@ -18,7 +19,10 @@ import torch
 
 from . import _lib
 
-DEFAULT_SEG_LEN = 32        # adjacency rows
+DEFAULT_SEG_LEN = int(os.environ.get("DL_SEG_LEN", "32"))        # adjacency rows (DL_SEG_LEN: experiments only)
+# routing plan (no per-row reduction, hence no partials: shorter segments only add waves in flight — squirrel route
+# phase 46.6 -> 42.9 us, real chameleon 33.4 -> 25.2, Penn94-sized unchanged); 0 = the adjacency plan's
+DEFAULT_ROUTE_SEG_LEN = int(os.environ.get("DL_ROUTE_SEG_LEN", "16"))
 DEFAULT_INC_SEG_LEN = 64    # pair-incidence rows (backward of the scorer)
 DEFAULT_RUN_LEN = 64        # pairs-by-first-endpoint rows (forward scorer)
 DEFAULT_SLICES = 8          # XCDs of an MI355X
@@ -261,7 +265,8 @@ class Graph:
         # XCD slicing of the routing plan was measured and rejected: hub rows already give the Z gathers a high
         # L2 hit rate, and the extra segments cost more than they save (squirrel 50 -> 72 us; 41.6k-node shard
         # 115 -> 107 us).  `row_bytes` is kept for callers that pass the model shape.
-        route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo, seg_len=seg_len, n_slices=1,
+        route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo,
+                              seg_len=min(seg_len, DEFAULT_ROUTE_SEG_LEN or seg_len), n_slices=1,
                               keep=(lc >= lr + lo) if mirror else None)
         route.rowptr, route.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
         return Graph(plan, _i32(rev) if mirror else None, route, mirror)
