@@ -66,6 +66,39 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
     }
 }
 
+// W2 [rows = K*D][nhid] -> planes [3][rows][nhid_p] for layer 2 of the forward, whose B operand is the layer-1
+// accumulator itself: register r of lane half t holds hidden row 8*(r>>2) + 4t + (r&3) of its 32-row tile, so the 8
+// k-slots a lane half supplies to one K = 16 block b are the hidden units 16b + 8*(s>>2) + 4t + (s&3), s = 0..7.
+// The planes are stored in that order (position 16b + 8t + s within every group of 32 hidden units), so the A operand
+// of the block is one 16-byte load per plane.  Hidden units past nhid are zero.
+__global__ __launch_bounds__(256) void split_w2_kernel(const float* __restrict__ W2, int rows, int nhid,
+                                                       __bf16* __restrict__ dst, int nhid_p, size_t ps) {
+    const int groups = nhid_p / 8;
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (size_t)rows * groups) return;
+    const int row = (int)(g / groups), pos = (int)(g % groups) * 8;
+    const int g32 = pos / 32, b = (pos % 32) / 16, t = (pos % 16) / 8;
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int h = 32 * g32 + 16 * b + 8 * (s >> 2) + 4 * t + (s & 3);
+        const float x = h < nhid ? W2[(size_t)row * nhid + h] : 0.0f;
+        __bf16 hi, mid, lo;
+        split3(x, hi, mid, lo);
+        p0[s] = hi; p1[s] = mid; p2[s] = lo;
+    }
+    __bf16* o = dst + (size_t)row * nhid_p + pos;
+    *reinterpret_cast<bf16x8*>(o) = p0;
+    *reinterpret_cast<bf16x8*>(o + ps) = p1;
+    *reinterpret_cast<bf16x8*>(o + 2 * ps) = p2;
+}
+
+void split_w2(const float* W2, int rows, int nhid, __bf16* dst, int nhid_p, hipStream_t st) {
+    const size_t items = (size_t)rows * (nhid_p / 8);
+    hipLaunchKernelGGL(split_w2_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, W2, rows, nhid, dst, nhid_p,
+                       (size_t)rows * nhid_p);
+}
+
 void split_rows(const float* src, int B, int R, int C, int ld, size_t sb, __bf16* dst, hipStream_t st) {
     const int nrb = (int)(round_up(R, PLANE_ROWS) / PLANE_ROWS), ncb = plane_chunks<SPLIT_COLS>(C, SPLIT_COLS);
     const size_t items = (size_t)nrb * ncb * (PLANE_ROWS * SPLIT_COLS / 8);

@@ -1,8 +1,8 @@
 // Factor projection Z[n][k][:] = MLP_k(x[n]) on the matrix cores (model.py:13-15, 24-27, 106) — the
-// only dense contraction of the path.  fp32 in / fp32 results: layer 1 as six exact bf16 products per term
-// from three bf16 planes per operand (dl_tiles.h; fp32-grade accuracy), or — without a workspace, with
-// DL_PROJECT_FP32_MFMA=1, and always for layer 2 — v_mfma_f32_32x32x2_f32, which is bit-for-bit a k-ordered
-// fmaf chain; either way the result keeps the reference's fp32 semantics up to rounding / summation order.
+// only dense contraction of the path.  fp32 in / fp32 results: both layers as six exact bf16 products per term
+// from three bf16 planes per operand (dl_tiles.h; fp32-grade accuracy), or — without a workspace or with
+// DL_PROJECT_FP32_MFMA=1 — v_mfma_f32_32x32x2_f32, which is bit-for-bit a k-ordered fmaf chain; either way
+// the result keeps the reference's fp32 semantics up to rounding / summation order.
 //
 // Two-layer form (Factor2): one workgroup = 8 waves = 128 nodes x ONE factor k, looping over (a group
 // of) 128-unit chunks of the hidden layer.  Waves are 4 x 2: node quarter wn, hidden half wh; each wave
@@ -80,7 +80,10 @@ __device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
 // SPLIT: layer 1 on the bf16 matrix path from three bf16 planes per operand (dl_tiles.h: fp32-grade accuracy at a
 // multiple of the fp32 MFMA rate); x and W1 arrive as padded plane arrays (dl_planes.hip) and the [128][32] tiles are
 // copied without masks.  VEC then only says nhid % 4 == 0 (W2 / b1 quads).
-struct FwdPlanes { const __bf16* x; const __bf16* w; size_t w_batch; int ncb; };   // tile-major planes of x and of the K matrices W1_k
+struct FwdPlanes {
+    const __bf16* x; const __bf16* w; size_t w_batch; int ncb;     // tile-major planes of x and of the K matrices W1_k
+    const __bf16* w2; size_t w2_ps; int nhid_p;                    // planes [3][K*D][nhid_p] of W2 in layer 2's k-slot order
+};
 
 template <int D, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
@@ -167,7 +170,23 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bias[ht][g] = load4_raw<VEC>(b1k, hbase + ht * 32 + 8 * g + 4 * half, nhid);
-            load_w2(wnext, 0, hbase);
+            if constexpr (!SPLIT) load_w2(wnext, 0, hbase);
+        }
+        // SPLIT: the A operand of layer 2 for group grp = (d-tile, hidden tile, K = 16 block): one 16-byte load per plane
+        auto load_w2p = [&](bf16x8 (&a)[3], int grp) {
+            const int dt = grp >> 2, ht = (grp >> 1) & 1, b = grp & 1;
+            const __bf16* src = P.w2 + ((size_t)k * D + dt * 32 + li) * P.nhid_p + hbase + ht * 32 + 16 * b + 8 * half;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(src + p * P.w2_ps);
+        };
+        // one group in flight (issued here for the first, a layer-1 step ahead; three in flight measured no faster)
+        constexpr int W2PF = 1;
+        bf16x8 w2a[W2PF + 1][3];
+        if constexpr (SPLIT) {
+            if (last) {
+#pragma unroll
+                for (int q = 0; q < W2PF; ++q) load_w2p(w2a[q], q);
+            }
         }
         if constexpr (SPLIT) {
             // lane half h supplies features 8h .. 8h+7 of each 16-wide block: A = W1 rows (two hidden tiles), B = x rows
@@ -249,6 +268,26 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                         if (h < nhid && n < N) hid_out[((size_t)k * nhid + h) * ldh + n] = hacc[ht][r];
                     }
             }
+            if constexpr (SPLIT) {
+                // layer 2 on the bf16 matrix path too: the post-ReLU accumulator is split into its three planes in
+                // registers (slot s of block b = register 8b + s), W2 comes pre-split in the matching order
+                bf16x8 hp[2][2][3];
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int s8 = 0; s8 < 8; ++s8) {
+                            __bf16 hi, mid, lo;
+                            split3(hacc[ht][8 * b + s8], hi, mid, lo);
+                            hp[ht][b][0][s8] = hi; hp[ht][b][1][s8] = mid; hp[ht][b][2][s8] = lo;
+                        }
+#pragma unroll
+                for (int grp = 0; grp < 4 * DT; ++grp) {
+                    if (grp + W2PF < 4 * DT) load_w2p(w2a[(grp + W2PF) % (W2PF + 1)], grp + W2PF);
+                    mfma_split6(zacc[grp >> 2], w2a[grp % (W2PF + 1)], hp[(grp >> 1) & 1][grp & 1]);
+                }
+            } else {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 float4 wv[2][4];
@@ -267,6 +306,7 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                         DL_MFMA(zacc[dt], wv[ht][g].w, hacc[ht][4 * g + 3]);
                     }
             }
+            }   // !SPLIT
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) zero_acc(hacc[ht]);
         }
@@ -402,7 +442,7 @@ static int fwd_block_rows(int N) {
 }
 
 // Workspace of the two-layer forward: [Z slabs of the G groups][x planes of one node block][W1 planes]
-struct FwdLayout { int G, R; size_t off_xp, off_wp, bytes; };
+struct FwdLayout { int G, R, nhid_p; size_t off_xp, off_wp, off_w2p, bytes; };
 static FwdLayout fwd_layout(int N, int F, int K, int nhid, int d) {
     FwdLayout L{};
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -414,6 +454,9 @@ static FwdLayout fwd_layout(int N, int F, int K, int nhid, int d) {
         off += al(sizeof(__bf16) * project::plane_array_elems(L.R, F, project::SPLIT_COLS));
         L.off_wp = off;
         off += al(sizeof(__bf16) * K * project::plane_array_elems(nhid, F, project::SPLIT_COLS));
+        L.off_w2p = off;
+        L.nhid_p = (int)project::round_up(nhid, project::TH);
+        off += al(sizeof(__bf16) * 3 * (size_t)K * d * L.nhid_p);
     }
     L.bytes = off;
     return L;
@@ -459,7 +502,10 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         __bf16* xP = reinterpret_cast<__bf16*>(base + L.off_xp);
         __bf16* wP = reinterpret_cast<__bf16*>(base + L.off_wp);
         split_rows(W1, K, nhid, F, F, (size_t)nhid * F, wP, st);
-        P = FwdPlanes{xP, wP, plane_array_elems(nhid, F, SPLIT_COLS), plane_chunks<SPLIT_COLS>(F, SPLIT_COLS)};
+        __bf16* w2P = reinterpret_cast<__bf16*>(base + L.off_w2p);
+        split_w2(W2, K * d, nhid, w2P, L.nhid_p, st);
+        P = FwdPlanes{xP, wP, plane_array_elems(nhid, F, SPLIT_COLS), plane_chunks<SPLIT_COLS>(F, SPLIT_COLS),
+                      w2P, (size_t)K * d * L.nhid_p, L.nhid_p};
     }
     const int nhc = (nhid + TH - 1) / TH;
     const int cpg = (nhc + G - 1) / G;

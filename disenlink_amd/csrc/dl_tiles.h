@@ -215,7 +215,9 @@ struct PlaneStage {
 // dst + b * plane_array_elems(R, C)), and of the TRANSPOSE of src [R][C] (rows = c, columns = r); everything out to
 // the padded extents is written.
 void split_rows(const float* src, int B, int R, int C, int ld, size_t sb, __bf16* dst, hipStream_t st);      // 32-column tiles, columns padded to 32
-void split_transposed(const float* src, int R, int C, int ld, __bf16* dst, hipStream_t st);                 // 16-column tiles, columns (= R) padded to 128
+void split_transposed(const float* src, int R, int C, int ld, __bf16* dst, hipStream_t st);
+// W2 [rows][nhid] -> planes [3][rows][nhid_p] in the k-slot order of the forward's layer 2 (dl_planes.hip)
+void split_w2(const float* W2, int rows, int nhid, __bf16* dst, int nhid_p, hipStream_t st);                 // 16-column tiles, columns (= R) padded to 128
 
 }  // namespace project
 }  // namespace dl

@@ -151,10 +151,11 @@ size_t dl_workspace_bytes(const dl_csr_plan* plan, int K, int d);
  *                          W1 [K][nhid][F], b1 [K][nhid], W2 [K][d][nhid], b2 [K][d]
  *   single layer (Factor): pass W2 = b2 = NULL, nhid = 1:  Z[n][k][:] = W1[k] . x[n] + b1[k],  W1 [K][d][F], b1 [K][d]
  * x is fp32 [N][F] row-major, Z fp32 [N][K][d].  d must be 32, 64 or 128 (dl_project_supported).
- * fp32 in, fp32 results.  With the workspace, layer 1 runs on the bf16 matrix path at fp32-grade accuracy: x and W1
- * are split once per call into three bf16 planes each (x = hi + mid + lo) and every term is the sum of six exact
- * bf16 products in an fp32 accumulator; layer 2, and everything when ws is NULL / too small or
- * DL_PROJECT_FP32_MFMA=1 is set, is plain fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain).
+ * fp32 in, fp32 results.  With the workspace, both layers run on the bf16 matrix path at fp32-grade accuracy: x, W1,
+ * W2 (once per call) and the hidden activations (in registers) are split into three bf16 planes each
+ * (v = hi + mid + lo) and every term is the sum of six exact bf16 products in an fp32 accumulator; when ws is
+ * NULL / too small or DL_PROJECT_FP32_MFMA=1 is set, everything is plain fp32 MFMA (v_mfma_f32_32x32x2_f32: an
+ * exact k-ordered fmaf chain).
  * ws (optional, dl_project_fwd_workspace_bytes): the plane arrays, and on small graphs the partial sums of the
  * several workgroups per node tile that share the hidden layer (added in a fixed order); without it one workgroup
  * walks the whole hidden layer with fp32 MFMA — same result up to rounding / summation order, slower. */
