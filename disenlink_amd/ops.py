@@ -265,7 +265,7 @@ def _pad_features(x, W1):
 def keep_hidden(N: int, F: int, K: int, nhid: int) -> bool:
     """Should the forward keep the hidden layer for the backward?  Recomputing it costs 2*F FLOP per hidden unit
     against 8 bytes of traffic: measured faster at every width tried (F = 128: fwd+bwd 0.35 -> 0.30 ms, F = 2089:
-    2.9 -> 2.0 ms, tools/project_keep_times.py; snap-patents-sized, 45 GiB of hidden layer: epoch 445 -> 397 ms) — while
+    2.9 -> 2.0 ms, tools/project_keep_times.py; snap-patents-sized, 45 GiB of hidden layer: epoch 445 -> 393 ms) — while
     the [K,nhid,N] buffer stays within a quarter of the device's memory, at most 64 GiB (of 288 GB on an MI355X); past
     that the recompute is what keeps large graphs in memory."""
     mode = os.environ.get("DL_KEEP_HIDDEN", "auto")
