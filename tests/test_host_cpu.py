@@ -296,3 +296,19 @@ def test_module_copies_and_pickles_without_its_caches():
     torch.save(m, buf)
     x = torch.randn(4, 6)
     assert torch.equal(c.project(x), m.project(x))               # the copy re-stacks its own parameters
+
+
+def test_bench_pmc_table_covers_every_phase_kernel():
+    """bench.py prices each timed phase with the PMC traffic of its kernels (profiles/pmc_traffic_latest.json, keyed by
+    the kernel names rocprofv3 reports): a renamed kernel must come with regenerated counters, or `traffic` silently
+    turns into null."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    table = json.load(open(bench.PMC_SUMMARY))
+    for phase, names in bench.PHASE_KERNEL.items():
+        for name in names:
+            assert name in table and table[name]["traffic_bytes"] > 0, (phase, name)
+        assert bench.pmc_traffic(phase) > 0
