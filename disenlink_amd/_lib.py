@@ -69,6 +69,8 @@ EXPORTS = {
     "dl_score_allpairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _z, _P]),
     "dl_auc_pair_counts_supported": (_i, [_i, _i]),
     "dl_auc_pair_counts": (_i, [_P, _P, _i, _P, _i, _P, _P]),
+    "dl_score_pairs_train_supported": (_i, [_P, _i, _i, _i]),
+    "dl_score_pairs_train": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_pair_bce": (_i, [_P, _P, _P, _i, _P, _P, _P, _z, _P]),
     "dl_score_pairs_bwd": (_i, [_P, _P, _i, _i, _i, _f, _I, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),

@@ -312,6 +312,29 @@ int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtyp
                                    (hipStream_t)stream);
 }
 
+int dl_score_pairs_train_supported(const dl_pair_incidence* inc, int K, int d, dl_dtype dtype) {
+    return inc != nullptr && use_fast(&inc->csr, K, d, dtype) ? 1 : 0;
+}
+
+int dl_score_pairs_train(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
+                         const dl_pair_incidence* inc, const float* y, const float* w, float* prob, float* dZ,
+                         float* dH, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_shape(K, d)) return rc;
+    DL_REQUIRE(inc != nullptr, "incidence is NULL");
+    const dl_csr_plan* c = &inc->csr;
+    if (int rc = check_plan(c, "incidence")) return rc;
+    if (int rc = check_dtype(c, K, d, dtype)) return rc;
+    DL_REQUIRE(t != 0.0f, "temperature is 0");
+    DL_REQUIRE(use_fast(c, K, d, dtype), "dl_score_pairs_train needs a tuned kernel for K=%d d=%d (dl_score_pairs_train_supported)",
+               K, d);
+    if (c->n_rows == 0) return DL_OK;
+    DL_REQUIRE(Z && H && dZ && dH, "NULL argument");
+    if (c->n_entries > 0) DL_REQUIRE(inc->inc_pair && y && w && prob, "NULL pair argument");
+    Workspace wsp;
+    if (int rc = check_workspace(c, K, d, ws, ws_bytes, &wsp)) return rc;
+    return fast_score_pairs_train(inc, Z, H, K, d, dtype, t, y, w, prob, dZ, dH, wsp.row_part, (hipStream_t)stream);
+}
+
 int dl_route_aggregate_bwd_phase1(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
                                   const uint8_t* p, const float* a, const float* s, const float* dH, float* dw,
                                   float* dwr, float* ds, void* ws, size_t ws_bytes, void* stream) {

@@ -691,13 +691,21 @@ __global__ __launch_bounds__(BLOCK) void score_allpairs_kernel(const T* __restri
 
 // Scorer backward, recomputing e_k and q_k (used when the forward did not store them): one wave per
 // segment of node u's pair slots.  Partials (multi-segment rows) hold [dZ row | dH row] per slot.
-template <int K, int D, typename T>
+// FUSED (training step, dl_score_pairs_train): the same walk IS the forward — the wave has S_k and Q_k of every
+// entry, so it forms prob itself, applies the weighted-BCE gradient of main_disentangled.py:195 inline
+// (g = w (p - y) / max(p (1 - p), 1e-12), exactly dl_pair_bce's) and writes prob[q] (both directions of a pair
+// compute the same bits and both write them).  prob_in / g_prob are then unused, y / w / prob_out are used instead:
+// one pass that gathers the partner rows once per direction, instead of a forward pass plus two backward passes.
+template <int K, int D, typename T, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
                                                               const T* __restrict__ Z, const T* __restrict__ H,
                                                               float t, const float* __restrict__ prob,
                                                               const float* __restrict__ g_prob,
                                                               float* __restrict__ dZ, float* __restrict__ dH,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part,
+                                                              const float* __restrict__ y = nullptr,
+                                                              const float* __restrict__ w = nullptr,
+                                                              float* __restrict__ prob_out = nullptr) {
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
@@ -716,18 +724,24 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     Chunk<VEC> accZ[K], accH[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { accZ[k] = zero_chunk<VEC>(); accH[k] = zero_chunk<VEC>(); }
-    int my_col = si.grow;
-    float my_gl = 0.0f;
+    int my_col = si.grow, my_q = 0;
+    float my_gl = 0.0f, my_y = 0.0f, my_w = 0.0f;
     if (si.beg + lane < si.end) {
         my_col = g.col[si.beg + lane];
         const int q = inc_pair[si.beg + lane];
-        const float pr = prob[q];
-        my_gl = g_prob[q] * pr * (1.0f - pr);           // sigmoid backward p(1-p)
+        if constexpr (FUSED) {
+            my_q = q;
+            my_y = y[q];
+            my_w = w[q];
+        } else {
+            const float pr = prob[q];
+            my_gl = g_prob[q] * pr * (1.0f - pr);       // sigmoid backward p(1-p)
+        }
     }
     for (int base = si.beg; base < si.end; base += EPW) {
         const int idx = base + grp - si.beg;
         const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
-        const float gl = __shfl(my_gl, idx, DL_WAVE);    // 0 past the segment end
+        float gl = __shfl(my_gl, idx, DL_WAVE);          // 0 past the segment end
         Chunk<VEC> zv[K], hv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -743,10 +757,26 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
         }
         TransposedReduce<KP, G / 2>::run(pq, c);
         TransposedReduce<KP, G / 2>::run(ps, c);
-        float ch_lane[VPL], cz_lane[VPL];
+        float ch_lane[VPL], cz_lane[VPL], ek_lane[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) ek_lane[i] = expf(div_t(ps[i], t));
+        if constexpr (FUSED) {
+            float term = 0.0f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (FL::primary(c) && FL::factor_base(c) + i < K) term += pq[i] * ek_lane[i];
+            const float p = sigmoid_ref(group_allreduce_sum<G>(term));
+            const float yy = __shfl(my_y, idx, DL_WAVE), ww = __shfl(my_w, idx, DL_WAVE);   // w = 0 past the segment end
+            const int qq = __shfl(my_q, idx, DL_WAVE);
+            // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(r, 1e-12) * r with r = p (1 - p) — i.e.
+            // w (p - y) itself unless r underflows the clamp (saturated scores: r = 0 gives exactly 0), without the division
+            const float r = p * (1.0f - p);
+            gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (r >= 1e-12f ? 1.0f : r * 1e12f);
+            if (base + grp < si.end && c == 0) prob_out[qq] = p;
+        }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const float ek = expf(div_t(ps[i], t));
+            const float ek = ek_lane[i];
             ch_lane[i] = gl == 0.0f ? 0.0f : gl * ek;
             cz_lane[i] = gl == 0.0f ? 0.0f : gl * pq[i] * ek / t;
         }
@@ -994,12 +1024,25 @@ struct Ops {
                                    part, ROW, no_x, 0.0f, 1.0f, dZ, 0, part_h, dH);
             return check_launch("score_pairs_bwd(fast, stored terms)");
         }
-        hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
+        hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T, false>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
                            (const T*)Z, (const T*)H, t, prob, g_prob, dZ, dH, part);
         if (g->n_multi > 0)
             hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g, part,
                                2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
         return check_launch("score_pairs_bwd(fast)");
+    }
+
+    // training step of the scorer in one pass: prob, and dZ / dH for the weighted BCE of (y, w)
+    static int score_train(const dl_pair_incidence* inc, const void* Z, const void* H, float t, const float* y,
+                           const float* w, float* prob, float* dZ, float* dH, float* part, hipStream_t st) {
+        const dl_csr_plan* g = &inc->csr;
+        const float* no_x = nullptr;
+        hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
+                           (const T*)Z, (const T*)H, t, no_x, no_x, dZ, dH, part, y, w, prob);
+        if (g->n_multi > 0)
+            hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g, part,
+                               2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
+        return check_launch("score_pairs_train(fast)");
     }
 };
 
@@ -1090,6 +1133,15 @@ int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void
                          float* part, hipStream_t st) {
 #define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::score_bwd(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
 #define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::score_bwd(inc, Z, H, t, prob, g_prob, coef, dZ, dH, part, st);
+    DL_DISPATCH(X)
+#undef X_F32
+#undef X_BF16
+}
+
+int fast_score_pairs_train(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype, float t,
+                           const float* y, const float* w, float* prob, float* dZ, float* dH, float* part, hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::score_train(inc, Z, H, t, y, w, prob, dZ, dH, part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::score_train(inc, Z, H, t, y, w, prob, dZ, dH, part, st);
     DL_DISPATCH(X)
 #undef X_F32
 #undef X_BF16

@@ -35,6 +35,8 @@ int fast_bwd_phase2(const dl_csr_plan* g, const void* Z, int K, int d, int dtype
                     const float* dwr, const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
 int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const void* Z, const void* H, int K, int d, int dtype,
                          float t, float* prob, float* coef, hipStream_t st);
+int fast_score_pairs_train(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype, float t,
+                           const float* y, const float* w, float* prob, float* dZ, float* dH, float* part, hipStream_t st);
 int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype,
                          float t, const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
                          float* part, hipStream_t st);

@@ -192,6 +192,19 @@ class Disentangle(nn.Module):
         link_pred = ops.ScoreAllPairs.apply(Z, H, float(self.temperature))
         return H.view(H.shape[0], -1), link_pred
 
+    def forward_pairs_loss(self, x, graph: Graph, pairs: PairList, label, weight):
+        """(emb [N,K*d], prob [P], loss) with loss = sum_q weight BCE(prob, label) (main_disentangled.py:195 on a pair
+        list; metrics.pair_bce_weights): the training step's scorer runs forward and backward in one pass
+        (ops.HotPathPairsLoss).  Falls back to forward_pairs + the fused loss where no tuned kernel exists."""
+        Z = self.project(x)
+        dt = ops._lib.DL_F32 if self.table_dtype == torch.float32 else ops._lib.DL_BF16
+        if ops.score_pairs_train_supported(pairs, Z.shape[1], Z.shape[2], dt):
+            H, prob, loss = ops.HotPathPairsLoss.apply(Z, graph, pairs, float(self.beta), float(self.temperature),
+                                                       self.table_dtype, label, weight)
+            return H.view(H.shape[0], -1), prob, loss
+        H, prob = ops.HotPathPairs.apply(Z, graph, pairs, float(self.beta), float(self.temperature), self.table_dtype)
+        return H.view(H.shape[0], -1), prob, ops.PairBCE.apply(prob, label, weight)
+
     def forward_pairs(self, x, graph: Graph, pairs: PairList):
         """(emb [N,K*d], prob [P]) — the same model evaluated on a pair list only."""
         Z = self.project(x)

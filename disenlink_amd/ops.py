@@ -192,6 +192,32 @@ def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, 
     return dZ, dH
 
 
+def score_pairs_train_supported(pairs: PairList, K: int, d: int, dt: int) -> bool:
+    return bool(_lib.load().dl_score_pairs_train_supported(pairs.c_struct(pairs.n_pairs), K, d, dt))
+
+
+def score_pairs_train(Z, H, pairs: PairList, t: float, label, weight):
+    """-> prob f32[P], dZ, dH f32[N,K,d]: scorer forward, the weighted-BCE gradient of (label, weight) and the scorer
+    backward in ONE pass over the incidence plan (dl_score_pairs_train; tuned (K, d) only).  dZ / dH are the
+    gradients of sum_q weight BCE(prob, label)."""
+    lib = _lib.load()
+    (Z, dt), (H, _dth), label, weight = _tab(Z), _tab(H), _f32c(label), _f32c(weight)
+    _need_cuda(Z, H, label, weight, pairs.inc.rowptr)
+    N, K, d = _nkd(Z)
+    P = int(label.numel())
+    if weight.numel() != P or P != pairs.n_pairs:
+        raise ValueError("label / weight must cover the pair list")
+    prob = _empty(P, torch.float32, Z.device)
+    dZ = _empty(Z.shape, torch.float32, Z.device)
+    dH = _empty(Z.shape, torch.float32, Z.device)
+    inc = pairs.c_struct(P)
+    ws = _workspace(pairs.c_plan(), Z.device, K, d)
+    _lib.check(lib.dl_score_pairs_train(Z.data_ptr(), H.data_ptr(), K, d, dt, float(t), inc, label.data_ptr(),
+                                        weight.data_ptr(), prob.data_ptr(), dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), _stream()), "dl_score_pairs_train")
+    return prob, dZ, dH
+
+
 def route_aggregate_bwd(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_accum=None) -> torch.Tensor:
     """-> dZ f32[N,K,d] (added onto ``dZ_accum`` in place when given).  Unsharded graphs only."""
     lib = _lib.load()
@@ -500,6 +526,47 @@ class HotPathPairs(torch.autograd.Function):
             dH += g_emb
         route_aggregate_bwd(ctx.graph, Zt, ctx.beta, ctx.t, ctx.p, a, s, dH, dZ_accum=dZ)
         return dZ, None, None, None, None, None
+
+
+class HotPathPairsLoss(torch.autograd.Function):
+    """Z [N,K,d] fp32 -> (emb, prob [P], loss): route + aggregate + pair scorer + weighted BCE of (label, weight) as ONE
+    autograd node whose scorer part runs forward AND backward in a single pass (score_pairs_train): the gradients of
+    the loss w.r.t. the scorer's inputs are ready when the forward returns, and the backward only scales them by the
+    incoming d/dloss and continues into aggregation and routing.  A gradient arriving on ``prob`` (another loss on the
+    same scores) is added through the ordinary scorer backward."""
+
+    @staticmethod
+    def forward(ctx, Z, graph: Graph, pairs: PairList, beta: float, t: float, table_dtype, label, weight):
+        ctx.set_materialize_grads(False)
+        lib = _lib.load()
+        Zt = _f32c(Z) if table_dtype == torch.float32 else _f32c(Z).to(table_dtype)
+        p, a, s = route_fwd(graph, Zt, t)
+        H = aggregate_fwd(graph, Zt, beta, p, a, s)
+        prob, dZs, dHs = score_pairs_train(Zt, H, pairs, t, label, weight)
+        loss = _empty(1, torch.float32, prob.device)
+        g = _empty_like(prob)                                   # dl_pair_bce's gradient output: the loss VALUE is what is used
+        ws = _ws.get(8192, prob.device)
+        _lib.check(lib.dl_pair_bce(prob.data_ptr(), _f32c(label).data_ptr(), _f32c(weight).data_ptr(), prob.numel(),
+                                   loss.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_pair_bce")
+        ctx.graph, ctx.pairs, ctx.beta, ctx.t, ctx.p = graph, pairs, beta, t, p
+        ctx.save_for_backward(Zt, H, a, s, prob, dZs, dHs)
+        return H.float(), prob, loss[0]
+
+    @staticmethod
+    def backward(ctx, g_emb, g_prob, g_loss):
+        Zt, H, a, s, prob, dZs, dHs = ctx.saved_tensors
+        if g_loss is not None:
+            dZ, dH = dZs * g_loss, dHs * g_loss
+        else:
+            dZ, dH = torch.zeros_like(dZs), torch.zeros_like(dHs)
+        if g_prob is not None:                                   # some other function of the scores
+            dZ2, dH2 = score_pairs_bwd(Zt, H, ctx.pairs, ctx.t, prob, g_prob.contiguous())
+            dZ += dZ2
+            dH += dH2
+        if g_emb is not None:
+            dH += g_emb
+        route_aggregate_bwd(ctx.graph, Zt, ctx.beta, ctx.t, ctx.p, a, s, dH, dZ_accum=dZ)
+        return dZ, None, None, None, None, None, None, None
 
 
 class ScorePairs(torch.autograd.Function):

@@ -61,6 +61,17 @@ class RunResult:
 
 
 _FUSED_ADAM = os.environ.get("DL_FUSED_ADAM", "1") != "0"
+# scorer forward + loss gradient + scorer backward in one pass (model.forward_pairs_loss); 0 = separate kernels
+_ONE_PASS_SCORER = os.environ.get("DL_ONE_PASS_SCORER", "1") != "0"
+
+
+def _scores_and_loss(model, x, run, label_all, weight_all):
+    """(prob over [pos | neg | validation], loss) of one training forward on the GPU path."""
+    if _ONE_PASS_SCORER and hasattr(model, "forward_pairs_loss"):
+        _emb, prob, loss = model.forward_pairs_loss(x, run.graph, run.train_val_pairs, label_all, weight_all)
+        return prob, loss
+    _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
+    return prob, pair_bce_loss_fused(prob, label_all, weight_all)
 
 
 def _loss_vectors(run, device):
@@ -83,8 +94,7 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     val_plan = AucPlan(run.label_val)
 
     def epoch():
-        _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
-        loss = pair_bce_loss_fused(prob, label_all, weight_all)
+        prob, loss = _scores_and_loss(model, x, run, label_all, weight_all)
         opt.zero_grad(set_to_none=False)
         loss.backward()
         opt.step()
@@ -144,10 +154,10 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
         label_all, weight_all = _loss_vectors(run, x.device)
     for epoch in range(epochs):
         model.train()
-        _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
         if fused:
-            loss = pair_bce_loss_fused(prob, label_all, weight_all)
+            prob, loss = _scores_and_loss(model, x, run, label_all, weight_all)
         else:
+            _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)
             loss = pair_bce_loss(prob[:a], run.label_pos, prob[a:b], run.label_neg, run.m)
         opt.zero_grad()
         loss.backward()

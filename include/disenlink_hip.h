@@ -253,6 +253,20 @@ int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtyp
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob,
                        const float* coef, float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream);
 
+/* Training step of the scorer in ONE pass over the incidence plan: scorer forward (model.py:109-113), the weighted
+ * BCE gradient of main_disentangled.py:195 (g = w (p - y) / max(p (1 - p), 1e-12), as dl_pair_bce computes it) and
+ * the scorer backward (main_disentangled.py:198) together.  The wave that owns a node's pair slots has the
+ * per-factor dot products of every entry, so it forms prob itself and accumulates dZ / dH from the partner rows it
+ * just gathered: the partner rows are gathered once per direction (2 x n_pairs x 2 rows) instead of once for the
+ * forward plus twice for the backward.  Writes prob[q] for every pair of the plan (for the loss VALUE — call
+ * dl_pair_bce on it — and for the validation AUC) and dZ, dH for the plan's rows = d(sum_q w BCE(prob, y)) / d(Z, H).
+ * Pairs with w = 0 (validation pairs riding along) contribute exactly nothing to the gradients.
+ * Tuned (K, d) only: dl_score_pairs_train_supported; otherwise use dl_score_pairs_fwd / dl_pair_bce / _bwd. */
+int dl_score_pairs_train_supported(const dl_pair_incidence* inc, int K, int d, dl_dtype dtype);
+int dl_score_pairs_train(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
+                         const dl_pair_incidence* inc, const float* y, const float* w,
+                         float* prob, float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream);
+
 /* Backward of aggregate + normaliser + routing softmax (autograd of model.py:56-75; argmax and
  * masks carry no gradient), SURVEY.md Appendix A.3, split at its one global dependency:
  *   phase 1:  dw[e] = (1-beta) dH[i][p].Z[j][p],  dwr[e] = (1-beta) dH[j][p].Z[i][p]  (reverse edge)

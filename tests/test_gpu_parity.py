@@ -1122,3 +1122,58 @@ def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
 
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,d,dtype", [(8, 64, torch.float32), (4, 32, torch.float32), (16, 128, torch.float32), (8, 64, torch.bfloat16)])
+def test_one_pass_training_scorer_matches_the_separate_kernels(K, d, dtype):
+    """dl_score_pairs_train (scorer forward + weighted-BCE gradient + scorer backward in one pass over the incidence
+    plan) against dl_score_pairs_fwd -> dl_pair_bce -> dl_score_pairs_bwd: prob, loss, dZ, dH and the full autograd
+    step through ops.HotPathPairsLoss vs ops.HotPathPairs + PairBCE — incl. saturated pairs, weight-0 pairs (validation
+    pairs riding along) and a gradient arriving on prob as well."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import Graph, PairList
+    from disenlink_amd.metrics import pair_bce_weights
+    rng = np.random.default_rng(K * 7 + d)
+    N, E, P = 700, 5000, 9000
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+    pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N, row_bytes=K * d * 4)
+    amp = 0.35 * (32 / d) ** 0.5
+    Z = (torch.randn(N, K, d, generator=torch.Generator().manual_seed(1)) * amp).to(DEV)
+    Z[3] *= 6.0                                                     # a few saturated scores (prob = 1 exactly)
+    label = torch.from_numpy((rng.random(P) < 0.3).astype(np.float32)).to(DEV)
+    weight = pair_bce_weights(int(P * 0.2), P - int(P * 0.2), 5, DEV)
+    weight[-500:] = 0.0                                             # pairs outside the loss
+    beta, t = 0.6, 1.0
+    # raw entry points on the same tables
+    Zt = Z if dtype == torch.float32 else Z.to(dtype)
+    H = ops.aggregate_fwd(G, Zt, beta, *ops.route_fwd(G, Zt, t))
+    prob1, dZ1, dH1 = ops.score_pairs_train(Zt, H, pairs, t, label, weight)
+    prob0 = ops.score_pairs_fwd(Zt, H, pairs.pu, pairs.pv, t, pairs)
+    np.testing.assert_allclose(prob1.cpu().numpy(), prob0.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    pr = prob1.detach().clone().requires_grad_(True)
+    loss_ref = ops.PairBCE.apply(pr, label, weight)
+    (g_prob,) = torch.autograd.grad(loss_ref, pr)
+    dZ0, dH0 = ops.score_pairs_bwd(Zt, H, pairs, t, prob1, g_prob)          # recompute form on the SAME prob
+    for name, got, want in (("dZ", dZ1, dZ0), ("dH", dH1, dH0)):
+        assert torch.isfinite(got).all(), name
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-12, name
+    assert torch.equal(prob1, ops.score_pairs_train(Zt, H, pairs, t, label, weight)[0])       # reproducible
+    # the autograd nodes, with another function of the scores on top of the loss
+    outs = {}
+    for fused in (True, False):
+        Zp = Z.clone().requires_grad_(True)
+        if fused:
+            emb, prob, loss = ops.HotPathPairsLoss.apply(Zp, G, pairs, beta, t, dtype, label, weight)
+        else:
+            emb, prob = ops.HotPathPairs.apply(Zp, G, pairs, beta, t, dtype)
+            loss = ops.PairBCE.apply(prob, label, weight)
+        total = 2.0 * loss + 1e-3 * (prob * prob).sum() + 1e-4 * emb.sum()
+        (gZ,) = torch.autograd.grad(total, Zp)
+        outs[fused] = (loss.detach(), prob.detach(), gZ)
+    assert abs(float(outs[True][0]) - float(outs[False][0])) <= 1e-6 * abs(float(outs[False][0]))
+    np.testing.assert_allclose(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy(), rtol=2e-6, atol=1e-7)
+    scale = float(outs[False][2].abs().max())
+    assert float((outs[True][2] - outs[False][2]).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-3) * scale
