@@ -693,7 +693,7 @@ __global__ __launch_bounds__(BLOCK) void score_allpairs_kernel(const T* __restri
 // segment of node u's pair slots.  Partials (multi-segment rows) hold [dZ row | dH row] per slot.
 // FUSED (training step, dl_score_pairs_train): the same walk IS the forward — the wave has S_k and Q_k of every
 // entry, so it forms prob itself, applies the weighted-BCE gradient of main_disentangled.py:195 inline
-// (g = w (p - y) / max(p (1 - p), 1e-12), exactly dl_pair_bce's) and writes prob[q] (both directions of a pair
+// (g = w (p - y) / max(p (1 - p), 1e-12) as in dl_pair_bce, folded with the sigmoid backward) and writes prob[q] (both directions of a pair
 // compute the same bits and both write them).  prob_in / g_prob are then unused, y / w / prob_out are used instead:
 // one pass that gathers the partner rows once per direction, instead of a forward pass plus two backward passes.
 template <int K, int D, typename T, bool FUSED>
