@@ -61,13 +61,10 @@ class RunResult:
 
 
 _FUSED_ADAM = os.environ.get("DL_FUSED_ADAM", "1") != "0"
-# scorer forward + loss gradient + scorer backward in one pass (model.forward_pairs_loss); 0 = separate kernels
-_ONE_PASS_SCORER = os.environ.get("DL_ONE_PASS_SCORER", "1") != "0"
-
-
 def _scores_and_loss(model, x, run, label_all, weight_all):
-    """(prob over [pos | neg | validation], loss) of one training forward on the GPU path."""
-    if _ONE_PASS_SCORER and hasattr(model, "forward_pairs_loss"):
+    """(prob over [pos | neg | validation], loss) of one training forward on the GPU path; the model decides whether
+    the scorer runs forward + loss gradient + backward in one pass (model.forward_pairs_loss, DL_ONE_PASS_SCORER)."""
+    if hasattr(model, "forward_pairs_loss"):
         _emb, prob, loss = model.forward_pairs_loss(x, run.graph, run.train_val_pairs, label_all, weight_all)
         return prob, loss
     _emb, prob = model.forward_pairs(x, run.graph, run.train_val_pairs)

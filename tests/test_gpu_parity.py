@@ -1174,6 +1174,25 @@ def test_one_pass_training_scorer_matches_the_separate_kernels(K, d, dtype):
         (gZ,) = torch.autograd.grad(total, Zp)
         outs[fused] = (loss.detach(), prob.detach(), gZ)
     assert abs(float(outs[True][0]) - float(outs[False][0])) <= 1e-6 * abs(float(outs[False][0]))
+    # the module picks the one-pass form by table size (forced here) and gives the same loss either way
+    if dtype == torch.float32 and (K, d) == (8, 64):
+        import os
+        from disenlink_amd.model import Disentangle
+        torch.manual_seed(0)
+        m = Disentangle(16, 32, d, nfactor=K, beta=beta, t=t).to(DEV)
+        xx = torch.randn(N, 16, device=DEV)
+        got = {}
+        for mode in ("1", "0"):
+            os.environ["DL_ONE_PASS_SCORER"] = mode
+            try:
+                _e, pr_m, ls_m = m.forward_pairs_loss(xx, G, pairs, label, weight)
+                ls_m.backward()
+                got[mode] = (float(ls_m), m.factor_0.mlp1.weight.grad.clone())
+                m.zero_grad()
+            finally:
+                os.environ.pop("DL_ONE_PASS_SCORER", None)
+        assert abs(got["1"][0] - got["0"][0]) <= 1e-6 * abs(got["0"][0])
+        assert float((got["1"][1] - got["0"][1]).abs().max()) <= 2e-5 * float(got["0"][1].abs().max())
     np.testing.assert_allclose(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy(), rtol=2e-6, atol=1e-7)
     scale = float(outs[False][2].abs().max())
     assert float((outs[True][2] - outs[False][2]).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-3) * scale
