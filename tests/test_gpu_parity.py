@@ -1196,3 +1196,28 @@ def test_one_pass_training_scorer_matches_the_separate_kernels(K, d, dtype):
     np.testing.assert_allclose(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy(), rtol=2e-6, atol=1e-7)
     scale = float(outs[False][2].abs().max())
     assert float((outs[True][2] - outs[False][2]).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-3) * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_training_with_the_one_pass_scorer_follows_the_separate_kernels(use_graph, monkeypatch):
+    """The training loop with DL_ONE_PASS_SCORER=1 (scorer forward + loss gradient + backward in one pass, the form large
+    graphs take by default) against DL_ONE_PASS_SCORER=0 on the same seeded run, eager and replayed from a HIP graph:
+    the same loss / validation-AUC trajectory and test AUC."""
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sg = synthetic_graph("chameleon", seed=5)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=5)
+    run = prepare_run(split, torch.device(DEV), row_bytes=8 * 64 * 4)
+    x = torch.from_numpy(sg.features()).to(DEV)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DL_ONE_PASS_SCORER", mode)
+        torch.manual_seed(0)
+        model = Disentangle(sg.n_feat, 64, 64, nfactor=8, beta=0.6, t=1).to(DEV)
+        out[mode] = run_link_prediction(model, x, run, epochs=25, lr=1e-3, use_graph=use_graph)
+    np.testing.assert_allclose(out["1"].losses, out["0"].losses, rtol=2e-4)
+    np.testing.assert_allclose(out["1"].val_aucs, out["0"].val_aucs, atol=2e-4)
+    assert abs(out["1"].test_auc - out["0"].test_auc) <= 2e-4
