@@ -257,6 +257,34 @@ def main():
     torch.cuda.synchronize()
     fb_ms = (time.perf_counter() - t0) / nb * 1e3
 
+    # extra: the scorer's training step in its two forms: forward storing terms + two backward passes,
+    # and dl_score_pairs_train (forward, loss gradient and backward in one pass; the default for tables that live in HBM)
+    scorer_train = None
+    if args.dtype == "f32":
+        from disenlink_amd.metrics import pair_bce_weights
+        Hs = ops.aggregate_fwd(graph, Z, beta, *ops.route_fwd(graph, Z, t))
+        yb = (torch.rand(P, device=device) < 0.2).float()
+        wb = pair_bce_weights(P // 6, P - P // 6, 5, device)
+        def separate():
+            prob, coef = ops.score_pairs_fwd(Z, Hs, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+            return ops.score_pairs_bwd(Z, Hs, pairs, t, prob, gp, coef=coef)
+        def one_pass():
+            return ops.score_pairs_train(Z, Hs, pairs, t, yb, wb)
+        times = {}
+        for name, fn in (("separate_us", separate), ("one_pass_us", one_pass)):
+            if name == "one_pass_us" and not ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32):
+                continue
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            e1.synchronize()
+            times[name] = e0.elapsed_time(e1) / 5 * 1e3
+        scorer_train = {**times, "pairs": P, "note": "separate = dl_score_pairs_fwd(coef) + dl_score_pairs_bwd; one pass = dl_score_pairs_train"}
+
     # extra: the projection (excluded from the headline) — the path's only MFMA-bound kernels.
     # fp32 in / fp32 results, priced against the fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU); layer 1
     # and the dW1 contraction run as six exact bf16 products per term from three bf16 planes per operand (fp32-grade
@@ -344,6 +372,7 @@ def main():
                          "edges_per_s": E / scatter_t},
         "kernels": kernels,
         "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},
+        "scorer_training_step": scorer_train,
         "projection": proj,
         "dense_allpairs": dense,
     }
