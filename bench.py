@@ -1,19 +1,38 @@
 #!/usr/bin/env python3
 """edges/sec (aggregate+score) at K=8, d=64 — the metric of BASELINE.json — on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload squirrel|chameleon|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload squirrel|chameleon|penn94|snap_patents|...]
+                    [--dtype f32|bf16] [--scaling weak|strong] [--sections all|headline,hbm_bound,...]
 
 One "step" = one forward pass of the hot path over the whole training graph with inputs
 resident in HBM: route (model.py:56-72) + aggregate (model.py:73-75) over the E_sym directed
 non-zeros of the training adjacency, + the pair scorer (model.py:109-113) over the P scored
-training pairs.  value = (E_sym + P) * steps / time  (SURVEY.md §8d headline rate).  The
+training pairs.  value = (E_sym + P) / median step time  (SURVEY.md §8d headline rate).  The
 projection GEMM and the one-time CSR construction are outside the timed region, as §8d says.
+
+Timing: W warm-up steps, then R = --repeats blocks of exactly K steps, each block bracketed by a
+device synchronise; ms_per_step is the MEDIAN block (a 20-step block of the default workload is ~5 ms,
+one sample of that says little).
+
+Roofline accounting.  Two byte counts per kernel phase:
+  * algorithmic_bytes — SURVEY.md §8(d)'s per-unit figures (no cache credit, every directed edge, the u rows of the
+    scorer counted per pair): the nominal size of the problem;
+  * moved_bytes — what the kernels actually request from the memory system per launch: rows gathered (routing walks
+    each undirected edge once; the scorer stages the u rows once per segment in LDS and gathers only v rows), per-entry
+    scalars, per-segment descriptors, outputs and the partial-slot round trips.
+`roofline.achieved` = moved_bytes / kernel time.  On the default workload (squirrel: Z+H = 21 MB) those bytes come out
+of the XCD L2s / the Infinity Cache, not HBM, so the bound that applies is the L2 bandwidth (MI355X_MICROARCH.md §L2:
+34.5 TB/s) and `roofline.bound` says "l2"; the HBM-side traffic measured by rocprofv3 PMC passes rides along as
+`traffic`.  The `hbm_bound` block repeats the measurement IN THE SAME RUN on a workload whose tables (>= 1 GiB) cannot
+sit in any cache, where the 8 TB/s HBM roofline is the bound: that is the number the north star's "fraction of the HBM
+roofline on the K-factor edge-scatter" refers to.
 
 N > 1 is launched by torch.distributed.run, one rank per GPU (see disenlink_amd/dist.py).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,25 +45,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md §L2 (per XCD): ~34.5 TB/s aggregate over the 8 XCDs
+L2_GATHER_REF_GBS = (16800.0, 18800.0)   # ibid. §Indexed rows: L2-resident row gather into LDS, measured lower bounds
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 256 FLOP/clk/CU x 256 CUs x 2.4 GHz
-# kernel behind each timed phase (the name rocprofv3 reports) -> PMC summary of tools/pmc_traffic.py
-# kernels launched by each phase of the step (names as in the rocprofv3 traces); the combine kernels of a phase are
-# included at their per-launch average
-PHASE_KERNEL = {"route": ("dl::fast::route_seg_kernel<8, 64, float, true>", "dl::fast::s_rowsum_thread_kernel<8>",
-                          "dl::fast::vec_combine_kernel"),
-                "aggregate": ("dl::fast::aggregate_seg_kernel<8, 64, float>", "dl::fast::row_combine_kernel<512, float, float>"),
-                "score": ("dl::fast::score_fwd_seg_kernel<8, 64, float, false>",)}
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: dense bf16 MFMA
+# kernels launched by each phase of the step (names as rocprofv3 reports them, template arguments stripped)
+PHASE_KERNELS = {"route": ("route_seg_kernel", "s_rowsum_thread_kernel", "vec_combine_kernel"),
+                 "aggregate": ("aggregate_seg_kernel", "aggregate_wg_kernel", "row_combine_kernel"),
+                 "score": ("score_fwd_seg_kernel",)}
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+NAMES = ("route", "aggregate", "score")
 
 
-def pmc_traffic(phase):
-    """HBM-side bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; same command, same workload), or None."""
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources: a PMC summary collected for other kernels is not this build's traffic."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "disenlink_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload_key: str):
+    """HBM-side bytes per launch and phase from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, separate passes of `bench.py --sections <...>`), or None when no summary exists for
+    this workload or it was collected for different kernel sources."""
     try:
         table = json.load(open(PMC_SUMMARY))
-        return float(sum(table[k]["traffic_bytes"] for k in PHASE_KERNEL[phase]))
-    except (OSError, KeyError, ValueError):
-        return None
+    except (OSError, ValueError):
+        return None, "no PMC summary committed"
+    entry = table.get(workload_key)
+    if not entry:
+        return None, f"no PMC passes committed for {workload_key}"
+    if entry.get("kernel_source_hash") != kernel_source_hash():
+        return None, (f"PMC passes in profiles/ were collected for kernel sources {entry.get('kernel_source_hash')}, "
+                      f"this build is {kernel_source_hash()}: not reported")
+    out = {}
+    for phase, kernels in PHASE_KERNELS.items():
+        tot = 0.0
+        for kname, v in entry["kernels"].items():
+            base = kname.split("<")[0].split("::")[-1]
+            if base in kernels and v.get("phase", phase) == phase:
+                tot += v["traffic_bytes"] * v.get("launches_per_step", 1.0)
+        out[phase] = tot
+    return out, entry.get("source", "profiles/pmc_traffic_latest.json")
 
 
 def algorithmic_bytes(K, d, n_nodes, n_edges, n_pairs, w=4):
@@ -53,6 +99,26 @@ def algorithmic_bytes(K, d, n_nodes, n_edges, n_pairs, w=4):
     route = n_edges * (K * d * w + 9) + n_nodes * (K * d * w + K * 4 + 4)
     aggregate = n_edges * (d * w + 13) + n_nodes * (2 * K * d * w + K * 4 + 4)
     score = n_pairs * (4 * K * d * w + 12)
+    return dict(route=route, aggregate=aggregate, score=score)
+
+
+def moved_bytes(graph, pairs, K, d, w=4):
+    """Bytes the kernels request per launch: gathered rows count every time they are gathered, rows staged
+    in LDS or held in registers count once per segment, partial slots count their write and their read-back."""
+    row = K * d * w
+    plan, rp, pu = graph.plan, graph.route, pairs.by_u
+    E, N = plan.n_entries, plan.n_rows
+    walked = int((rp.seg_end.long() - rp.seg_beg.long()).sum()) if rp is not None else E
+    n_rseg = rp.n_seg if rp is not None else plan.n_seg
+    mirror = 2 if graph.route_mirror else 1
+    route = (walked * (row + 4 + (4 if graph.route_mirror else 0)) + mirror * walked * 5      # gathers, col, rev; p, a out
+             + n_rseg * (row + 16)                                                              # z_i + descriptor
+             + E * 5 + plan.n_seg * 16 + N * K * 4 + plan.n_slots * K * 8)                      # row sums of (p, a) -> s
+    aggregate = (E * (d * w + 4 + 1 + 4 + 4) + plan.n_seg * 16                                  # slice gather, col, p, a, s[col]
+                 + N * 2 * row                                                                  # z_i in, h_i out
+                 + plan.n_slots * K * d * 4 * 2)                                                # partial rows: written, read back
+    P = pairs.n_pairs
+    score = P * (2 * row + 4 + 4 + 4) + pu.n_seg * (2 * row + 16)                               # v rows; u rows once per segment
     return dict(route=route, aggregate=aggregate, score=score)
 
 
@@ -135,21 +201,122 @@ def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=
                 seconds_per_pass=med)
 
 
+def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats):
+    """-> (per-block seconds per step [repeats], per-phase kernel seconds (HIP events on the launch stream, mean))."""
+    def step():
+        p, a, s = ops.route_fwd(graph, Z, t)
+        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+        return ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
+
+    for _ in range(warmup):
+        step()
+    blocks = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / steps)
+    # per-kernel durations with HIP events on the launch stream (torch's current stream), same loop
+    n_ev = min(steps, 50)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
+    torch.cuda.synchronize()
+    for i in range(n_ev):
+        ev[i][0].record()
+        p, a, s = ops.route_fwd(graph, Z, t)
+        ev[i][1].record()
+        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+        ev[i][2].record()
+        ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
+        ev[i][3].record()
+    torch.cuda.synchronize()
+    ktime = {n: float(np.median([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(n_ev)])) * 1e-3
+             for j, n in enumerate(NAMES)}
+    return blocks, ktime
+
+
+def phase_table(ktime, abytes, mbytes, peak, traffic=None):
+    out = {}
+    for n in NAMES:
+        out[n] = dict(avg_us=ktime[n] * 1e6, algorithmic_bytes=abytes[n], moved_bytes=mbytes[n],
+                      achieved_GBs=mbytes[n] / ktime[n] / 1e9, frac=mbytes[n] / ktime[n] / 1e9 / peak,
+                      algorithmic_GBs=abytes[n] / ktime[n] / 1e9)
+        if traffic is not None:
+            out[n]["traffic"] = traffic[n]
+            out[n]["hbm_GBs"] = traffic[n] / ktime[n] / 1e9
+            out[n]["hbm_frac"] = traffic[n] / ktime[n] / 1e9 / HBM_PEAK_GBS
+    return out
+
+
+def scatter_entry(kernels, E, peak):
+    t_ = (kernels["route"]["avg_us"] + kernels["aggregate"]["avg_us"]) * 1e-6
+    mb = kernels["route"]["moved_bytes"] + kernels["aggregate"]["moved_bytes"]
+    ab = kernels["route"]["algorithmic_bytes"] + kernels["aggregate"]["algorithmic_bytes"]
+    out = {"kernels": "route+aggregate", "avg_us": t_ * 1e6, "algorithmic_bytes": ab, "moved_bytes": mb,
+           "achieved_GBs": mb / t_ / 1e9, "frac": mb / t_ / 1e9 / peak, "edges_per_s": E / t_}
+    if "traffic" in kernels["route"]:
+        tr = kernels["route"]["traffic"] + kernels["aggregate"]["traffic"]
+        out.update(traffic=tr, hbm_GBs=tr / t_ / 1e9, hbm_frac=tr / t_ / 1e9 / HBM_PEAK_GBS)
+    return out
+
+
+def hbm_bound_section(ops, device, K, d, nhid, steps, warmup, repeats, workload="snap_patents", scale=0.25, dtype="f32"):
+    """The same forward on a graph whose Z and H tables are far larger than every cache (snap-patents-shaped,
+    a quarter of its size: N = 731k, tables 2 x 1.5 GB in fp32): here the HBM roofline is the bound."""
+    wb = 2 if dtype == "bf16" else 4
+    sg, split, graph, pairs, model, x, Z = build_workload(workload, device, K, d, nhid, scale=scale, elem_bytes=wb)
+    if dtype == "bf16":
+        Z = Z.to(torch.bfloat16)
+    del model, x
+    E, P, N = graph.n_edges, pairs.n_pairs, graph.n_nodes
+    blocks, ktime = time_forward(ops, graph, pairs, Z, 0.5, 1.0, steps, warmup, repeats)
+    ab, mb = algorithmic_bytes(K, d, N, E, P, w=wb), moved_bytes(graph, pairs, K, d, w=wb)
+    key = f"{workload}x{scale:g}_K{K}_d{d}_{dtype}"
+    traffic, src = pmc_traffic(key)
+    kernels = phase_table(ktime, ab, mb, HBM_PEAK_GBS, traffic)
+    dom = max(NAMES, key=lambda n: ktime[n])
+    med = float(np.median(blocks))
+    out = {"workload": f"{workload}-synthetic x{scale:g} (seed 0): N={N}, E_sym={E}, P={P}, K={K}, d={d}, {dtype}; "
+                       f"Z+H = {2 * N * K * d * wb / 2**30:.2f} GiB",
+           "pmc_key": key, "table_bytes": 2 * N * K * d * wb, "n_nodes": N, "E_sym": E, "P": P,
+           "steps": steps, "repeats": repeats, "ms_per_step": med * 1e3, "ms_per_step_blocks": [b * 1e3 for b in blocks],
+           "edges_per_s": (E + P) / med,
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": kernels[dom].get("traffic"),
+                        "traffic_source": src, "moved_bytes": kernels[dom]["moved_bytes"],
+                        "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "avg_us": kernels[dom]["avg_us"]},
+           "edge_scatter": scatter_entry(kernels, E, HBM_PEAK_GBS),
+           "kernels": kernels,
+           "step_bytes_over_time_GBs": sum(mb.values()) / med / 1e9}
+    del graph, pairs, Z
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is their median")
     ap.add_argument("--workload", default="squirrel")
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--nhidden", type=int, default=512)
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = the graph grows with the GPU count, strong = the same graph on every count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the gathered Z/H tables (arithmetic is fp32 either way)")
+    ap.add_argument("--sections", default="all",
+                    help="comma list of: headline, hbm_bound, fwd_bwd, scorer_train, projection, dense, cpu (default all)")
+    ap.add_argument("--hbm-scale", type=float, default=0.25, help="scale of the snap_patents graph of the hbm_bound block")
+    ap.add_argument("--hbm-steps", type=int, default=5)
     args = ap.parse_args()
+    want = lambda s: args.sections == "all" or s in args.sections.split(",")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -190,78 +357,54 @@ def main():
         dist.destroy_process_group()
         return
 
+    wbytes = 2 if args.dtype == "bf16" else 4
     sg, split, graph, pairs, model, x, Z = build_workload(args.workload, device, K, d, args.nhidden, scale=args.scale,
-                                                          elem_bytes=2 if args.dtype == "bf16" else 4)
+                                                          elem_bytes=wbytes)
     E, P, N = graph.n_edges, pairs.n_pairs, graph.n_nodes
-    wbytes = 4
     if args.dtype == "bf16":
-        Z, wbytes = Z.to(torch.bfloat16), 2
+        Z = Z.to(torch.bfloat16)
 
-    def step():
-        p, a, s = ops.route_fwd(graph, Z, t)
-        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
-        return p, a, s, H, prob
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-
-    # per-kernel durations with HIP events on the launch stream (torch's current stream), same loop
-    names = ("route", "aggregate", "score")
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    for i in range(args.steps):
-        ev[i][0].record()
-        p, a, s = ops.route_fwd(graph, Z, t)
-        ev[i][1].record()
-        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
-        ev[i][2].record()
-        prob = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
-        ev[i][3].record()
-    torch.cuda.synchronize()
-    ktime = {n: float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(args.steps)])) * 1e-3
-             for j, n in enumerate(names)}
-    abytes = algorithmic_bytes(K, d, N, E, P, w=wbytes)
-    kernels = {n: dict(avg_us=ktime[n] * 1e6, algorithmic_bytes=abytes[n],
-                       achieved_GBs=abytes[n] / ktime[n] / 1e9, frac=abytes[n] / ktime[n] / 1e9 / HBM_PEAK_GBS)
-               for n in names}
+    table_bytes = 2 * N * K * d * wbytes
+    in_cache = table_bytes <= 128 << 20               # Z+H well inside the 256 MiB Infinity Cache (and near the L2s)
+    peak = L2_PEAK_GBS if in_cache else HBM_PEAK_GBS
+    if want("headline"):
+        blocks, ktime = time_forward(ops, graph, pairs, Z, beta, t, args.steps, args.warmup, args.repeats)
+    else:
+        blocks, ktime = [float("nan")], {n: float("nan") for n in NAMES}
+    step_s = float(np.median(blocks))
+    abytes, mbytes = algorithmic_bytes(K, d, N, E, P, w=wbytes), moved_bytes(graph, pairs, K, d, w=wbytes)
+    pmc_key = f"{args.workload}x{args.scale:g}_K{K}_d{d}_{args.dtype}"
+    traffic, traffic_src = pmc_traffic(pmc_key)
+    kernels = phase_table(ktime, abytes, mbytes, peak, traffic)
     kernels["score"]["pairs_per_s"] = P / ktime["score"]                  # P / t_score
-    default_case = args.workload == "squirrel" and K == 8 and d == 64 and args.dtype == "f32" and args.scale == 1.0
-    for n in names:                                                       # measured fabric-side bytes beside the algorithmic ones
-        kernels[n]["traffic"] = pmc_traffic(n) if default_case else None
-    dom = max(names, key=lambda n: ktime[n])
-    scatter_t = ktime["route"] + ktime["aggregate"]
-    scatter_b = abytes["route"] + abytes["aggregate"]
+    dom = max(NAMES, key=lambda n: ktime[n])
 
     # extra: forward+backward of the same path (what one training epoch adds on top), not the headline
-    gp = torch.full((P,), 1.0 / P, device=device)
-    def train_step():
-        p, a, s = ops.route_fwd(graph, Z, t)
-        H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
-        prob, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
-        dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp, coef=coef)
-        return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
-    for _ in range(3):
-        train_step()
-    torch.cuda.synchronize()
-    nb = max(5, args.steps // 4)
-    t0 = time.perf_counter()
-    for _ in range(nb):
-        train_step()
-    torch.cuda.synchronize()
-    fb_ms = (time.perf_counter() - t0) / nb * 1e3
+    fb_ms = None
+    if want("fwd_bwd"):
+        gp = torch.full((P,), 1.0 / P, device=device)
+        def train_step():
+            p, a, s = ops.route_fwd(graph, Z, t)
+            H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+            prob, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+            dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp, coef=coef)
+            return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize()
+        nb = max(5, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            train_step()
+        torch.cuda.synchronize()
+        fb_ms = (time.perf_counter() - t0) / nb * 1e3
 
     # extra: the scorer's training step in its two forms: forward storing terms + two backward passes,
     # and dl_score_pairs_train (forward, loss gradient and backward in one pass; the default for tables that live in HBM)
     scorer_train = None
-    if args.dtype == "f32":
+    if want("scorer_train") and args.dtype == "f32":
         from disenlink_amd.metrics import pair_bce_weights
+        gp = torch.full((P,), 1.0 / P, device=device)
         Hs = ops.aggregate_fwd(graph, Z, beta, *ops.route_fwd(graph, Z, t))
         yb = (torch.rand(P, device=device) < 0.2).float()
         wb = pair_bce_weights(P // 6, P - P // 6, 5, device)
@@ -283,14 +426,16 @@ def main():
             e1.record()
             e1.synchronize()
             times[name] = e0.elapsed_time(e1) / 5 * 1e3
-        scorer_train = {**times, "pairs": P, "note": "separate = dl_score_pairs_fwd(coef) + dl_score_pairs_bwd; one pass = dl_score_pairs_train"}
+        scorer_train = {**times, "pairs": P, "forward_us": ktime["score"] * 1e6,
+                        "note": "separate = dl_score_pairs_fwd(coef) + dl_score_pairs_bwd; one pass = dl_score_pairs_train"}
 
     # extra: the projection (excluded from the headline) — the path's only MFMA-bound kernels.
-    # fp32 in / fp32 results, priced against the fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU); layer 1
-    # and the dW1 contraction run as six exact bf16 products per term from three bf16 planes per operand (fp32-grade
-    # accuracy), so "achieved" is fp32-equivalent FLOP/s.
+    # fp32 in / fp32 results; layer 1 and the dW1 contraction run as six exact bf16 products per term from three bf16
+    # planes per operand (fp32-grade accuracy).  Two fractions: fp32-equivalent FLOP/s against the fp32
+    # matrix peak (what a caller gets), and the bf16 MFMA FLOP/s actually issued (6x) against the bf16 matrix peak (how
+    # busy the pipe that is used is).
     proj = None
-    if ops.project_supported(d) and not model.single_layer:
+    if want("projection") and ops.project_supported(d) and not model.single_layer:
         st = model._stacked
         W1, b1 = st[("mlp1", "weight")], st[("mlp1", "bias")]
         W2, b2 = st[("mlp2", "weight")], st[("mlp2", "bias")]
@@ -314,19 +459,27 @@ def main():
         fl_f = 2.0 * N * K * nh * (Fx + d)
         fl_b = 2.0 * N * K * nh * (2 * Fx + 2 * d)              # recomputed layer 1, dW1, dhid, dW2
         fl_bk = 2.0 * N * K * nh * (Fx + 2 * d)                 # kept hidden layer: dW1, dhid, dW2
-        proj = {"bound": "mfma", "dtype": "f32" if os.environ.get("DL_PROJECT_FP32_MFMA") else
-                "f32 results; layer 1 and dW1 from three bf16 planes per operand (six exact products per term)",
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp32-equivalent, against the fp32 matrix peak)",
+        planes = not os.environ.get("DL_PROJECT_FP32_MFMA")
+        def both(fl, tt):
+            e = {"avg_us": tt * 1e6, "achieved": fl / tt / 1e12, "frac": fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            if planes:
+                e["bf16_pipe_TFLOPs"] = 6.0 * fl / tt / 1e12
+                e["bf16_pipe_frac"] = 6.0 * fl / tt / 1e12 / BF16_MFMA_PEAK_TFLOPS
+            return e
+        proj = {"bound": "mfma", "dtype": "f32" if not planes else
+                "f32 results; products from three bf16 planes per operand (six exact bf16 MFMA products per term)",
+                "peak": FP32_MFMA_PEAK_TFLOPS, "bf16_peak": BF16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s (fp32-equivalent against the fp32 matrix peak; bf16_pipe_* = issued bf16 MFMA flops, "
+                        "6 per fp32 flop, against the dense bf16 peak — an upper bound: kernel A of the backward and the "
+                        "recompute form's layer 1 still run fp32 MFMA)",
                 "shape": {"N": N, "F": Fx, "K": K, "nhid": nh, "d": d},
-                "fwd": {"avg_us": t_f * 1e6, "achieved": fl_f / t_f / 1e12, "frac": fl_f / t_f / 1e12 / FP32_MFMA_PEAK_TFLOPS},
-                "bwd": {"avg_us": t_b * 1e6, "achieved": fl_b / t_b / 1e12, "frac": fl_b / t_b / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+                "fwd": both(fl_f, t_f), "bwd": both(fl_b, t_b),
                 "fwd_keeping_hidden": {"avg_us": t_fk * 1e6},
-                "bwd_from_kept_hidden": {"avg_us": t_bk * 1e6, "achieved": fl_bk / t_bk / 1e12,
-                                         "frac": fl_bk / t_bk / 1e12 / FP32_MFMA_PEAK_TFLOPS}}
+                "bwd_from_kept_hidden": both(fl_bk, t_bk)}
 
     # extra: the dense [N,N] scorer of the drop-in forward (model.py:109-113 as written): Gram products on MFMA
     dense = None
-    if N <= 12000 and args.dtype == "f32":
+    if want("dense") and N <= 12000 and args.dtype == "f32":
         Hd = ops.aggregate_fwd(graph, Z, beta, *ops.route_fwd(graph, Z, t))
         for _ in range(2):
             ops.score_allpairs_fwd(Z, Hd, t)
@@ -339,19 +492,27 @@ def main():
         t_d = float(np.mean([evd[i].elapsed_time(evd[i + 1]) for i in range(5)])) * 1e-3
         nt = (N + 127) // 128                                   # 128x128 tiles; only u tile <= v tile is computed
         fl_d = 4.0 * K * d * 128 * 128 * (nt * (nt + 1) // 2)   # MFMA flops executed (P is symmetric: half mirrored)
+        split_d = not os.environ.get("DL_DENSE_FP32_MFMA")
         dense = {"bound": "mfma", "dtype": "f32 results from three bf16 planes per operand (six exact products per term)"
-                 if not os.environ.get("DL_DENSE_FP32_MFMA") else "f32", "peak": FP32_MFMA_PEAK_TFLOPS,
+                 if split_d else "f32", "peak": FP32_MFMA_PEAK_TFLOPS,
                  "unit": "TFLOP/s (fp32-equivalent, against the fp32 matrix peak)", "pairs": N * N,
                  "avg_us": t_d * 1e6, "achieved": fl_d / t_d / 1e12, "frac": fl_d / t_d / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                  "effective": 4.0 * N * N * K * d / t_d / 1e12, "pairs_per_s": N * N / t_d}
+        if split_d:
+            dense["bf16_pipe_frac"] = 6.0 * fl_d / t_d / 1e12 / BF16_MFMA_PEAK_TFLOPS
 
     units = E + P
+    bound_note = ("Z+H (%.0f MB) sit in the XCD L2s / the Infinity Cache: the bytes the kernels move come from L2, priced "
+                  "against the L2 bandwidth (MI355X_MICROARCH.md: 34.5 TB/s; its L2-resident row-gather rates are "
+                  "16.8-18.8 TB/s, lower bounds); hbm_* = HBM-side bytes of the rocprofv3 PMC passes against 8 TB/s; "
+                  "the HBM-bound measurement is the hbm_bound block" % (table_bytes / 1e6)) if in_cache else \
+                 "tables far larger than the caches: HBM roofline"
     result = {
         "metric": "edges/sec (aggregate+score) at K=8 d=64",
-        "value": units * args.steps / wall,
+        "value": units / step_s,
         "unit": "edges/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
+        "ms_per_step": step_s * 1e3, "ms_per_step_blocks": [b * 1e3 for b in blocks],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "real edge rows, synthetic features" if args.workload.endswith("_real") else "synthetic",
         "config": {"workload": f"{args.workload + ' (edge list of the parity fixture)' if args.workload.endswith('_real') else args.workload + '-synthetic'}(seed 0): N={N}, edge rows={sg.src.size}, 85/5/10 split, "
@@ -359,30 +520,36 @@ def main():
                                "forward route+aggregate+score_pairs",
                    "K": K, "d": d, "n_nodes": N, "E_sym": E, "P": P, "fast_path": bool(lib.dl_has_fast_path(K, d))
                    and not args.force_generic},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": kernels[dom]["frac"],
-                     "traffic": kernels[dom]["traffic"],
-                     "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                       "separate passes of this command; bytes leaving the XCD L2s per launch)",
-                     "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "avg_us": kernels[dom]["avg_us"]},
-        "edge_scatter": {"kernels": "route+aggregate", "avg_us": scatter_t * 1e6, "algorithmic_bytes": scatter_b,
-                         "achieved_GBs": scatter_b / scatter_t / 1e9, "frac": scatter_b / scatter_t / 1e9 / HBM_PEAK_GBS,
-                         "traffic": (kernels["route"]["traffic"] + kernels["aggregate"]["traffic"])
-                         if default_case and None not in (kernels["route"]["traffic"], kernels["aggregate"]["traffic"]) else None,
-                         "edges_per_s": E / scatter_t},
+        "roofline": {"bound": "l2" if in_cache else "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"],
+                     "peak": peak, "unit": "GB/s", "frac": kernels[dom]["frac"],
+                     "traffic": kernels[dom].get("traffic"), "traffic_source": traffic_src,
+                     "hbm_frac": kernels[dom].get("hbm_frac"),
+                     "moved_bytes": kernels[dom]["moved_bytes"], "algorithmic_bytes": kernels[dom]["algorithmic_bytes"],
+                     "avg_us": kernels[dom]["avg_us"], "l2_gather_reference_GBs": list(L2_GATHER_REF_GBS),
+                     "note": bound_note},
+        "edge_scatter": scatter_entry(kernels, E, peak),
         "kernels": kernels,
-        "fwd_bwd": {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)},
-        "scorer_training_step": scorer_train,
-        "projection": proj,
-        "dense_allpairs": dense,
+        "step_bytes_over_time_GBs": sum(mbytes.values()) / step_s / 1e9,
+        "kernel_source_hash": kernel_source_hash(),
     }
-    if not args.no_cpu_baseline:
-        gcpu = graph.to("cpu")
-        Zc = Z.float().cpu()
+    if fb_ms is not None:
+        result["fwd_bwd"] = {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)}
+    result["scorer_training_step"] = scorer_train
+    result["projection"] = proj
+    result["dense_allpairs"] = dense
+    gcpu = graph.to("cpu") if want("cpu") and not args.no_cpu_baseline else None
+    Zc = Z.float().cpu() if gcpu is not None else None
+    pcpu = (pairs.pu.cpu(), pairs.pv.cpu()) if gcpu is not None else None
+    if want("hbm_bound"):
+        del graph, pairs, Z, model, x
+        torch.cuda.empty_cache()
+        result["hbm_bound"] = hbm_bound_section(ops, device, 8, 64, args.nhidden, args.hbm_steps, 2, args.repeats,
+                                                scale=args.hbm_scale)
+    if gcpu is not None:
         if N <= 12000:                                          # dense [K,N,N] fits: the reference's own form
             result["cpu_baseline"] = cpu_baseline(Zc, gcpu, units, beta, t)
         else:
-            result["cpu_baseline"] = cpu_baseline_sparse(Zc, gcpu, (pairs.pu.cpu(), pairs.pv.cpu()), units, beta, t)
+            result["cpu_baseline"] = cpu_baseline_sparse(Zc, gcpu, pcpu, units, beta, t)
     print(json.dumps(result))
 
 
