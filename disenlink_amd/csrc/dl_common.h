@@ -32,27 +32,81 @@ static inline unsigned seg_blocks(const dl_csr_plan* c) {
 // ---- device helpers ---------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (DL_WAVE - 1); }
 
-// Butterfly all-reduce over the 64 lanes of a wave; every lane ends with the same bits.
-__device__ __forceinline__ float wave_allreduce_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, DL_WAVE);
-    return v;
+// ---- cross-lane exchange without the LDS pipe ----------------------------------------------------------------
+// HIP's __shfl_xor compiles to ds_bpermute_b32 whatever the mask: every butterfly step of every reduction then goes
+// through the LDS crossbar, and the segment kernels (88 of them per wave in the first aggregate kernel, 22 per loop
+// iteration in the router and the scorer) became LDS-issue-bound (SQ_WAIT_INST_LDS 22 % of the wave cycles,
+// profiles/).  A constant xor mask needs none of that on gfx950: masks 1 / 2 / 4 / 8 are DPP modifiers inside a row of
+// 16 lanes (quad_perm, row_half_mirror + quad reverse, row_ror:8), masks 16 / 32 are v_permlane16_swap /
+// v_permlane32_swap — all VALU, and a DPP move folds into the add that consumes it.  Every lane must be active.
+template <int OFF>
+__device__ __forceinline__ int xor_lane_i(int x) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "xor mask must be a power of two < 64");
+    if constexpr (OFF == 1) {
+        return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, true);            // quad_perm:[1,0,3,2]
+    } else if constexpr (OFF == 2) {
+        return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, true);            // quad_perm:[2,3,0,1]
+    } else if constexpr (OFF == 4) {
+        const int y = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, true);    // row_half_mirror: i -> 7 - i
+        return __builtin_amdgcn_update_dpp(y, y, 0x1B, 0xF, 0xF, true);            // quad_perm:[3,2,1,0]: -> i ^ 4
+    } else if constexpr (OFF == 8) {
+        return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, true);           // row_ror:8
+    } else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+        return (threadIdx.x & 16) ? (int)r[0] : (int)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);       // r[0] = lower half twice, r[1] = upper half twice
+        return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+    }
 }
+template <int OFF>
+__device__ __forceinline__ float xor_lane(float v) { return __int_as_float(xor_lane_i<OFF>(__float_as_int(v))); }
+
+// v + (v of lane ^ OFF): for the two wide masks the swap already delivers both addends to every lane
+template <int OFF>
+__device__ __forceinline__ float add_xor(float v) {
+    if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+        return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+    } else if constexpr (OFF == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+        return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+    } else {
+        return v + xor_lane<OFF>(v);
+    }
+}
+
+// butterfly v += xor(v, OFF) for OFF = HI, HI/2, ..., LO (compile-time recursion: the masks must be constants)
+template <int HI, int LO>
+__device__ __forceinline__ float butterfly_down(float v) {
+    if constexpr (HI >= LO && HI >= 1) {
+        return butterfly_down<HI / 2, LO>(add_xor<HI>(v));
+    } else {
+        return v;
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ float butterfly_up(float v) {
+    if constexpr (LO <= HI) {
+        return butterfly_up<LO * 2, HI>(add_xor<LO>(v));
+    } else {
+        return v;
+    }
+}
+
+// Butterfly all-reduce over the 64 lanes of a wave; every lane ends with the same bits.
+__device__ __forceinline__ float wave_allreduce_sum(float v) { return butterfly_down<32, 1>(v); }
 
 // All-reduce over aligned groups of G lanes (G a power of two <= 64).
 template <int G>
 __device__ __forceinline__ float group_allreduce_sum(float v) {
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, DL_WAVE);
-    return v;
+    return butterfly_down<G / 2, 1>(v);
 }
 
 // Sum over the 64/G groups of a wave: lanes with equal (lane % G) are added together.
 template <int G>
 __device__ __forceinline__ float across_groups_sum(float v) {
-#pragma unroll
-    for (int off = G; off < DL_WAVE; off <<= 1) v += __shfl_xor(v, off, DL_WAVE);
-    return v;
+    return butterfly_up<G, 32>(v);
 }
 
 // ---- transposed group reduction ------------------------------------------------------------
@@ -88,11 +142,11 @@ struct TransposedReduce {
                 for (int i = 0; i < N / 2; ++i) {
                     const float send = up ? v[i] : v[i + N / 2];
                     const float keep = up ? v[i + N / 2] : v[i];
-                    v[i] = keep + __shfl_xor(send, OFF, DL_WAVE);
+                    v[i] = keep + xor_lane<OFF>(send);
                 }
                 TransposedReduce<N / 2, OFF / 2>::run(v, c);
             } else {
-                v[0] += __shfl_xor(v[0], OFF, DL_WAVE);
+                v[0] = add_xor<OFF>(v[0]);
                 TransposedReduce<1, OFF / 2>::run(v, c);
             }
         }
@@ -109,15 +163,19 @@ __device__ __forceinline__ bool beats(float v, float best) {
     return (v > best) || (v != v && best == best);
 }
 
-template <int G>
-__device__ __forceinline__ void group_argmax_first(float& best, int& win) {
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, DL_WAVE);
-        const int ow = __shfl_xor(win, off, DL_WAVE);
+template <int OFF>
+__device__ __forceinline__ void argmax_step(float& best, int& win) {
+    if constexpr (OFF >= 1) {
+        const float ob = xor_lane<OFF>(best);
+        const int ow = xor_lane_i<OFF>(win);
         const bool take = ow != 255 && (win == 255 || beats(ob, best) || (!beats(best, ob) && ow < win));
         if (take) { best = ob; win = ow; }
+        argmax_step<OFF / 2>(best, win);
     }
+}
+template <int G>
+__device__ __forceinline__ void group_argmax_first(float& best, int& win) {
+    argmax_step<G / 2>(best, win);
 }
 
 // x / t exactly as the reference divides; t == 1 (the usual temperature) skips the IEEE division
@@ -137,24 +195,69 @@ struct SegInfo {
     int row, grow, beg, end, slot;
 };
 
-__device__ __forceinline__ SegInfo load_seg(const dl_csr_plan& c, int seg) {
-    SegInfo s;
-    s.row = c.seg_row[seg];
-    s.grow = s.row + c.row_offset;
-    s.beg = c.seg_beg[seg];
-    s.end = c.seg_end[seg];
-    s.slot = c.seg_slot[seg];
-    return s;
-}
+static_assert(WAVES_PER_BLOCK == DL_UNIT_SEGS, "a workgroup serves DL_UNIT_SEGS segment positions, one per wavefront");
 
-// Segment served by this wave, or -1.  Segments are stored slice-major and workgroup b serves column
-// slice b % n_slices: workgroups b and b+8 are observed to land on the same XCD, so with 8 slices an
-// XCD's L2 only gathers rows of one eighth of the node table.  Placement changes speed only.
-__device__ __forceinline__ int wave_segment(const dl_csr_plan& c) {
-    const int x = blockIdx.x % c.n_slices;
-    const int i = (blockIdx.x / c.n_slices) * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int seg = c.slice_seg0[x] + i;
-    return seg < c.slice_seg0[x + 1] ? seg : -1;
+// Wave index inside the workgroup as a scalar (every lane of a wave has the same value; the compiler cannot know).
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// What a wave needs to know about its segment and its UNIT (the aligned run of segments of one row inside the
+// workgroup, summed on chip).  Everything comes from scalar loads, and from as few DEPENDENT rounds of them as possible
+// — these kernels run tens of microseconds on small graphs and every round trip to memory in a wave's prologue shows:
+// round 1 = the stream bounds (skipped for unsliced plans: they are [0, n_seg)), round 2 = the DL_UNIT_SEGS rows of the
+// workgroup and the wave's own beg / end / slot, all unconditional (a clamped, valid position; selects afterwards).
+//
+// Positions are stored slice-major and workgroup b serves column slice b % n_slices: workgroups b and b+8 are observed
+// to land on the same XCD, so with 8 slices an XCD's L2 only gathers rows of one eighth of the node table.  Placement
+// changes speed only.  Every slice stream holds a multiple of DL_UNIT_SEGS positions.
+struct WaveSeg {
+    SegInfo si;
+    bool active;      // a real segment (not padding, not past the end)
+    bool head;        // first wave of its unit: sums the unit and writes its result
+    int wave;         // wave index in the workgroup
+    int n_unit;       // head: number of waves (segments) in the unit
+};
+
+__device__ __forceinline__ WaveSeg load_wave_seg(const dl_csr_plan& c) {
+    WaveSeg w;
+    w.wave = wave_index();
+    int s0 = 0, s1 = c.n_seg, wg = (int)blockIdx.x;
+    if (c.n_slices > 1) {
+        const int x = blockIdx.x % c.n_slices;
+        s0 = c.slice_seg0[x];
+        s1 = c.slice_seg0[x + 1];
+        wg = (int)(blockIdx.x / c.n_slices);
+    }
+    const int pos0 = s0 + wg * WAVES_PER_BLOCK;
+    const bool in = pos0 < s1;
+    const int q = in ? pos0 : 0;                                   // launches have n_seg >= DL_UNIT_SEGS
+    int rows[WAVES_PER_BLOCK];
+#pragma unroll
+    for (int u = 0; u < WAVES_PER_BLOCK; ++u) rows[u] = c.seg_row[q + u];
+    const int beg = c.seg_beg[q + w.wave], end = c.seg_end[q + w.wave], slot = c.seg_slot[q + w.wave];
+    int mine = -1, prev = -1;
+#pragma unroll
+    for (int u = 0; u < WAVES_PER_BLOCK; ++u) {
+        if (!in) rows[u] = -1;
+        if (u == w.wave) mine = rows[u];
+        if (u + 1 == w.wave) prev = rows[u];
+    }
+    w.active = mine >= 0;
+    w.head = w.active && (w.wave == 0 || prev != mine);
+    w.n_unit = 0;
+    bool run = true;
+#pragma unroll
+    for (int u = 0; u < WAVES_PER_BLOCK; ++u) {
+        if (u >= w.wave) {
+            run = run && rows[u] == mine;
+            w.n_unit += run ? 1 : 0;
+        }
+    }
+    w.si.row = mine;
+    w.si.grow = mine + c.row_offset;
+    w.si.beg = w.active ? beg : 0;
+    w.si.end = w.active ? end : 0;
+    w.si.slot = w.active ? slot : -1;
+    return w;
 }
 
 }  // namespace dl

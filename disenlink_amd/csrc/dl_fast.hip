@@ -14,11 +14,14 @@
 // log2(G) exchange steps every lane owns the complete dot product of one factor, so exp, softmax
 // weight and the per-factor terms are computed once per factor, not once per lane.
 //
-// Rows with one segment write their outputs directly; segments of multi-segment rows write
-// per-segment partials (fp32, in the caller's workspace) that a combine kernel sums in segment
-// order.  No float atomics anywhere: results are bitwise reproducible.
+// A workgroup (4 waves) serves 4 consecutive segment positions; the segments of a row sit in aligned
+// runs (UNITS, dl_csr_plan) that the workgroup sums on chip through LDS, in segment order.  Rows of one
+// unit (<= 4 segments) write their outputs directly; only rows with several units write per-unit
+// partials (fp32, in the caller's workspace) that a combine kernel sums in unit order.  No float
+// atomics anywhere: results are bitwise reproducible, and independent of how the rows are sharded.
 //
 // Tables Z and H may be stored as fp32 or bf16 (dl_dtype); all arithmetic and all gradients are fp32.
+#include <stdlib.h>
 #include "dl_common.h"
 #include "dl_kernels.h"
 
@@ -140,21 +143,74 @@ __device__ __forceinline__ float lane_exps(float* part, int c, float t, float (&
     return group_allreduce_sum<G>(mine);
 }
 
+// 4 consecutive elements of a table (fp32 or bf16 storage) as a float4
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu),
+                       bf16_to_f32(q.y >> 16));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
+    uint2 q;
+    q.x = f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16);
+    q.y = f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+
+// ---------------------------------------------------------------------------- unit reduction through LDS
+// A segment kernel ends with its per-segment result complete in the lanes of group 0 (lane c: elements
+// kk*D + c*VEC .. of every factor kk).  Every active wave stages it in its own LDS row; after the workgroup barrier the
+// head wave of each unit adds the rows of its unit in wave (= segment) order, all 64 lanes at work: lane l ends up with
+// the float4s x = q*64 + l of the row.
+template <int K, int D, int VEC>
+__device__ __forceinline__ void stage_row(float* dst, const Chunk<VEC> (&acc)[K], int c) {
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) store_f32<VEC>(dst + kk * D + c * VEC, acc[kk]);
+}
+
+template <int ROWF>
+struct UnitSum {
+    static constexpr int F4 = ROWF / 4;
+    static constexpr int NQ = (F4 + DL_WAVE - 1) / DL_WAVE;
+    static_assert(ROWF % 4 == 0, "row length must be a multiple of 4 floats");
+    // red: [WAVES_PER_BLOCK][ROWF] floats, 16-byte aligned
+    static __device__ __forceinline__ void run(const float* red, int wave, int n, int lane, float4 (&r)[NQ]) {
+        const float4* red4 = reinterpret_cast<const float4*>(red);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x < F4) {
+                r[q] = red4[wave * F4 + x];
+                for (int u = 1; u < n; ++u) {
+                    const float4 v = red4[(wave + u) * F4 + x];
+                    r[q].x += v.x; r[q].y += v.y; r[q].z += v.z; r[q].w += v.w;
+                }
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------- route
 // p[e], a[e] for the entries of the plan's segments.  MIRROR: the plan covers col >= row only and
 // every result is also written to the reverse entry (routing is symmetric, bitwise).
 template <int K, int D, typename T, bool MIRROR>
-__global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ rev,
+__global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 6 : 4)) void route_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ rev,
                                                           const T* __restrict__ Z, float t,
                                                           uint8_t* __restrict__ p, float* __restrict__ a) {
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL;
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
+    const WaveSeg ws = load_wave_seg(g);
+    if (!ws.active) return;
+    const SegInfo si = ws.si;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
-    const SegInfo si = load_seg(g, seg);
     const int kb = FL::factor_base(c);
 
     Chunk<VEC> zi[K];
@@ -195,52 +251,43 @@ __global__ __launch_bounds__(BLOCK) void route_seg_kernel(dl_csr_plan g, const i
     }
 }
 
-// s[i][k] = sum_{e in row i, p[e]=k} a[e] (raw; model.py:70-71), one wave per segment of the full plan:
-// lane l holds entry l of the segment; factor k's sum is a wave all-reduce of the lanes routed to k.
-__global__ __launch_bounds__(BLOCK) void s_rowsum_seg_kernel(dl_csr_plan g, int K, const uint8_t* __restrict__ p,
-                                                             const float* __restrict__ a, float* __restrict__ s,
-                                                             float* __restrict__ s_part) {
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
-    const int lane = lane_id();
-    const SegInfo si = load_seg(g, seg);
-    int my_k = 255;
-    float my_a = 0.0f;
-    if (si.beg + lane < si.end) {
-        my_k = p[si.beg + lane];
-        my_a = a[si.beg + lane];
-    }
-    float mine = 0.0f;                                   // lane k ends up with s_k of the segment
-    for (int k = 0; k < K; ++k) {
-        const float v = wave_allreduce_sum(my_k == k ? my_a : 0.0f);
-        if (lane == k) mine = v;
-    }
-    if (lane < K) {
-        float* dst = si.slot < 0 ? s + (size_t)si.grow * K : s_part + (size_t)si.slot * K;
-        dst[lane] = mine;
-    }
+// s[i][k] = sum_{e in row i, p[e]=k} a[e] (raw; model.py:70-71).  Four LANES per segment position (a wavefront per
+// segment would leave most lanes idle and spend its time in K all-reduces; one thread per segment walks 32 entries in
+// eight dependent round trips): lane `sub` of a position adds the entries sub, sub + 4, ... of the segment in order and
+// keeps the K sums in registers; the four lanes are then added as (0 + 1) + (2 + 3), and the (<= 4) positions of a unit —
+// one aligned group of 16 lanes, a DPP row — in segment order by the unit's first position.  All exchanges are DPP
+// (quad_perm, row_shl): no LDS.  KP = K rounded up to 4 / 8 / 16 / 32.
+constexpr int ROWSUM_SUB = 4;                                   // lanes per segment position
+constexpr int ROWSUM_POS_PER_BLOCK = BLOCK / ROWSUM_SUB;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_move_i(int v) {
+    return __builtin_amdgcn_update_dpp(-1, v, CTRL, 0xF, 0xF, false);     // lanes shifted in from outside the row keep -1
 }
 
-// The same sums with one THREAD per segment (a segment of the sliced adjacency plan holds ~9 entries on squirrel: a
-// wavefront per segment leaves 55 lanes idle and spends 48 shuffles on the K all-reduces): the thread walks its entries
-// in order and keeps the K sums in registers.  KP = K rounded up to 4 / 8 / 16 / 32.
 template <int KP>
 __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, int K, const uint8_t* __restrict__ p,
                                                                 const float* __restrict__ a, float* __restrict__ s,
                                                                 float* __restrict__ s_part) {
-    const int seg = blockIdx.x * BLOCK + threadIdx.x;
-    if (seg >= g.n_seg) return;
-    const SegInfo si = load_seg(g, seg);
+    const int seg = blockIdx.x * ROWSUM_POS_PER_BLOCK + (int)(threadIdx.x / ROWSUM_SUB);
+    const int sub = threadIdx.x % ROWSUM_SUB;
+    const int row = seg < g.n_seg ? g.seg_row[seg] : -1;
+    int beg = 0, end = 0, slot = -1;
+    if (row >= 0) { beg = g.seg_beg[seg]; end = g.seg_end[seg]; slot = g.seg_slot[seg]; }
     float acc[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) acc[k] = 0.0f;
-    for (int e = si.beg; e < si.end; e += 4) {                  // four entries in flight (clamped loads), added in order
+    for (int e = beg + sub; e < end; e += 4 * ROWSUM_SUB) {     // four entries in flight per lane (clamped loads), added in order
         int k[4];
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = min(e + j, si.end - 1);
-            k[j] = e + j < si.end ? (int)p[i] : 255;
+            const int i = min(e + j * ROWSUM_SUB, end - 1);
+            k[j] = e + j * ROWSUM_SUB < end ? (int)p[i] : 255;
             v[j] = a[i];
         }
 #pragma unroll
@@ -248,10 +295,30 @@ __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, i
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk) acc[kk] += k[j] == kk ? v[j] : 0.0f;
     }
-    float* dst = si.slot < 0 ? s + (size_t)si.grow * K : s_part + (size_t)si.slot * K;
+    // segment sum over the four lanes of the position: (0 + 1) + (2 + 3), every lane of the quad gets it
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) acc[kk] = add_xor<2>(add_xor<1>(acc[kk]));
+    // unit sum: the 4 positions of a workgroup-sized group are the 4 quads of one DPP row; a unit is a run of equal rows
+    // among them, added in segment order by its first position (row_shl:4q brings quad +q)
+    const int pos_in_grp = (threadIdx.x / ROWSUM_SUB) % WAVES_PER_BLOCK;
+    const int prev_row = dpp_move_i<0x114>(row);                 // row_shr:4: the previous position's row (-1 at the group's start)
+    const bool head = row >= 0 && (pos_in_grp == 0 || prev_row != row);
+    const int r1 = dpp_move_i<0x104>(row), r2 = dpp_move_i<0x108>(row), r3 = dpp_move_i<0x10C>(row);   // row_shl:4 / 8 / 12
+    const bool ok1 = r1 == row, ok2 = ok1 && r2 == row, ok3 = ok2 && r3 == row;
+    float tot[KP];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+        const float v1 = dpp_move<0x104>(acc[kk]), v2 = dpp_move<0x108>(acc[kk]), v3 = dpp_move<0x10C>(acc[kk]);
+        tot[kk] = acc[kk];
+        tot[kk] += ok1 ? v1 : 0.0f;
+        tot[kk] += ok2 ? v2 : 0.0f;
+        tot[kk] += ok3 ? v3 : 0.0f;
+    }
+    if (!head || sub != 0) return;
+    float* dst = slot < 0 ? s + ((size_t)row + g.row_offset) * K : s_part + (size_t)slot * K;
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk)
-        if (kk < K) dst[kk] = acc[kk];
+        if (kk < K) dst[kk] = tot[kk];
 }
 
 // Per multi-segment row: out[grow][k] = f(sum of the K-vectors of its slots, in slot order).
@@ -277,58 +344,87 @@ __global__ __launch_bounds__(BLOCK) void vec_combine_kernel(dl_csr_plan g, int K
 }
 
 // ---------------------------------------------------------------------------- aggregate
-template <int K, int D, typename T>
+// U = gather batches: the loads of U wave iterations (U * 64/G entries) are issued before the first of them is used, so a
+// segment costs ceil(entries / (U * EPW)) memory round trips instead of one per EPW entries (the kernel is latency-bound:
+// 369k edges on 256 CUs).  The per-group summation order is unchanged (entries grp, grp + EPW, ... ascending).
+template <int K, int D, typename T, int U>
 __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
                                                               const uint8_t* __restrict__ p,
                                                               const float* __restrict__ a,
                                                               const float* __restrict__ s, T* __restrict__ H,
                                                               float* __restrict__ h_part) {
     using GE = Geo<K, D, T>;
-    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW;
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
+    using US = UnitSum<ROW>;
+    __shared__ __attribute__((aligned(16))) float red[WAVES_PER_BLOCK][ROW];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
-    const SegInfo si = load_seg(g, seg);
-
-    Chunk<VEC> acc[K];
+    // the row's own z (for h = b z + (1-b) sum) is fetched by the wave that will write h, before anything depends on it
+    float4 zrow[US::NQ];
+    if (ws.head && si.slot < 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
-    // per-entry scalars are computed once by the entry's own lane, then shuffled to its group
-    int my_col = si.grow, my_k = 0;
-    float my_w = 0.0f;
-    if (si.beg + lane < si.end) {
-        my_col = g.col[si.beg + lane];
-        my_k = p[si.beg + lane];
-        my_w = a[si.beg + lane] / one_if_zero(s[(size_t)my_col * K + my_k]);
+        for (int q = 0; q < US::NQ; ++q)
+            if (q * DL_WAVE + lane < US::F4) zrow[q] = load4<T>(Z + (size_t)si.grow * ROW + 4 * (q * DL_WAVE + lane));
     }
-    for (int base = si.beg; base < si.end; base += EPW) {
-        const int idx = base + grp - si.beg;
-        const int j = __shfl(my_col, idx, DL_WAVE);
-        const int k = __shfl(my_k, idx, DL_WAVE);
-        const float w = __shfl(my_w, idx, DL_WAVE);           // 0 past the segment end
-        const Chunk<VEC> v = Tab<T>::load(Z + (size_t)j * GE::ROW + k * D + c * VEC);
+    if (ws.active) {
+        Chunk<VEC> acc[K];
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) fma_chunk(acc[kk], (kk == k) ? w : 0.0f, v);
-    }
+        for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
+        // per-entry scalars are computed once by the entry's own lane, then shuffled to its group
+        int my_col = si.grow, my_k = 0;
+        float my_a = 0.0f, my_w = 0.0f;
+        if (si.beg + lane < si.end) {
+            my_col = g.col[si.beg + lane];
+            my_k = p[si.beg + lane];
+            my_a = a[si.beg + lane];
+        }
+        const int cnt = si.end - si.beg;
+        for (int base = 0; base < cnt; base += EPW * U) {
+            Chunk<VEC> v[U];
+            int kx[U], ix[U];
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
-    if (grp == 0) {
-        if (si.slot < 0) {
-            const float omb = 1.0f - beta;
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                const size_t o = (size_t)si.grow * GE::ROW + kk * D + c * VEC;
-                const Chunk<VEC> z = Tab<T>::load(Z + o);
-                Chunk<VEC> h;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) h.v[i] = beta * z.v[i] + omb * acc[kk].v[i];
-                Tab<T>::store(H + o, h);
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * EPW + grp;
+                ix[u] = idx < cnt ? idx : -1;                     // past the end: a valid row, weight 0
+                const int ic = idx < cnt ? idx : 0;
+                const int j = __shfl(my_col, ic, DL_WAVE);
+                kx[u] = __shfl(my_k, ic, DL_WAVE);
+                v[u] = Tab<T>::load(Z + (size_t)j * ROW + kx[u] * D + c * VEC);
             }
-        } else {
+            // the neighbour's normaliser is fetched BEHIND the first batch of row gathers (which need only col and p):
+            // one round trip to memory fewer in a wave's life
+            if (base == 0 && lane < cnt) my_w = my_a / one_if_zero(s[(size_t)my_col * K + my_k]);
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                store_f32<VEC>(h_part + (size_t)si.slot * GE::ROW + kk * D + c * VEC, acc[kk]);
+            for (int u = 0; u < U; ++u) {
+                const float w = __shfl(my_w, ix[u] < 0 ? 0 : ix[u], DL_WAVE);
+                const float wu = ix[u] < 0 ? 0.0f : w;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) fma_chunk(acc[kk], (kk == kx[u]) ? wu : 0.0f, v[u]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
+        if (grp == 0) stage_row<K, D, VEC>(red[ws.wave], acc, c);
+    }
+    __syncthreads();
+    if (!ws.head) return;
+    float4 r[US::NQ];
+    US::run(&red[0][0], ws.wave, ws.n_unit, lane, r);
+    const float omb = 1.0f - beta;
+#pragma unroll
+    for (int q = 0; q < US::NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < US::F4) {
+            if (si.slot < 0) {
+                const size_t o = (size_t)si.grow * ROW + 4 * x;
+                const float4 z = zrow[q];
+                store4(H + o, make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
+                                          beta * z.w + omb * r[q].w));
+            } else {
+                store4(h_part + (size_t)si.slot * ROW + 4 * x, r[q]);
+            }
         }
     }
 }
@@ -336,24 +432,6 @@ __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, con
 // Per multi-segment row:  out[grow] = (accumulate ? out[grow] : 0) + cx * X[grow] + cp * sum_slots part[slot].
 // One 256-thread block per row: each of the 4 waves sums every 4th slot, LDS combines them in wave
 // order.  Partials are fp32 rows `pstride` floats apart; X and out are tables of type TX / TO.
-template <typename T>
-__device__ __forceinline__ float4 load4(const T* p);
-template <>
-__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <>
-__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
-    const uint2 q = *reinterpret_cast<const uint2*>(p);
-    return make_float4(bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu),
-                       bf16_to_f32(q.y >> 16));
-}
-__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
-    uint2 q;
-    q.x = f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16);
-    q.y = f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16);
-    *reinterpret_cast<uint2*>(p) = q;
-}
-
 template <int TOT, typename TX, typename TO>
 __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const float* __restrict__ part0, int pstride,
                                                             const TX* __restrict__ X, float cx, float cp,
@@ -422,49 +500,53 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, co
                                                                float* __restrict__ ds, float* __restrict__ ds_part) {
     using GE = Geo<K, D, T>;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW;
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
+    __shared__ float redk[WAVES_PER_BLOCK][K];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
-    const SegInfo si = load_seg(g, seg);
     const float omb = 1.0f - beta;
-    float acc[K];
+    if (ws.active) {
+        float acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-    int my_col = si.grow, my_k = 0;
-    float my_a = 0.0f;
-    if (si.beg + lane < si.end) {
-        my_col = g.col[si.beg + lane];
-        my_k = p[si.beg + lane];
-        my_a = a[si.beg + lane];
-    }
-    for (int base = si.beg; base < si.end; base += EPW) {
-        const int e = base + grp;
-        const bool live = e < si.end;
-        const int j = __shfl(my_col, e - si.beg, DL_WAVE);
-        const int k = __shfl(my_k, e - si.beg, DL_WAVE);
-        const float ae = __shfl(my_a, e - si.beg, DL_WAVE);
-        const size_t oi = (size_t)si.grow * GE::ROW + k * D + c * VEC, oj = (size_t)j * GE::ROW + k * D + c * VEC;
-        const float v = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oi), Tab<T>::load(Z + oj)));
-        const float vr = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oj), Tab<T>::load(Z + oi)));
-        if (live && c == 0) { dw[e] = v; dwr[e] = vr; }
-        const float contrib = live ? vr * ae : 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) acc[kk] += (kk == k) ? contrib : 0.0f;
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = across_groups_sum<G>(acc[k]);
-    if (lane == 0) {
-        if (si.slot < 0) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const size_t o = (size_t)si.grow * K + k;
-                ds[o] = ds_from_acc(acc[k], s[o]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) ds_part[(size_t)si.slot * K + k] = acc[k];
+        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+        int my_col = si.grow, my_k = 0;
+        float my_a = 0.0f;
+        if (si.beg + lane < si.end) {
+            my_col = g.col[si.beg + lane];
+            my_k = p[si.beg + lane];
+            my_a = a[si.beg + lane];
         }
+        for (int base = si.beg; base < si.end; base += EPW) {
+            const int e = base + grp;
+            const bool live = e < si.end;
+            const int j = __shfl(my_col, e - si.beg, DL_WAVE);
+            const int k = __shfl(my_k, e - si.beg, DL_WAVE);
+            const float ae = __shfl(my_a, e - si.beg, DL_WAVE);
+            const size_t oi = (size_t)si.grow * GE::ROW + k * D + c * VEC, oj = (size_t)j * GE::ROW + k * D + c * VEC;
+            const float v = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oi), Tab<T>::load(Z + oj)));
+            const float vr = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oj), Tab<T>::load(Z + oi)));
+            if (live && c == 0) { dw[e] = v; dwr[e] = vr; }
+            const float contrib = live ? vr * ae : 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) acc[kk] += (kk == k) ? contrib : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = across_groups_sum<G>(acc[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) redk[ws.wave][k] = acc[k];
+        }
+    }
+    __syncthreads();
+    if (!ws.head || lane >= K) return;
+    float tot = redk[ws.wave][lane];                              // lane k: factor k of the unit, waves added in order
+    for (int u = 1; u < ws.n_unit; ++u) tot += redk[ws.wave + u][lane];
+    if (si.slot < 0) {
+        const size_t o = (size_t)si.grow * K + lane;
+        ds[o] = ds_from_acc(tot, s[o]);
+    } else {
+        ds_part[(size_t)si.slot * K + lane] = tot;
     }
 }
 
@@ -477,81 +559,87 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     float* __restrict__ dZ, int accumulate, float* __restrict__ dz_part) {
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
-    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL;
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
+    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
+    using US = UnitSum<ROW>;
+    __shared__ __attribute__((aligned(16))) float red[WAVES_PER_BLOCK][ROW];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
-    const SegInfo si = load_seg(g, seg);
     const float omb = 1.0f - beta;
     const int kb = FL::factor_base(c);
-
-    Chunk<VEC> zi[K], acc[K];
+    if (ws.active) {
+        Chunk<VEC> zi[K], acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        zi[k] = Tab<T>::load(Z + (size_t)si.grow * GE::ROW + k * D + c * VEC);
-        acc[k] = zero_chunk<VEC>();
-    }
-    // per-entry scalars (routing factor, softmax-gradient scale cc, aggregation weight w2) are
-    // computed once by the entry's own lane and shuffled to its group inside the loop
-    int my_col = si.grow, my_k = 0;
-    float my_cc = 0.0f, my_w2 = 0.0f;
-    if (si.beg + lane < si.end) {
-        const int e = si.beg + lane;
-        my_col = g.col[e];
-        my_k = p[e];
-        const float ae = a[e];
-        const float s_i = one_if_zero(s[(size_t)si.grow * K + my_k]);
-        const float s_j = one_if_zero(s[(size_t)my_col * K + my_k]);
-        const float da = dw[e] / s_j + ds[(size_t)si.grow * K + my_k];
-        const float dar = dwr[e] / s_i + ds[(size_t)my_col * K + my_k];
-        my_cc = (da + dar) * ae;
-        my_w2 = omb * ae / s_i;
-    }
-    for (int base = si.beg; base < si.end; base += EPW) {
-        const int idx = base + grp - si.beg;
-        const int j = __shfl(my_col, idx, DL_WAVE);
-        const int k = __shfl(my_k, idx, DL_WAVE);
-        const float cc = __shfl(my_cc, idx, DL_WAVE);          // 0 past the segment end
-        const float w2 = __shfl(my_w2, idx, DL_WAVE);
-        Chunk<VEC> zj[K];
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) zj[kk] = Tab<T>::load(Z + (size_t)j * GE::ROW + kk * D + c * VEC);
-        const Chunk<VEC> dhj = load_f32<VEC>(dH + (size_t)j * GE::ROW + k * D + c * VEC);
-        float part[KP];
-#pragma unroll
-        for (int kk = 0; kk < KP; ++kk) part[kk] = kk < K ? dot(zi[kk < K ? kk : 0], zj[kk < K ? kk : 0]) : 0.0f;
-        float ex[VPL];
-        const float S = lane_exps<K, G>(part, c, t, ex);
-        float ck_lane[VPL];                                     // coefficient of the factors this lane owns
-#pragma unroll
-        for (int i = 0; i < VPL; ++i)
-            ck_lane[i] = cc == 0.0f ? 0.0f : cc * ((kb + i == k ? 1.0f : 0.0f) - ex[i] / S) / t;
-        const int gbase = lane & ~(G - 1);
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-            const float ck = __shfl(ck_lane[FL::src_slot(kk)], gbase + FL::src_lane(kk), DL_WAVE);
-            fma_chunk(acc[kk], ck, zj[kk]);
-            fma_chunk(acc[kk], kk == k ? w2 : 0.0f, dhj);
+        for (int k = 0; k < K; ++k) {
+            zi[k] = Tab<T>::load(Z + (size_t)si.grow * ROW + k * D + c * VEC);
+            acc[k] = zero_chunk<VEC>();
         }
-    }
+        // per-entry scalars (routing factor, softmax-gradient scale cc, aggregation weight w2) are
+        // computed once by the entry's own lane and shuffled to its group inside the loop
+        int my_col = si.grow, my_k = 0;
+        float my_cc = 0.0f, my_w2 = 0.0f;
+        if (si.beg + lane < si.end) {
+            const int e = si.beg + lane;
+            my_col = g.col[e];
+            my_k = p[e];
+            const float ae = a[e];
+            const float s_i = one_if_zero(s[(size_t)si.grow * K + my_k]);
+            const float s_j = one_if_zero(s[(size_t)my_col * K + my_k]);
+            const float da = dw[e] / s_j + ds[(size_t)si.grow * K + my_k];
+            const float dar = dwr[e] / s_i + ds[(size_t)my_col * K + my_k];
+            my_cc = (da + dar) * ae;
+            my_w2 = omb * ae / s_i;
+        }
+        for (int base = si.beg; base < si.end; base += EPW) {
+            const int idx = base + grp - si.beg;
+            const int j = __shfl(my_col, idx, DL_WAVE);
+            const int k = __shfl(my_k, idx, DL_WAVE);
+            const float cc = __shfl(my_cc, idx, DL_WAVE);          // 0 past the segment end
+            const float w2 = __shfl(my_w2, idx, DL_WAVE);
+            Chunk<VEC> zj[K];
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
-    if (grp == 0) {
-        if (si.slot < 0) {
+            for (int kk = 0; kk < K; ++kk) zj[kk] = Tab<T>::load(Z + (size_t)j * ROW + kk * D + c * VEC);
+            const Chunk<VEC> dhj = load_f32<VEC>(dH + (size_t)j * ROW + k * D + c * VEC);
+            float part[KP];
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) part[kk] = kk < K ? dot(zi[kk < K ? kk : 0], zj[kk < K ? kk : 0]) : 0.0f;
+            float ex[VPL];
+            const float S = lane_exps<K, G>(part, c, t, ex);
+            float ck_lane[VPL];                                     // coefficient of the factors this lane owns
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                ck_lane[i] = cc == 0.0f ? 0.0f : cc * ((kb + i == k ? 1.0f : 0.0f) - ex[i] / S) / t;
+            const int gbase = lane & ~(G - 1);
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                const size_t o = (size_t)si.grow * GE::ROW + kk * D + c * VEC;
-                const Chunk<VEC> dh = load_f32<VEC>(dH + o);
-                Chunk<VEC> r = accumulate ? load_f32<VEC>(dZ + o) : zero_chunk<VEC>();
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) r.v[i] += beta * dh.v[i] + acc[kk].v[i];
-                store_f32<VEC>(dZ + o, r);
+                const float ck = __shfl(ck_lane[FL::src_slot(kk)], gbase + FL::src_lane(kk), DL_WAVE);
+                fma_chunk(acc[kk], ck, zj[kk]);
+                fma_chunk(acc[kk], kk == k ? w2 : 0.0f, dhj);
             }
-        } else {
+        }
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                store_f32<VEC>(dz_part + (size_t)si.slot * GE::ROW + kk * D + c * VEC, acc[kk]);
+        for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
+        if (grp == 0) stage_row<K, D, VEC>(red[ws.wave], acc, c);
+    }
+    __syncthreads();
+    if (!ws.head) return;
+    float4 r[US::NQ];
+    US::run(&red[0][0], ws.wave, ws.n_unit, lane, r);
+#pragma unroll
+    for (int q = 0; q < US::NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < US::F4) {
+            if (si.slot < 0) {
+                const size_t o = (size_t)si.grow * ROW + 4 * x;
+                const float4 dh = load4<float>(dH + o);
+                float4 o4 = accumulate ? load4<float>(dZ + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                o4.x += beta * dh.x + r[q].x; o4.y += beta * dh.y + r[q].y;
+                o4.z += beta * dh.z + r[q].z; o4.w += beta * dh.w + r[q].w;
+                store4(dZ + o, o4);
+            } else {
+                store4(dz_part + (size_t)si.slot * ROW + 4 * x, r[q]);
+            }
         }
     }
 }
@@ -571,7 +659,7 @@ __device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ 
 // One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
 // in LDS, every lane group then scores one pair per iteration from the gathered v rows.
 template <int K, int D, typename T, bool COEF>
-__global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
+__global__ __launch_bounds__(BLOCK, K <= 10 ? 4 : 2) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
                                                               const T* __restrict__ Z, const T* __restrict__ H,
                                                               float t, float* __restrict__ prob,
                                                               float* __restrict__ coef_e,
@@ -582,14 +670,11 @@ __global__ __launch_bounds__(BLOCK) void score_fwd_seg_kernel(dl_csr_plan g, con
     using FLB = FactorLanes<G, KB>;
     constexpr int KBP = FLB::KP;
     __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int seg = wave_segment(g);
-    const bool active = seg >= 0;
-    SegInfo si{0, 0, 0, 0, -1};
-    if (active) {
-        si = load_seg(g, seg);
-        stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
-    }
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
+    const int wave = ws.wave, lane = lane_id();
+    const bool active = ws.active;
+    if (active) stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
     __syncthreads();
     if (!active) return;
     const int c = lane % G, grp = lane / G;
@@ -709,95 +794,107 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
+    using US = UnitSum<2 * ROW>;
+    // per wave: the u rows of Z and H during the walk, then (the same memory) the wave's [dZ row | dH row] for the unit sum
     __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int seg = wave_segment(g);
-    const bool active = seg >= 0;
-    SegInfo si{0, 0, 0, 0, -1};
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
+    const int wave = ws.wave, lane = lane_id();
+    const bool active = ws.active;
+    if (active) stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
+    __syncthreads();
+    const int c = lane % G, grp = lane / G;
     if (active) {
-        si = load_seg(g, seg);
-        stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
+        Chunk<VEC> accZ[K], accH[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { accZ[k] = zero_chunk<VEC>(); accH[k] = zero_chunk<VEC>(); }
+        int my_col = si.grow, my_q = 0;
+        float my_gl = 0.0f, my_y = 0.0f, my_w = 0.0f;
+        if (si.beg + lane < si.end) {
+            my_col = g.col[si.beg + lane];
+            const int q = inc_pair[si.beg + lane];
+            if constexpr (FUSED) {
+                my_q = q;
+                my_y = y[q];
+                my_w = w[q];
+            } else {
+                const float pr = prob[q];
+                my_gl = g_prob[q] * pr * (1.0f - pr);       // sigmoid backward p(1-p)
+            }
+        }
+        for (int base = si.beg; base < si.end; base += EPW) {
+            const int idx = base + grp - si.beg;
+            const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
+            float gl = __shfl(my_gl, idx, DL_WAVE);          // 0 past the segment end
+            Chunk<VEC> zv[K], hv[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                zv[k] = Tab<T>::load(Z + v * ROW + k * D + c * VEC);
+                hv[k] = Tab<T>::load(H + v * ROW + k * D + c * VEC);
+            }
+            float pq[KP], ps[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int kk = k < K ? k : 0;
+                pq[k] = k < K ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
+                ps[k] = k < K ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zv[kk]) : 0.0f;
+            }
+            TransposedReduce<KP, G / 2>::run(pq, c);
+            TransposedReduce<KP, G / 2>::run(ps, c);
+            float ch_lane[VPL], cz_lane[VPL], ek_lane[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) ek_lane[i] = expf(div_t(ps[i], t));
+            if constexpr (FUSED) {
+                float term = 0.0f;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i)
+                    if (FL::primary(c) && FL::factor_base(c) + i < K) term += pq[i] * ek_lane[i];
+                const float p = sigmoid_ref(group_allreduce_sum<G>(term));
+                const float yy = __shfl(my_y, idx, DL_WAVE), ww = __shfl(my_w, idx, DL_WAVE);   // w = 0 past the segment end
+                const int qq = __shfl(my_q, idx, DL_WAVE);
+                // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(r, 1e-12) * r with r = p (1 - p) — i.e.
+                // w (p - y) itself unless r underflows the clamp (saturated scores: r = 0 gives exactly 0), without the division
+                const float r = p * (1.0f - p);
+                gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (r >= 1e-12f ? 1.0f : r * 1e12f);
+                if (base + grp < si.end && c == 0) prob_out[qq] = p;
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float ek = ek_lane[i];
+                ch_lane[i] = gl == 0.0f ? 0.0f : gl * ek;
+                cz_lane[i] = gl == 0.0f ? 0.0f : gl * pq[i] * ek / t;
+            }
+            const int gbase = lane & ~(G - 1);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float ch = __shfl(ch_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
+                const float cz = __shfl(cz_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
+                fma_chunk(accH[k], ch, hv[k]);
+                fma_chunk(accZ[k], cz, zv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { across_groups_sum_chunk<G>(accZ[k]); across_groups_sum_chunk<G>(accH[k]); }
+        // the wave is done with its u rows (its own LDS region, program order): the region now takes its results
+        if (grp == 0) {
+            stage_row<K, D, VEC>(urow[wave], accZ, c);
+            stage_row<K, D, VEC>(urow[wave] + ROW, accH, c);
+        }
     }
     __syncthreads();
-    if (!active) return;
-    const int c = lane % G, grp = lane / G;
-    Chunk<VEC> accZ[K], accH[K];
+    if (!ws.head) return;
+    float4 r[US::NQ];
+    US::run(&urow[0][0], wave, ws.n_unit, lane, r);
 #pragma unroll
-    for (int k = 0; k < K; ++k) { accZ[k] = zero_chunk<VEC>(); accH[k] = zero_chunk<VEC>(); }
-    int my_col = si.grow, my_q = 0;
-    float my_gl = 0.0f, my_y = 0.0f, my_w = 0.0f;
-    if (si.beg + lane < si.end) {
-        my_col = g.col[si.beg + lane];
-        const int q = inc_pair[si.beg + lane];
-        if constexpr (FUSED) {
-            my_q = q;
-            my_y = y[q];
-            my_w = w[q];
-        } else {
-            const float pr = prob[q];
-            my_gl = g_prob[q] * pr * (1.0f - pr);       // sigmoid backward p(1-p)
-        }
-    }
-    for (int base = si.beg; base < si.end; base += EPW) {
-        const int idx = base + grp - si.beg;
-        const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
-        float gl = __shfl(my_gl, idx, DL_WAVE);          // 0 past the segment end
-        Chunk<VEC> zv[K], hv[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            zv[k] = Tab<T>::load(Z + v * ROW + k * D + c * VEC);
-            hv[k] = Tab<T>::load(H + v * ROW + k * D + c * VEC);
-        }
-        float pq[KP], ps[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int kk = k < K ? k : 0;
-            pq[k] = k < K ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
-            ps[k] = k < K ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zv[kk]) : 0.0f;
-        }
-        TransposedReduce<KP, G / 2>::run(pq, c);
-        TransposedReduce<KP, G / 2>::run(ps, c);
-        float ch_lane[VPL], cz_lane[VPL], ek_lane[VPL];
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) ek_lane[i] = expf(div_t(ps[i], t));
-        if constexpr (FUSED) {
-            float term = 0.0f;
-#pragma unroll
-            for (int i = 0; i < VPL; ++i)
-                if (FL::primary(c) && FL::factor_base(c) + i < K) term += pq[i] * ek_lane[i];
-            const float p = sigmoid_ref(group_allreduce_sum<G>(term));
-            const float yy = __shfl(my_y, idx, DL_WAVE), ww = __shfl(my_w, idx, DL_WAVE);   // w = 0 past the segment end
-            const int qq = __shfl(my_q, idx, DL_WAVE);
-            // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(r, 1e-12) * r with r = p (1 - p) — i.e.
-            // w (p - y) itself unless r underflows the clamp (saturated scores: r = 0 gives exactly 0), without the division
-            const float r = p * (1.0f - p);
-            gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (r >= 1e-12f ? 1.0f : r * 1e12f);
-            if (base + grp < si.end && c == 0) prob_out[qq] = p;
-        }
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const float ek = ek_lane[i];
-            ch_lane[i] = gl == 0.0f ? 0.0f : gl * ek;
-            cz_lane[i] = gl == 0.0f ? 0.0f : gl * pq[i] * ek / t;
-        }
-        const int gbase = lane & ~(G - 1);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float ch = __shfl(ch_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
-            const float cz = __shfl(cz_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
-            fma_chunk(accH[k], ch, hv[k]);
-            fma_chunk(accZ[k], cz, zv[k]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) { across_groups_sum_chunk<G>(accZ[k]); across_groups_sum_chunk<G>(accH[k]); }
-    if (grp == 0) {
-        float* oz = si.slot < 0 ? dZ + (size_t)si.grow * ROW : part + (size_t)si.slot * 2 * ROW;
-        float* oh = si.slot < 0 ? dH + (size_t)si.grow * ROW : part + (size_t)si.slot * 2 * ROW + ROW;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            store_f32<VEC>(oz + k * D + c * VEC, accZ[k]);
-            store_f32<VEC>(oh + k * D + c * VEC, accH[k]);
+    for (int q = 0; q < US::NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < US::F4) {
+            if (si.slot < 0) {
+                float* o = x < ROW / 4 ? dZ + (size_t)si.grow * ROW + 4 * x : dH + (size_t)si.grow * ROW + 4 * (x - ROW / 4);
+                store4(o, r[q]);
+            } else {
+                store4(part + (size_t)si.slot * 2 * ROW + 4 * x, r[q]);       // [dZ row | dH row]
+            }
         }
     }
 }
@@ -813,57 +910,66 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g
                                                                    float* __restrict__ out, float* __restrict__ part) {
     using GE = Geo<K, D, T>;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
-    const int seg = wave_segment(g);
-    if (seg < 0) return;
+    using US = UnitSum<ROW>;
+    __shared__ __attribute__((aligned(16))) float red[WAVES_PER_BLOCK][ROW];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
-    const SegInfo si = load_seg(g, seg);
-    Chunk<VEC> acc[K];
+    if (ws.active) {
+        Chunk<VEC> acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
-    int my_col = si.grow, my_pair = 0;
-    float my_gl = 0.0f;
-    if (si.beg + lane < si.end) {
-        my_col = g.col[si.beg + lane];
-        my_pair = inc_pair[si.beg + lane];
-        const float pr = prob[my_pair];
-        my_gl = g_prob[my_pair] * pr * (1.0f - pr);      // sigmoid backward p(1-p)
-        if (PASS == 0) my_gl = div_t(my_gl, t);
-    }
-    for (int base = si.beg; base < si.end; base += EPW) {
-        const int idx = base + grp - si.beg;
-        const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
-        const int q = __shfl(my_pair, idx, DL_WAVE);
-        const float gl = __shfl(my_gl, idx, DL_WAVE);     // 0 past the segment end
-        float ck[K];
-        if constexpr (K % 4 == 0) {
+        for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
+        int my_col = si.grow, my_pair = 0;
+        float my_gl = 0.0f;
+        if (si.beg + lane < si.end) {
+            my_col = g.col[si.beg + lane];
+            my_pair = inc_pair[si.beg + lane];
+            const float pr = prob[my_pair];
+            my_gl = g_prob[my_pair] * pr * (1.0f - pr);      // sigmoid backward p(1-p)
+            if (PASS == 0) my_gl = div_t(my_gl, t);
+        }
+        for (int base = si.beg; base < si.end; base += EPW) {
+            const int idx = base + grp - si.beg;
+            const size_t v = (size_t)__shfl(my_col, idx, DL_WAVE);
+            const int q = __shfl(my_pair, idx, DL_WAVE);
+            const float gl = __shfl(my_gl, idx, DL_WAVE);     // 0 past the segment end
+            float ck[K];
+            if constexpr (K % 4 == 0) {
 #pragma unroll
-            for (int k = 0; k < K; k += 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(coef + (size_t)q * K + k);
-                ck[k] = t4.x; ck[k + 1] = t4.y; ck[k + 2] = t4.z; ck[k + 3] = t4.w;
+                for (int k = 0; k < K; k += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(coef + (size_t)q * K + k);
+                    ck[k] = t4.x; ck[k + 1] = t4.y; ck[k + 2] = t4.z; ck[k + 3] = t4.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) ck[k] = coef[(size_t)q * K + k];
             }
-        } else {
+            // gathers in blocks of <= 8 factor slices: bounded live registers for any K
 #pragma unroll
-            for (int k = 0; k < K; ++k) ck[k] = coef[(size_t)q * K + k];
+            for (int b0 = 0; b0 < K; b0 += 8) {
+                Chunk<VEC> xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k < K) xv[k] = Tab<T>::load(X + v * ROW + (b0 + k) * D + c * VEC);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k < K) fma_chunk(acc[b0 + k], gl * ck[b0 + k], xv[k]);
+            }
         }
-        // gathers in blocks of <= 8 factor slices: bounded live registers for any K
 #pragma unroll
-        for (int b0 = 0; b0 < K; b0 += 8) {
-            Chunk<VEC> xv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (b0 + k < K) xv[k] = Tab<T>::load(X + v * ROW + (b0 + k) * D + c * VEC);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (b0 + k < K) fma_chunk(acc[b0 + k], gl * ck[b0 + k], xv[k]);
-        }
+        for (int k = 0; k < K; ++k) across_groups_sum_chunk<G>(acc[k]);
+        if (grp == 0) stage_row<K, D, VEC>(red[ws.wave], acc, c);
     }
+    __syncthreads();
+    if (!ws.head) return;
+    float4 r[US::NQ];
+    US::run(&red[0][0], ws.wave, ws.n_unit, lane, r);
+    float* o = si.slot < 0 ? out + (size_t)si.grow * ROW : part + (size_t)si.slot * ROW;
 #pragma unroll
-    for (int k = 0; k < K; ++k) across_groups_sum_chunk<G>(acc[k]);
-    if (grp == 0) {
-        float* o = si.slot < 0 ? out + (size_t)si.grow * ROW : part + (size_t)si.slot * ROW;
-#pragma unroll
-        for (int k = 0; k < K; ++k) store_f32<VEC>(o + k * D + c * VEC, acc[k]);
+    for (int q = 0; q < US::NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < US::F4) store4(o + 4 * x, r[q]);
     }
 }
 
@@ -917,12 +1023,11 @@ static inline int pow2_at_least(int k) {
 static void launch_s_rowsum(const dl_csr_plan* g, int K, const uint8_t* p, const float* a, float* s, float* s_part,
                             hipStream_t st) {
     if (g->n_seg <= 0) return;
-    const dim3 grid((unsigned)((g->n_seg + BLOCK - 1) / BLOCK)), block(BLOCK);
+    const dim3 grid((unsigned)((g->n_seg + ROWSUM_POS_PER_BLOCK - 1) / ROWSUM_POS_PER_BLOCK)), block(BLOCK);
     if (K <= 4) hipLaunchKernelGGL(s_rowsum_thread_kernel<4>, grid, block, 0, st, *g, K, p, a, s, s_part);
     else if (K <= 8) hipLaunchKernelGGL(s_rowsum_thread_kernel<8>, grid, block, 0, st, *g, K, p, a, s, s_part);
     else if (K <= 16) hipLaunchKernelGGL(s_rowsum_thread_kernel<16>, grid, block, 0, st, *g, K, p, a, s, s_part);
-    else if (K <= 32) hipLaunchKernelGGL(s_rowsum_thread_kernel<32>, grid, block, 0, st, *g, K, p, a, s, s_part);
-    else hipLaunchKernelGGL(s_rowsum_seg_kernel, dim3(seg_blocks(g)), block, 0, st, *g, K, p, a, s, s_part);
+    else hipLaunchKernelGGL(s_rowsum_thread_kernel<32>, grid, block, 0, st, *g, K, p, a, s, s_part);   // tuned shapes: K <= 32
 }
 
 static void launch_vec_combine(const dl_csr_plan* g, int K, const float* part, int mode, const float* s_raw,
@@ -954,8 +1059,19 @@ struct Ops {
 
     static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
                              const float* s, void* H, float* h_part, hipStream_t st) {
-        hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                           beta, p, a, s, (T*)H, h_part);
+        const int unroll = getenv("DL_AGG_UNROLL") ? atoi(getenv("DL_AGG_UNROLL")) : 4;      // experiments
+        if (unroll >= 8)
+            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 8>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                               beta, p, a, s, (T*)H, h_part);
+        else if (unroll >= 4)
+            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                               beta, p, a, s, (T*)H, h_part);
+        else if (unroll >= 2)
+            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 2>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                               beta, p, a, s, (T*)H, h_part);
+        else
+            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 1>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                               beta, p, a, s, (T*)H, h_part);
         if (g->n_multi > 0)
             hipLaunchKernelGGL((row_combine_kernel<ROW, T, T>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, ROW,
                                (const T*)Z, beta, 1.0f - beta, (T*)H, 0);

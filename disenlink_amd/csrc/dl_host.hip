@@ -72,10 +72,11 @@ void dl_host_csr_free(dl_host_csr* c) {
 }
 
 int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, const int32_t* col, int32_t seg_len,
-                       int32_t n_col_slices, const uint8_t* keep, dl_host_plan* out) {
+                       int32_t n_col_slices, const uint8_t* keep, int32_t unit_segs, dl_host_plan* out) {
     DL_REQUIRE(out != nullptr, "out is NULL");
     memset(out, 0, sizeof(*out));
     DL_REQUIRE(n_rows >= 0 && n_total >= n_rows && seg_len >= 1 && n_col_slices >= 1, "bad plan size");
+    DL_REQUIRE(unit_segs == 1 || unit_segs == DL_UNIT_SEGS, "unit_segs must be 1 or %d", DL_UNIT_SEGS);
     DL_REQUIRE(n_rows == 0 || rowptr, "rowptr is NULL");
     const int32_t n_streams = std::min<int32_t>(n_col_slices, 8);
     // column slices = contiguous node ranges holding equal numbers of (kept) entries: boundaries at the quantiles of
@@ -94,9 +95,25 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
     auto slice_of = [&](int32_t c) {
         return (int32_t)(std::upper_bound(bounds.begin(), bounds.end(), c) - bounds.begin());
     };
-    struct Seg { int32_t row, beg, end, slice, idx_in_row; };
+    // segments in entry order; a unit = up to DL_UNIT_SEGS consecutive segments of one (row, slice) group, counted
+    // from the group's first segment (graph.CsrPlan.build does the same with torch index ops)
+    struct Seg { int32_t row, beg, end, unit; };
+    struct Unit { int32_t row, slice, first_seg, size, pad, slot; int64_t pos; };
     std::vector<Seg> segs;
-    std::vector<int32_t> nseg_row((size_t)n_rows, 0);
+    std::vector<Unit> units;
+    std::vector<int32_t> nunit_row((size_t)n_rows, 0);
+    auto add_group = [&](int32_t row, int32_t q, int32_t b, int32_t e, bool empty_row) {
+        int32_t g = 0;
+        for (int32_t sb = b; sb < e || (empty_row && g == 0); sb += seg_len, ++g) {
+            if (g % unit_segs == 0) {
+                units.push_back({row, q, (int32_t)segs.size(), 0, 0, -1, 0});
+                nunit_row[row]++;
+            }
+            segs.push_back({row, sb, std::min(sb + seg_len, e), (int32_t)units.size() - 1});
+            units.back().size++;
+            if (empty_row) break;
+        }
+    };
     for (int32_t i = 0; i < n_rows; ++i) {
         // kept entries of the row: one contiguous run (checked)
         int32_t b = rowptr[i], e = rowptr[i + 1];
@@ -107,7 +124,8 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
             for (int32_t x = e2; x < e; ++x) DL_REQUIRE(!keep[x], "kept entries must be contiguous inside row %d", i);
             e = e2;
         }
-        int32_t pos = b, idx = 0;
+        int32_t pos = b;
+        bool any = false;
         while (pos < e) {
             const int32_t q = n_col_slices > 1 ? slice_of(col[pos]) : 0;
             int32_t gend = pos;
@@ -116,37 +134,63 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
                            "sliced plans need col ascending inside every row");
                 ++gend;
             }
-            for (int32_t sb = pos; sb < gend; sb += seg_len)
-                segs.push_back({i, sb, std::min(sb + seg_len, gend), q, idx++});
+            add_group(i, q, pos, gend, false);
+            any = true;
             pos = gend;
         }
-        if (idx == 0) segs.push_back({i, rowptr[i], rowptr[i], 0, idx++});   // empty rows own one empty segment
-        nseg_row[i] = idx;
+        if (!any) add_group(i, 0, rowptr[i], rowptr[i], true);   // empty rows own one empty segment
     }
-    // partial slots: consecutive per multi-segment row, in entry order
-    std::vector<int32_t> multi_row, multi_slot0(1, 0), row_slot0((size_t)n_rows, -1);
+    // partial slots: one per unit of a multi-unit row, consecutive per row, in entry order
+    std::vector<int32_t> multi_row, multi_slot0(1, 0), row_slot0((size_t)n_rows, -1), seen((size_t)n_rows, 0);
     for (int32_t i = 0; i < n_rows; ++i)
-        if (nseg_row[i] > 1) {
+        if (nunit_row[i] > 1) {
             row_slot0[i] = multi_slot0.back();
             multi_row.push_back(i);
-            multi_slot0.push_back(multi_slot0.back() + nseg_row[i]);
+            multi_slot0.push_back(multi_slot0.back() + nunit_row[i]);
         }
-    // storage order: one stream per XCD (slice q -> stream q % 8), slices of a stream in time order
-    std::stable_sort(segs.begin(), segs.end(), [&](const Seg& a, const Seg& b) {
-        const int32_t sa = a.slice % n_streams, sb = b.slice % n_streams;
-        return sa != sb ? sa < sb : a.slice < b.slice;
-    });
-    const size_t S = segs.size();
-    std::vector<int32_t> seg_row(S), seg_beg(S), seg_end(S), seg_slot(S), slice_seg0((size_t)n_streams + 1, 0);
-    for (size_t s = 0; s < S; ++s) {
-        seg_row[s] = segs[s].row; seg_beg[s] = segs[s].beg; seg_end[s] = segs[s].end;
-        seg_slot[s] = row_slot0[segs[s].row] < 0 ? -1 : row_slot0[segs[s].row] + segs[s].idx_in_row;
-        slice_seg0[(size_t)(segs[s].slice % n_streams) + 1]++;
+    for (Unit& u : units) {
+        u.pad = u.size == 3 ? 4 : u.size;
+        u.slot = row_slot0[u.row] < 0 ? -1 : row_slot0[u.row] + seen[u.row];
+        seen[u.row]++;
     }
+    // storage order: one stream per XCD (slice q -> stream q % 8), slices of a stream in time order; inside a slice
+    // the units by padded size, largest first (stable), so none straddles a group of DL_UNIT_SEGS positions
+    std::vector<int32_t> uorder(units.size());
+    for (size_t x = 0; x < units.size(); ++x) uorder[x] = (int32_t)x;
+    std::stable_sort(uorder.begin(), uorder.end(), [&](int32_t a, int32_t b) {
+        const Unit &ua = units[a], &ub = units[b];
+        const int32_t sa = ua.slice % n_streams, sb = ub.slice % n_streams;
+        if (sa != sb) return sa < sb;
+        if (ua.slice != ub.slice) return ua.slice < ub.slice;
+        return ua.pad > ub.pad;
+    });
+    std::vector<int64_t> sl_size((size_t)n_col_slices, 0), sl_base((size_t)n_col_slices, 0), sl_fill((size_t)n_col_slices, 0);
+    for (const Unit& u : units) sl_size[u.slice] += u.pad;
+    std::vector<int32_t> slice_seg0((size_t)n_streams + 1, 0);
+    int64_t total = 0;
     int32_t max_seg = 0;
     for (int32_t x = 0; x < n_streams; ++x) {
-        max_seg = std::max(max_seg, slice_seg0[x + 1]);
-        slice_seg0[x + 1] += slice_seg0[x];
+        slice_seg0[x] = (int32_t)total;
+        for (int32_t q = x; q < n_col_slices; q += n_streams) {
+            sl_size[q] = (sl_size[q] + DL_UNIT_SEGS - 1) / DL_UNIT_SEGS * DL_UNIT_SEGS;
+            sl_base[q] = total;
+            total += sl_size[q];
+        }
+        max_seg = std::max<int32_t>(max_seg, (int32_t)(total - slice_seg0[x]));
+    }
+    DL_REQUIRE(total < (1LL << 31), "too many segment positions");
+    slice_seg0[n_streams] = (int32_t)total;
+    for (int32_t x : uorder) {
+        Unit& u = units[x];
+        u.pos = sl_base[u.slice] + sl_fill[u.slice];
+        sl_fill[u.slice] += u.pad;
+    }
+    const size_t S = (size_t)total;
+    std::vector<int32_t> seg_row(S, -1), seg_beg(S, 0), seg_end(S, 0), seg_slot(S, -1);
+    for (size_t x = 0; x < segs.size(); ++x) {
+        const Unit& u = units[segs[x].unit];
+        const size_t p = (size_t)(u.pos + ((int64_t)x - u.first_seg));
+        seg_row[p] = segs[x].row; seg_beg[p] = segs[x].beg; seg_end[p] = segs[x].end; seg_slot[p] = u.slot;
     }
     out->seg_len = seg_len; out->n_seg = (int32_t)S; out->n_slices = n_streams; out->slice_max_seg = max_seg;
     out->n_multi = (int32_t)multi_row.size(); out->n_slots = multi_slot0.back();

@@ -26,6 +26,7 @@ DEFAULT_ROUTE_SEG_LEN = int(os.environ.get("DL_ROUTE_SEG_LEN", "16"))
 DEFAULT_INC_SEG_LEN = 64    # pair-incidence rows (backward of the scorer)
 DEFAULT_RUN_LEN = 64        # pairs-by-first-endpoint rows (forward scorer)
 DEFAULT_SLICES = 8          # XCDs of an MI355X
+UNIT_SEGS = 4               # wavefronts per workgroup = segment positions per workgroup (DL_UNIT_SEGS)
 L2_BYTES_PER_XCD = 4 << 20
 
 
@@ -77,9 +78,14 @@ def _i32(t: torch.Tensor) -> torch.Tensor:
 class CsrPlan:
     """Rows [row_offset, row_offset + n_rows) of a CSR over n_total nodes + its segment plan.
 
-    ``n_slices > 1`` makes the plan XCD-aware: the column space is cut into ``n_slices`` node ranges of equal entry count
-    ranges, no segment spans two ranges (needs ``col`` ascending inside each row) and segments are
-    stored slice-major (``slice_seg0``)."""
+    ``n_slices > 1`` makes the plan XCD-aware: the column space is cut into ``n_slices`` node ranges of equal entry
+    count, no segment spans two ranges (needs ``col`` ascending inside each row) and segments are stored slice-major
+    (``slice_seg0``).
+
+    The ``seg_*`` arrays are indexed by POSITION: a workgroup of ``UNIT_SEGS`` wavefronts serves ``UNIT_SEGS``
+    consecutive positions, and the segments of a row are placed in aligned runs (units) of at most ``UNIT_SEGS`` that
+    the workgroup sums on chip; ``seg_row == -1`` marks a padding position, ``seg_slot`` is the partial slot of the
+    segment's unit (-1: the row is a single unit and needs no partials).  See include/disenlink_hip.h."""
     n_rows: int
     row_offset: int
     n_total: int
@@ -111,9 +117,14 @@ class CsrPlan:
 
     @staticmethod
     def build(rowptr: torch.Tensor, col: torch.Tensor, n_total: int, row_offset: int = 0,
-              seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1, keep: torch.Tensor | None = None) -> "CsrPlan":
+              seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1, keep: torch.Tensor | None = None,
+              unit_segs: int = UNIT_SEGS) -> "CsrPlan":
         """``keep`` (bool per entry, optional): segments cover only the kept entries, which must form one
-        contiguous run inside every row (e.g. the upper triangle ``col >= row`` of a sorted row)."""
+        contiguous run inside every row (e.g. the upper triangle ``col >= row`` of a sorted row).
+        ``unit_segs = 1``: every segment is its own unit — for plans whose kernels reduce nothing across segments
+        (routing, the forward scorer): positions then simply follow the entry order."""
+        if unit_segs not in (1, UNIT_SEGS):
+            raise ValueError(f"unit_segs must be 1 or {UNIT_SEGS}")
         if seg_len < 1 or n_slices < 1:
             raise ValueError("seg_len and n_slices must be >= 1")
         rowptr = rowptr.to(torch.int64)
@@ -160,30 +171,72 @@ class CsrPlan:
         seg_beg = torch.cat([seg_beg, rowptr[empty]])
         seg_end = torch.cat([seg_end, rowptr[empty]])
         seg_slice = torch.cat([seg_slice, torch.zeros_like(empty)])
-        # row order: index of a segment inside its row -> partial slots of multi-segment rows
+        # entry order: (row, first entry); a (row, slice) group is a run of this order
         order = torch.argsort(seg_row * (E_all + 1) + seg_beg, stable=True)
         seg_row, seg_beg, seg_end, seg_slice = seg_row[order], seg_beg[order], seg_end[order], seg_slice[order]
-        nseg_row = torch.bincount(seg_row, minlength=n_rows)
-        row_seg0 = torch.cumsum(nseg_row, 0) - nseg_row
-        idx_in_row = ar(seg_row.numel()) - row_seg0[seg_row]
-        multi_row = torch.nonzero(nseg_row > 1).reshape(-1)
+        S = int(seg_row.numel())
+        # UNITS: up to UNIT_SEGS consecutive segments of one (row, slice) group, counted from the group's first
+        # segment — so the chunking of a row depends on that row alone (a shard cuts its rows exactly like the whole
+        # graph does: results stay bitwise independent of the sharding).  A workgroup (UNIT_SEGS wavefronts) serves
+        # UNIT_SEGS consecutive POSITIONS of a slice stream and sums each unit on chip; only rows with more than one
+        # unit go through partial slots (one per UNIT, not per segment).
+        grp_key = seg_row * n_slices + seg_slice
+        gnew = torch.ones(S, dtype=torch.bool, device=dev)
+        gnew[1:] = grp_key[1:] != grp_key[:-1]
+        gstart_pos = torch.nonzero(gnew).reshape(-1)
+        g_of = torch.cumsum(gnew, 0) - 1
+        idx_in_grp = ar(S) - gstart_pos[g_of]
+        unew = gnew | (idx_in_grp % unit_segs == 0)
+        u_of = torch.cumsum(unew, 0) - 1                          # unit of every segment, units in entry order
+        ufirst = torch.nonzero(unew).reshape(-1)
+        n_units = int(ufirst.numel())
+        u_size = torch.bincount(u_of, minlength=n_units)
+        u_pad = torch.where(u_size == 3, torch.full_like(u_size, 4), u_size)   # 1, 2, 4: aligned when placed largest first
+        u_row, u_slice = seg_row[ufirst], seg_slice[ufirst]
+        # partial slots: one per unit of a multi-unit row, consecutive per row in entry order
+        nunit_row = torch.bincount(u_row, minlength=n_rows)
+        multi_row = torch.nonzero(nunit_row > 1).reshape(-1)
         multi_slot0 = torch.zeros(multi_row.numel() + 1, dtype=torch.int64, device=dev)
-        multi_slot0[1:] = torch.cumsum(nseg_row[multi_row], dim=0)
+        multi_slot0[1:] = torch.cumsum(nunit_row[multi_row], dim=0)
         row_slot0 = torch.full((n_rows,), -1, dtype=torch.int64, device=dev)
         row_slot0[multi_row] = multi_slot0[:-1]
-        rs = row_slot0[seg_row]
-        seg_slot = torch.where(rs >= 0, rs + idx_in_row, rs)
-        # storage order: one STREAM of segments per XCD.  Column slice q belongs to stream q % 8 and the
-        # slices of a stream follow each other in time (q // 8), so an XCD works on one slice at a time;
-        # stable sort keeps row order inside a slice.
+        row_unit0 = torch.cumsum(nunit_row, 0) - nunit_row
+        u_idx_in_row = ar(n_units) - row_unit0[u_row]
+        u_slot = torch.where(row_slot0[u_row] >= 0, row_slot0[u_row] + u_idx_in_row, row_slot0[u_row])
+        # storage: one STREAM of positions per XCD.  Column slice q belongs to stream q % 8 and the slices of a stream
+        # follow each other in time (q // 8), so an XCD works on one slice at a time.  Inside a slice the units are placed
+        # by padded size, largest first (stable: entry order among equals), so no unit straddles a group of UNIT_SEGS
+        # positions; every slice region is padded to a multiple of UNIT_SEGS.  Pad positions have seg_row = -1.
         n_streams = min(n_slices, DEFAULT_SLICES)
-        stream = seg_slice % n_streams
-        perm = torch.argsort(stream * (n_slices + 1) + seg_slice, stable=True)
+        u_stream = u_slice % n_streams
+        uperm = torch.argsort((u_stream * (n_slices + 1) + u_slice) * 8 + (UNIT_SEGS - u_pad), stable=True)
+        sl_size = torch.zeros(n_slices, dtype=torch.int64, device=dev).index_add_(0, u_slice, u_pad)
+        sl_size = (sl_size + UNIT_SEGS - 1) // UNIT_SEGS * UNIT_SEGS
+        sl_order = torch.argsort((ar(n_slices) % n_streams) * (n_slices + 1) + ar(n_slices), stable=True)   # (stream, slice)
+        sl_base = torch.zeros(n_slices, dtype=torch.int64, device=dev)
+        sl_base[sl_order] = torch.cumsum(sl_size[sl_order], 0) - sl_size[sl_order]
+        pad_sorted = u_pad[uperm]
+        run = torch.cumsum(pad_sorted, 0) - pad_sorted             # exclusive cumsum over all units in storage order ...
+        sl_sorted = u_slice[uperm]
+        first_of_slice = torch.ones(n_units, dtype=torch.bool, device=dev)
+        first_of_slice[1:] = sl_sorted[1:] != sl_sorted[:-1]
+        run0 = run[torch.nonzero(first_of_slice).reshape(-1)]      # ... minus its value at the slice's first unit
+        slice_rank = torch.cumsum(first_of_slice, 0) - 1
+        u_pos = torch.empty(n_units, dtype=torch.int64, device=dev)
+        u_pos[uperm] = sl_base[sl_sorted] + run - run0[slice_rank]
+        n_pos = int(sl_size.sum())
+        pos = u_pos[u_of] + (ar(S) - ufirst[u_of])
+        p_row = torch.full((n_pos,), -1, dtype=torch.int64, device=dev)
+        p_beg = torch.zeros(n_pos, dtype=torch.int64, device=dev)
+        p_end = torch.zeros(n_pos, dtype=torch.int64, device=dev)
+        p_slot = torch.full((n_pos,), -1, dtype=torch.int64, device=dev)
+        p_row[pos], p_beg[pos], p_end[pos], p_slot[pos] = seg_row, seg_beg, seg_end, u_slot[u_of]
+        stream_size = torch.zeros(n_streams, dtype=torch.int64, device=dev).index_add_(0, ar(n_slices) % n_streams, sl_size)
         slice_seg0 = torch.zeros(n_streams + 1, dtype=torch.int64, device=dev)
-        slice_seg0[1:] = torch.cumsum(torch.bincount(stream, minlength=n_streams), 0)
-        return CsrPlan(n_rows, row_offset, n_total, _i32(rowptr), _i32(col), seg_len, _i32(seg_row[perm]),
-                       _i32(seg_beg[perm]), _i32(seg_end[perm]), _i32(seg_slot[perm]), n_streams,
-                       int((slice_seg0[1:] - slice_seg0[:-1]).max()), _i32(slice_seg0),
+        slice_seg0[1:] = torch.cumsum(stream_size, 0)
+        return CsrPlan(n_rows, row_offset, n_total, _i32(rowptr), _i32(col), seg_len, _i32(p_row),
+                       _i32(p_beg), _i32(p_end), _i32(p_slot), n_streams,
+                       int(stream_size.max()), _i32(slice_seg0),
                        _i32(multi_row), _i32(multi_slot0), int(multi_slot0[-1]))
 
     def to(self, device) -> "CsrPlan":
@@ -267,7 +320,7 @@ class Graph:
         # 115 -> 107 us).  `row_bytes` is kept for callers that pass the model shape.
         route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo,
                               seg_len=min(seg_len, DEFAULT_ROUTE_SEG_LEN or seg_len), n_slices=1,
-                              keep=(lc >= lr + lo) if mirror else None)
+                              keep=(lc >= lr + lo) if mirror else None, unit_segs=1)
         route.rowptr, route.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
         return Graph(plan, _i32(rev) if mirror else None, route, mirror)
 
@@ -341,23 +394,24 @@ class PairList:
         dev = pu.device
         ids = torch.arange(P, device=dev)
 
-        def csr(node, other, pair, lo, hi, seg):
+        def csr(node, other, pair, lo, hi, seg, unit_segs=UNIT_SEGS):
             keep = (node >= lo) & (node < hi)
             node, other, pair = node[keep], other[keep], pair[keep]
             order = torch.argsort((node - lo) * n_nodes + other, stable=True)   # fixed order -> reproducible sums
             rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
             if node.numel():
                 rowptr[1:] = torch.cumsum(torch.bincount(node - lo, minlength=hi - lo), dim=0)
-            plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=n_slices)
+            plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=n_slices,
+                                 unit_segs=unit_segs)
             return plan, _i32(pair[order])
 
         ulo, uhi = (0, n_nodes) if by_u_range is None else by_u_range
         if P and build_by_u and (int(pu.min()) < ulo or int(pu.max()) >= uhi):
             raise ValueError("a first endpoint lies outside by_u_range")
         if build_by_u:
-            by_u, by_u_pair = csr(pu, pv, ids, ulo, uhi, run_len)
+            by_u, by_u_pair = csr(pu, pv, ids, ulo, uhi, run_len, unit_segs=1)     # the forward scorer sums nothing across segments
         else:                                              # backward-only list (sharded runs): empty forward plan
-            by_u, by_u_pair = csr(pu[:0], pv[:0], ids[:0], 0, 0, run_len)
+            by_u, by_u_pair = csr(pu[:0], pv[:0], ids[:0], 0, 0, run_len, unit_segs=1)
         lo, hi = (0, n_nodes) if row_range is None else row_range
         inc, inc_pair = csr(torch.cat([pu, pv]), torch.cat([pv, pu]), ids.repeat(2), lo, hi, seg_len)
         return PairList(n_nodes, _i32(pu), _i32(pv), by_u, by_u_pair, inc, inc_pair)

@@ -49,14 +49,24 @@ extern "C" {
 typedef enum dl_dtype { DL_F32 = 0, DL_BF16 = 1 } dl_dtype;
 
 /* A CSR over (a shard of) the nodes plus the segment plan that balances skewed rows: every row is
- * cut into >= 1 segments of <= seg_len consecutive entries; one wavefront owns one segment.  Rows
- * with several segments reduce through per-segment partial slots in the workspace.
+ * cut into >= 1 segments of <= seg_len consecutive entries; one wavefront owns one segment and one
+ * workgroup (DL_UNIT_SEGS = 4 wavefronts) serves DL_UNIT_SEGS consecutive POSITIONS of the seg_* arrays.
+ *
+ * Units.  The segments of a row (of one column slice of a row, see below) are grouped, counting from the
+ * row's first segment, into UNITS of at most DL_UNIT_SEGS consecutive segments.  A unit never straddles a
+ * group of DL_UNIT_SEGS positions (units of 3 are padded to 4, units are stored largest first inside a
+ * slice, every slice region is padded to a multiple of DL_UNIT_SEGS; seg_row = -1 marks a padding
+ * position), so the workgroup that holds it sums it on chip, in segment order.  Only rows with more than
+ * one unit reduce through partial slots in the workspace — one slot per unit, summed in slot (= entry)
+ * order by a combine kernel.  How a row is cut depends on that row alone, so a row shard gives the same
+ * bits as the whole graph.
  *
  * XCD-aware slicing (optional, n_slices = 8 on MI355X): the column space is cut into n_slices
- * equal node ranges and no segment spans two of them; segments are stored slice-major and
+ * node ranges of equal entry count and no segment spans two of them; positions are stored slice-major and
  * workgroup b serves slice b % n_slices.  Workgroups b and b+8 are observed to share an XCD, so
  * each XCD's 4 MiB L2 only ever gathers rows of "its" 1/8 of the node table.  Placement is a
  * speed matter only: results do not depend on it. */
+#define DL_UNIT_SEGS 4
 typedef struct dl_csr_plan {
     int32_t n_rows;             /* rows of this plan */
     int32_t row_offset;         /* global node id of row 0 */
@@ -65,16 +75,16 @@ typedef struct dl_csr_plan {
     const int32_t* rowptr;      /* [n_rows+1] */
     const int32_t* col;         /* [n_entries] global node ids */
     int32_t seg_len;
-    int32_t n_seg;
-    const int32_t* seg_row;     /* [n_seg] local row of the segment */
+    int32_t n_seg;              /* segment POSITIONS, padding included (a multiple of DL_UNIT_SEGS per slice) */
+    const int32_t* seg_row;     /* [n_seg] local row of the segment, -1 = padding position */
     const int32_t* seg_beg;     /* [n_seg] first entry of the segment */
     const int32_t* seg_end;     /* [n_seg] one past its last entry */
-    const int32_t* seg_slot;    /* [n_seg] partial slot, -1 if the row has a single segment */
+    const int32_t* seg_slot;    /* [n_seg] partial slot of the segment's UNIT, -1 if the row is a single unit */
     int32_t n_slices;           /* >= 1 */
-    int32_t slice_max_seg;      /* largest number of segments in one slice (sizes the launch grid) */
-    const int32_t* slice_seg0;  /* [n_slices+1] first segment of each column slice */
-    int32_t n_multi;            /* rows with more than one segment */
-    int32_t n_slots;            /* segments belonging to such rows */
+    int32_t slice_max_seg;      /* largest number of positions in one slice stream (sizes the launch grid) */
+    const int32_t* slice_seg0;  /* [n_slices+1] first position of each slice stream (multiples of DL_UNIT_SEGS) */
+    int32_t n_multi;            /* rows with more than one unit */
+    int32_t n_slots;            /* units belonging to such rows */
     const int32_t* multi_row;   /* [n_multi] local row */
     const int32_t* multi_slot0; /* [n_multi+1] first slot of each such row (slots are consecutive) */
 } dl_csr_plan;
@@ -128,9 +138,11 @@ void dl_host_csr_free(dl_host_csr* csr);
 
 /* Segment plan of a CSR (see dl_csr_plan): segments of <= seg_len entries, never spanning two of the
  * n_col_slices column slices (1 = unsliced; a multiple of 8 = XCD streams x time), optionally only over
- * the entries with keep[e] != 0 (one contiguous run per row, e.g. col >= row for symmetric routing). */
+ * the entries with keep[e] != 0 (one contiguous run per row, e.g. col >= row for symmetric routing).
+ * unit_segs = DL_UNIT_SEGS groups the segments of a row into units (plans whose kernels sum over a row);
+ * unit_segs = 1 makes every segment its own unit, positions in entry order (routing plan, forward scorer). */
 int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, const int32_t* col, int32_t seg_len,
-                       int32_t n_col_slices, const uint8_t* keep, dl_host_plan* out);
+                       int32_t n_col_slices, const uint8_t* keep, int32_t unit_segs, dl_host_plan* out);
 void dl_host_plan_free(dl_host_plan* plan);
 
 const char* dl_version(void);

@@ -62,17 +62,23 @@ def test_ops_fail_loudly_on_cpu_tensors():
         ops.route_fwd(g, Z, 1.0)
 
 
-def _check_plan(plan, rowptr, seg_len, col_slices=None):
-    """segment plan: every row covered exactly once, in order, by segments of <= seg_len entries that
-    never span two column slices; multi-segment rows own consecutive partial slots in entry order;
-    segments are stored slice-major"""
+def _check_plan(plan, rowptr, seg_len, col_slices=None, unit_segs=None):
+    """segment plan (include/disenlink_hip.h): every row covered exactly once, in order, by segments of <= seg_len
+    entries that never span two column slices; positions are stored slice-major, a multiple of UNIT_SEGS per stream,
+    padding positions have row -1; the segments of a (row, slice) group sit, in entry order, in units of <= UNIT_SEGS
+    consecutive positions that never straddle a group of UNIT_SEGS positions, full units first; rows with more than one
+    unit own consecutive partial slots, one per unit, in entry order"""
+    from disenlink_amd.graph import UNIT_SEGS
+    unit_segs = unit_segs or UNIT_SEGS                 # 1: every segment its own unit (plans of kernels that sum nothing over a row)
     deg = np.diff(rowptr)
     col = plan.col.numpy()
     seg_row, seg_beg, seg_end = plan.seg_row.numpy(), plan.seg_beg.numpy(), plan.seg_end.numpy()
     seg_slot, sl0 = plan.seg_slot.numpy(), plan.slice_seg0.numpy()
     col_slices = col_slices or plan.n_slices          # plan.n_slices = XCD streams; col_slices = column slices
+    real = seg_row >= 0
+    assert (seg_beg[~real] == 0).all() and (seg_end[~real] == 0).all() and (seg_slot[~real] == -1).all()
     # column slices hold equal numbers of the plan's entries: boundaries at the quantiles of the covered columns
-    covered = np.concatenate([col[b:e] for b, e in zip(seg_beg, seg_end)]) if plan.n_seg else np.zeros(0, col.dtype)
+    covered = np.concatenate([col[b:e] for b, e in zip(seg_beg[real], seg_end[real])]) if real.any() else np.zeros(0, col.dtype)
     srt = np.sort(covered)
     bounds = srt[(np.arange(1, col_slices) * srt.size) // col_slices] if srt.size and col_slices > 1 else np.zeros(0, col.dtype)
     slice_of = lambda c: np.searchsorted(bounds, c, side="right")
@@ -80,36 +86,58 @@ def _check_plan(plan, rowptr, seg_len, col_slices=None):
         counts = np.bincount(slice_of(covered), minlength=col_slices)
         assert counts.max() - srt.size / col_slices <= np.unique(srt, return_counts=True)[1].max()   # balanced up to ties
     assert sl0[0] == 0 and sl0[-1] == plan.n_seg and plan.slice_max_seg == np.diff(sl0).max()
+    assert (sl0 % UNIT_SEGS == 0).all()
     by_row = {i: [] for i in range(plan.n_rows)}
+    units = []                                          # (row, [positions]) in storage order
     for x in range(plan.n_slices):
         last_q = -1
-        for sgi in range(sl0[x], sl0[x + 1]):
-            b, e = seg_beg[sgi], seg_end[sgi]
-            assert 0 <= e - b <= seg_len
-            if e > b and col_slices > 1:
-                q = slice_of(col[b])
-                assert (slice_of(col[b:e]) == q).all()            # inside one column slice ...
-                assert q % plan.n_slices == x and q >= last_q    # ... of this stream, slices in time order
-                last_q = q
-            by_row[seg_row[sgi]].append((b, e, seg_slot[sgi]))
+        for g0 in range(sl0[x], sl0[x + 1], UNIT_SEGS):
+            prev = None
+            for sgi in range(g0, g0 + UNIT_SEGS):
+                if seg_row[sgi] < 0:
+                    prev = None
+                    continue
+                b, e = seg_beg[sgi], seg_end[sgi]
+                assert 0 <= e - b <= seg_len
+                if e > b and col_slices > 1:
+                    q = slice_of(col[b])
+                    assert (slice_of(col[b:e]) == q).all()            # inside one column slice ...
+                    assert q % plan.n_slices == x and q >= last_q    # ... of this stream, slices in time order
+                    last_q = q
+                by_row[seg_row[sgi]].append((b, e, seg_slot[sgi], sgi))
+                if prev == seg_row[sgi] and unit_segs > 1:
+                    units[-1][1].append(sgi)
+                else:
+                    units.append((seg_row[sgi], [sgi]))
+                prev = seg_row[sgi]
+    # a unit: consecutive positions, consecutive entries in order, one slot
+    for row, poss in units:
+        assert len(poss) <= unit_segs and poss == list(range(poss[0], poss[0] + len(poss)))
+        assert all(seg_end[a] == seg_beg[b] for a, b in zip(poss[:-1], poss[1:]))
+        assert len({seg_slot[q] for q in poss}) == 1
     multi = []
+    n_units_row = {i: 0 for i in range(plan.n_rows)}
+    for row, _ in units:
+        n_units_row[row] += 1
     for i in range(plan.n_rows):
         segs = sorted(by_row[i])
         assert len(segs) >= 1 and segs[0][0] == rowptr[i] and segs[-1][1] == rowptr[i + 1]
         assert all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:]))          # contiguous cover
         if plan.n_slices == 1:
             assert len(segs) == max(1, -(-deg[i] // seg_len))
-        if len(segs) > 1:
+            assert n_units_row[i] == -(-len(segs) // unit_segs)                 # units counted from the row's first segment
+        slots = [sg[2] for sg in segs]
+        if n_units_row[i] > 1:
             multi.append(i)
-            slots = [sg[2] for sg in segs]
-            assert slots == list(range(slots[0], slots[0] + len(segs)))
+            assert slots[0] >= 0 and all(b - a in (0, 1) for a, b in zip(slots[:-1], slots[1:]))   # entry order
+            assert slots[-1] - slots[0] + 1 == n_units_row[i]
         else:
-            assert segs[0][2] == -1
+            assert set(slots) == {-1}
     assert np.array_equal(plan.multi_row.numpy(), np.array(multi, dtype=np.int32))
     slot0 = plan.multi_slot0.numpy()
     assert slot0[0] == 0 and slot0[-1] == plan.n_slots
     for m, i in enumerate(multi):
-        assert sorted(by_row[i])[0][2] == slot0[m] and slot0[m + 1] - slot0[m] == len(by_row[i])
+        assert sorted(by_row[i])[0][2] == slot0[m] and slot0[m + 1] - slot0[m] == n_units_row[i]
 
 
 @pytest.mark.parametrize("name", golden_case_names())
@@ -129,11 +157,12 @@ def test_graph_builder_matches_oracle_csr(name):
         src = np.repeat(np.arange(G.n_nodes), np.diff(rowptr))
         cover = np.zeros(col.size, int)
         for r_, b_, e_ in zip(up.seg_row.numpy(), up.seg_beg.numpy(), up.seg_end.numpy()):
+            if r_ < 0:
+                continue                                                            # padding position
             assert 0 <= e_ - b_ <= seg_len and (src[b_:e_] == r_).all()
             cover[b_:e_] += 1
         assert np.array_equal(cover, (col >= src).astype(int))
-        assert sorted(up.seg_row.numpy().tolist()) == sorted(set(up.seg_row.numpy().tolist()) | set(range(G.n_nodes)))[:0] \
-            or set(up.seg_row.numpy().tolist()) == set(range(G.n_nodes))            # every row owns >= 1 segment
+        assert set(up.seg_row.numpy().tolist()) - {-1} == set(range(G.n_nodes))    # every row owns >= 1 segment
         # a shard keeps global column ids and re-bases rowptr
         lo, hi = G.n_nodes // 3, G.n_nodes - 2
         nz = np.nonzero(g["adj"])
@@ -168,7 +197,7 @@ def test_graph_from_edge_rows_symmetrises_and_collapses_duplicates():
     with pytest.raises(ValueError, match="outside"):
         Graph.from_edge_rows(torch.tensor([0]), torch.tensor([7]), 5)
     empty = Graph.from_edge_rows(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 4)
-    assert empty.n_edges == 0 and empty.n_seg == 4 and empty.rowptr.tolist() == [0] * 5
+    assert empty.n_edges == 0 and empty.n_seg == 4 and empty.rowptr.tolist() == [0] * 5     # four empty segments: one workgroup
     assert empty.plan.n_slots == 0 and empty.plan.multi_row.numel() == 0
 
 
@@ -197,7 +226,7 @@ def test_pair_incidence_lists_every_slot_once():
     for u in range(n):
         for q, v in zip(uid[uptr[u]:uptr[u + 1]], ucol[uptr[u]:uptr[u + 1]]):
             assert pu[q] == u and pv[q] == v
-    _check_plan(pl.by_u, uptr, 4)
+    _check_plan(pl.by_u, uptr, 4, unit_segs=1)
     assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 8
     from disenlink_amd.graph import auto_slices
     assert auto_slices(5201, 2048, 200) == 8 and auto_slices(2_900_000, 2048, 24) == 1
@@ -257,13 +286,14 @@ def test_c_abi_host_graph_prep_matches_python_builders(seed):
         assert np.array_equal(rowptr, G.rowptr.numpy()) and np.array_equal(col, G.col.numpy())
         assert np.array_equal(_host_arr(hc.rev, hc.n_entries), G.rev.numpy())
         row_of = np.repeat(np.arange(n), np.diff(rowptr))
-        cases = [(8, 1, None, G.plan), (8, 8, None, CsrPlan.build(G.rowptr, G.col, n, seg_len=8, n_slices=8)),
-                 (5, 24, None, CsrPlan.build(G.rowptr, G.col, n, seg_len=5, n_slices=24)),
-                 (8, 1, (col >= row_of).astype(np.uint8), G.route)]
-        for seg_len, slices, keep, ref in cases:
+        cases = [(8, 1, None, 4, G.plan), (8, 8, None, 4, CsrPlan.build(G.rowptr, G.col, n, seg_len=8, n_slices=8)),
+                 (5, 24, None, 4, CsrPlan.build(G.rowptr, G.col, n, seg_len=5, n_slices=24)),
+                 (3, 8, None, 1, CsrPlan.build(G.rowptr, G.col, n, seg_len=3, n_slices=8, unit_segs=1)),
+                 (8, 1, (col >= row_of).astype(np.uint8), 1, G.route)]
+        for seg_len, slices, keep, unit_segs, ref in cases:
             hp = _lib.DlHostPlan()
             kp = keep.ctypes.data if keep is not None else None
-            rc = lib.dl_host_plan_build(n, n, rowptr.ctypes.data, col.ctypes.data, seg_len, slices, kp, C.byref(hp))
+            rc = lib.dl_host_plan_build(n, n, rowptr.ctypes.data, col.ctypes.data, seg_len, slices, kp, unit_segs, C.byref(hp))
             assert rc == 0, lib.dl_last_error()
             try:
                 got = (hp.n_seg, hp.n_slices, hp.slice_max_seg, hp.n_multi, hp.n_slots)
@@ -299,16 +329,25 @@ def test_module_copies_and_pickles_without_its_caches():
 
 
 def test_bench_pmc_table_covers_every_phase_kernel():
-    """bench.py prices each timed phase with the PMC traffic of its kernels (profiles/pmc_traffic_latest.json, keyed by
-    the kernel names rocprofv3 reports): a renamed kernel must come with regenerated counters, or `traffic` silently
-    turns into null."""
+    """bench.py prices each timed phase with the PMC traffic of its kernels (profiles/pmc_traffic_latest.json: one entry
+    per workload, kernels keyed by the names rocprofv3 reports, tagged with the hash of the kernel sources it was
+    collected for).  Every entry must cover every phase; a summary collected for OTHER kernel sources must come back
+    as None with the reason, never as numbers."""
     import importlib.util
     import json
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     table = json.load(open(bench.PMC_SUMMARY))
-    for phase, names in bench.PHASE_KERNEL.items():
-        for name in names:
-            assert name in table and table[name]["traffic_bytes"] > 0, (phase, name)
-        assert bench.pmc_traffic(phase) > 0
+    assert table, "no PMC passes committed"
+    for key, entry in table.items():
+        assert len(entry["kernel_source_hash"]) == 16 and "rocprofv3" in entry["source"], key
+        bases = {k.split("<")[0].split("::")[-1]: v for k, v in entry["kernels"].items()}
+        for phase, names in bench.PHASE_KERNELS.items():
+            assert any(n in bases and bases[n]["traffic_bytes"] > 0 for n in names), (key, phase)
+        got, why = bench.pmc_traffic(key)
+        if entry["kernel_source_hash"] == bench.kernel_source_hash():
+            assert set(got) == set(bench.PHASE_KERNELS) and all(v > 0 for v in got.values())
+        else:
+            assert got is None and entry["kernel_source_hash"] in why
+    assert bench.pmc_traffic("no_such_workload")[0] is None

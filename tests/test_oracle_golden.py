@@ -129,6 +129,32 @@ def test_c_restatement_matches_numpy_oracle_and_reference(golden):
     np.testing.assert_allclose(prob, g["link_pred"], rtol=1e-5, atol=2e-6)
 
 
+def test_c_restatement_backward_matches_numpy_oracle(golden):
+    """The gather-form backward of oracle/c/sparse_ref.c (used for parity at the full benchmark sizes) against the numpy
+    oracle's scatter form, which test_sparse_backward_matches_reference_gradients pins to the reference's autograd."""
+    from oracle import c_ref
+    g, m = golden, golden["meta"]
+    Z = _Z_nkd(g)
+    N, K, d = Z.shape
+    rng = np.random.default_rng(N * 131 + K)
+    rowptr, col, rev = sparse_ref.csr_from_dense(g["adj"])
+    H, p, a, s_raw = sparse_ref.forward(Z, rowptr, col, m["beta"], m["t"])
+    P = 4 * N
+    pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
+    pu[:3], pv[:3] = pv[:3], pv[:3]                                   # a few self pairs
+    gp = (rng.standard_normal(P) * 0.3).astype(np.float32)
+    prob = sparse_ref.score_pairs(Z, H, pu, pv, m["t"])
+    dZs_n, dH_n = sparse_ref.score_pairs_bwd(Z, H, pu, pv, m["t"], gp)
+    dZs_c, dH_c = c_ref.score_pairs_bwd(Z, H, pu, pv, m["t"], prob, gp)
+    tol = lambda ref: 2e-5 * max(np.abs(ref).max(), 1e-6)
+    assert np.abs(dH_c - dH_n).max() <= tol(dH_n)
+    assert np.abs(dZs_c - dZs_n).max() <= tol(dZs_n)
+    dH_in = (dH_n + rng.standard_normal(dH_n.shape).astype(np.float32) * 0.1).astype(np.float32)
+    dZ_n = sparse_ref.route_aggregate_bwd(Z, rowptr, col, rev, p, a, s_raw, m["beta"], m["t"], dH_in)
+    dZ_c = c_ref.route_aggregate_bwd(Z, rowptr, col, p, a, s_raw, m["beta"], m["t"], dH_in)
+    assert np.abs(dZ_c - dZ_n).max() <= tol(dZ_n)
+
+
 @pytest.mark.parametrize("name", __import__("conftest").trajectory_names())
 def test_oracle_follows_the_reference_training_trajectory(name):
     """tests/golden/traj_*.npz: the reference model under the reference's schedule (Adam, weight decay 5e-4,

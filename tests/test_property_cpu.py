@@ -48,7 +48,7 @@ def test_graph_and_plans_on_random_edge_rows(rows, seg_len, n_slices):
         hp = _lib.DlHostPlan()
         rp32, c32 = rowptr.astype(np.int32), col.astype(np.int32)
         assert lib.dl_host_plan_build(n, n, rp32.ctypes.data, c32.ctypes.data if col.size else None, seg_len, n_slices,
-                                      None, C.byref(hp)) == 0, lib.dl_last_error()
+                                      None, 4, C.byref(hp)) == 0, lib.dl_last_error()
         try:
             for name, cnt in (("seg_row", hp.n_seg), ("seg_beg", hp.n_seg), ("seg_end", hp.n_seg), ("seg_slot", hp.n_seg)):
                 assert np.array_equal(_host_arr(getattr(hp, name), cnt), getattr(sliced, name).numpy()), name
@@ -66,7 +66,7 @@ def test_pair_plans_on_random_pairs(n, P, seed):
     pu, pv = rng.integers(0, n, P), rng.integers(0, n, P)
     pl = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=5, run_len=7, n_slices=8)
     assert pl.by_u.n_entries == P and pl.inc.n_entries == 2 * P
-    _check_plan(pl.by_u, pl.by_u.rowptr.numpy(), 7)
+    _check_plan(pl.by_u, pl.by_u.rowptr.numpy(), 7, unit_segs=1)
     _check_plan(pl.inc, pl.inc.rowptr.numpy(), 5)
     ids = pl.by_u_pair.numpy()
     assert sorted(ids.tolist()) == list(range(P))
