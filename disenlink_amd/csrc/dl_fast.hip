@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void vec_combine_kernel(dl_csr_plan g, int K
 // segment costs ceil(entries / (U * EPW)) memory round trips instead of one per EPW entries (the kernel is latency-bound:
 // 369k edges on 256 CUs).  The per-group summation order is unchanged (entries grp, grp + EPW, ... ascending).
 template <int K, int D, typename T, int U>
-__global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
+__global__ __launch_bounds__(BLOCK, (K * Tab<T>::VEC <= 32 && U <= 2) ? 8 : 1) void aggregate_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
                                                               const uint8_t* __restrict__ p,
                                                               const float* __restrict__ a,
                                                               const float* __restrict__ s, T* __restrict__ H,
@@ -361,13 +361,6 @@ __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, con
     const SegInfo si = ws.si;
     const int lane = lane_id();
     const int c = lane % G, grp = lane / G;
-    // the row's own z (for h = b z + (1-b) sum) is fetched by the wave that will write h, before anything depends on it
-    float4 zrow[US::NQ];
-    if (ws.head && si.slot < 0) {
-#pragma unroll
-        for (int q = 0; q < US::NQ; ++q)
-            if (q * DL_WAVE + lane < US::F4) zrow[q] = load4<T>(Z + (size_t)si.grow * ROW + 4 * (q * DL_WAVE + lane));
-    }
     if (ws.active) {
         Chunk<VEC> acc[K];
 #pragma unroll
@@ -419,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void aggregate_seg_kernel(dl_csr_plan g, con
         if (x < US::F4) {
             if (si.slot < 0) {
                 const size_t o = (size_t)si.grow * ROW + 4 * x;
-                const float4 z = zrow[q];
+                const float4 z = load4<T>(Z + o);
                 store4(H + o, make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
                                           beta * z.w + omb * r[q].w));
             } else {
@@ -1059,7 +1052,7 @@ struct Ops {
 
     static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
                              const float* s, void* H, float* h_part, hipStream_t st) {
-        const int unroll = getenv("DL_AGG_UNROLL") ? atoi(getenv("DL_AGG_UNROLL")) : 4;      // experiments
+        const int unroll = getenv("DL_AGG_UNROLL") ? atoi(getenv("DL_AGG_UNROLL")) : 2;      // experiments
         if (unroll >= 8)
             hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 8>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
                                beta, p, a, s, (T*)H, h_part);

@@ -2,16 +2,20 @@
 backend "nccl" == RCCL on ROCm).  The reference is single-process; this is the
 MI355X design of SURVEY.md §8(e).
 
-Partition: nodes are cut into ``world`` equal contiguous blocks (padded with isolated nodes so the
-blocks are equal, which keeps every collective a plain all-gather).  Rank r owns the CSR rows, the
-incidence rows and the feature rows of its block and a replica of the MLP weights.  Everything is
-"owner computes": each rank produces only rows of its own nodes, gathering what it needs from
-neighbours' rows, so there is no reduce-scatter and no float atomics anywhere.
+Partition.  Nodes are cut into ``world`` CONTIGUOUS blocks balanced by work, not by node count (squirrel: median degree
+17, maximum 1,904): the cut points are the quantiles of the per-node weight "edge rows touching the node + 1"
+(:func:`balanced_cuts`).  Every block is padded with isolated nodes to the size B of the largest one, so that every
+collective stays a plain equal-size all-gather; node ids are relabelled into that padded space (rank r owns
+[r B, (r+1) B), real rows first).  Rank r owns the CSR rows, the incidence rows and the feature rows of its block and a
+replica of the MLP weights.  Everything is "owner computes": each rank produces only rows of its own nodes, gathering
+what it needs from neighbours' rows, so there is no reduce-scatter and no float atomics anywhere.
 
   forward   Z_loc = MLP(x_loc)            -> all-gather Z   [N,K,d]
             route on local rows           -> all-gather s   [N,K]     (normaliser of the NEIGHBOUR, model.py:73)
-            aggregate on local rows       -> all-gather H   [N,K,d]   (before scoring, BASELINE.json north_star)
-            score the local slice of the pair list
+            aggregate on local rows       -> all-gather H   [N,K,d]   (before scoring, BASELINE.json north_star),
+                                             in C row chunks, asynchronously: pairs whose second endpoint is local are
+                                             scored at once, pairs whose second endpoint lies in chunk c as soon as
+                                             chunk c has landed — the scorer runs under the rest of the gather
   backward  all-gather (prob, g_prob)     [P]   (8 B per pair)
             scorer backward on local incidence rows -> dH_loc, dZ_loc
             all-gather dH [N,K,d]; phase 1 on local rows -> all-gather ds [N,K]; phase 2 -> dZ_loc
@@ -23,14 +27,17 @@ HIP backend and there is no fallback.
 """
 from __future__ import annotations
 
+import os
 import time
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from .graph import Graph, PairList
+
+DEFAULT_CHUNKS = int(os.environ.get("DL_GATHER_CHUNKS", "4"))
 
 
 # --------------------------------------------------------------------------- partition
@@ -43,17 +50,81 @@ def padded_nodes(n_nodes: int, world: int) -> int:
 
 
 def row_range(n_nodes: int, world: int, rank: int) -> tuple[int, int]:
-    """Rows of rank `rank` in the PADDED node space [0, padded_nodes)."""
+    """Rows of rank `rank` in the padded node space of EQUAL node blocks (balance="nodes")."""
     b = block_size(n_nodes, world)
     return rank * b, (rank + 1) * b
 
 
 def pair_slices(pu_sorted: np.ndarray, n_nodes: int, world: int):
-    """Pairs (sorted by u) are scored by the owner of u: contiguous slices of the list."""
+    """Pairs (sorted by u) are scored by the owner of u: contiguous slices of the list (equal node blocks)."""
     b = block_size(n_nodes, world)
     cuts = np.searchsorted(pu_sorted, np.arange(world + 1) * b, side="left")
     cuts[-1] = pu_sorted.size
     return cuts
+
+
+def balanced_cuts(weight: np.ndarray, world: int) -> np.ndarray:
+    """Cut points [world + 1] of contiguous node blocks of (nearly) equal total weight: block r = [cuts[r], cuts[r+1]).
+    A node goes to the block in which the MIDPOINT of its weight interval falls, so a hub heavier than a whole share
+    takes a block of its own instead of dragging its neighbours along."""
+    w = np.asarray(weight, dtype=np.float64)
+    n = w.size
+    if n == 0:
+        return np.zeros(world + 1, dtype=np.int64)
+    csum = np.cumsum(w)
+    mid = csum - 0.5 * w
+    owner = np.minimum((mid * world / csum[-1]).astype(np.int64), world - 1)
+    owner = np.maximum.accumulate(owner)                     # monotone by construction; guard against rounding
+    cuts = np.searchsorted(owner, np.arange(world + 1), side="left")
+    cuts[-1] = n
+    return cuts.astype(np.int64)
+
+
+@dataclass
+class Partition:
+    """Relabelling of the n real nodes into `world` padded blocks of `block` ids each."""
+    world: int
+    n_nodes: int
+    cuts: np.ndarray          # [world+1] real-node cut points
+    block: int                # B: ids per rank in the padded space (a multiple of n_chunks)
+    n_chunks: int
+
+    @property
+    def n_pad(self) -> int:
+        return self.block * self.world
+
+    @property
+    def chunk_rows(self) -> int:
+        return self.block // self.n_chunks
+
+    def to_padded(self, ids) -> np.ndarray:
+        ids = np.asarray(ids, dtype=np.int64)
+        owner = np.searchsorted(self.cuts, ids, side="right") - 1
+        return owner * self.block + (ids - self.cuts[owner])
+
+    def real_rows(self, rank: int) -> tuple[int, int]:
+        return int(self.cuts[rank]), int(self.cuts[rank + 1])
+
+    @staticmethod
+    def build(n_nodes: int, world: int, edge_src=None, edge_dst=None, balance: str = "nnz",
+              n_chunks: int = 1) -> "Partition":
+        if balance == "nodes" or edge_src is None:
+            b = block_size(n_nodes, world)
+            cuts = np.minimum(np.arange(world + 1, dtype=np.int64) * b, n_nodes)
+        elif balance == "nnz":
+            w = (np.bincount(np.asarray(edge_src, dtype=np.int64), minlength=n_nodes)
+                 + np.bincount(np.asarray(edge_dst, dtype=np.int64), minlength=n_nodes) + 1)
+            cuts = balanced_cuts(w, world)
+        else:
+            raise ValueError("balance must be 'nnz' or 'nodes'")
+        rows = int(np.max(np.diff(cuts))) if n_nodes else 0
+        block = max(1, -(-max(rows, 1) // n_chunks)) * n_chunks
+        return Partition(world, n_nodes, cuts, block, n_chunks)
+
+
+# --------------------------------------------------------------------------- collectives
+def _gloo_on_device(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"          # one-GPU rehearsal: gloo moves host memory
 
 
 def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None, src: torch.Tensor | None = None) -> None:
@@ -61,12 +132,54 @@ def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None, src: torch
     send buffer never aliases the receive buffer: `src` if the caller still holds the local rows elsewhere,
     else a copy of full[lo:hi] (a few microseconds against a collective of 8x the bytes)."""
     local = src if src is not None else full[lo:hi].clone()
-    if full.is_cuda and dist.get_backend(group) == "gloo":          # one-GPU rehearsal: gloo moves host memory
+    if _gloo_on_device(full, group):
         host = torch.empty(full.shape, dtype=full.dtype)
         dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
         full.copy_(host)
         return
     dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+
+
+class ChunkedRowGather:
+    """All-gather of a node table in C row chunks, asynchronously: chunk c = rows [c Bc, (c+1) Bc) of EVERY rank's
+    block.  `start` enqueues all C collectives (each into the views of `full` the chunk belongs to; the own block is
+    already in place and is not rewritten — its slot goes to a scratch buffer); `wait(c)` makes the current stream wait
+    for chunk c only, so kernels that need chunk c run under the transfer of chunks c+1 .."""
+
+    def __init__(self, full: torch.Tensor, part: Partition, rank: int, group=None):
+        self.full, self.part, self.rank, self.group = full, part, rank, group
+        self.works, self._keep = [], []
+
+    def start(self):
+        B, Bc, W = self.part.block, self.part.chunk_rows, self.part.world
+        full = self.full
+        host_path = _gloo_on_device(full, self.group)
+        for c in range(self.part.n_chunks):
+            send = full[self.rank * B + c * Bc: self.rank * B + (c + 1) * Bc].clone()
+            if host_path:
+                outs = [torch.empty(send.shape, dtype=send.dtype) for _ in range(W)]
+                work = dist.all_gather(outs, send.cpu(), group=self.group, async_op=True)
+                self._keep.append((send, outs))
+            else:
+                scratch = torch.empty_like(send)
+                outs = [scratch if q == self.rank else full[q * B + c * Bc: q * B + (c + 1) * Bc] for q in range(W)]
+                work = dist.all_gather(outs, send, group=self.group, async_op=True)
+                self._keep.append((send, scratch))
+            self.works.append(work)
+        return self
+
+    def wait(self, c: int):
+        self.works[c].wait()
+        if _gloo_on_device(self.full, self.group):
+            B, Bc = self.part.block, self.part.chunk_rows
+            for q, o in enumerate(self._keep[c][1]):
+                if q != self.rank:
+                    self.full[q * B + c * Bc: q * B + (c + 1) * Bc].copy_(o)
+
+    def wait_all(self):
+        for c in range(len(self.works)):
+            self.wait(c)
+        self._keep.clear()
 
 
 # --------------------------------------------------------------------------- backends
@@ -113,37 +226,61 @@ class Shard:
     n_pad: int              # padded node count (extent of node-indexed arrays)
     lo: int                 # first local row (padded space)
     hi: int
-    graph: Graph            # local rows of adj_sym, global columns
-    pairs: PairList         # local slice of the pair list (forward)
+    graph: Graph            # local rows of adj_sym, global (padded-space) columns
+    pairs: PairList         # local slice of the pair list (forward), in list order
     inc: PairList           # incidence rows of local nodes over the WHOLE pair list (backward)
     pair_lo: int            # position of the local slice in the global pair list
     pair_hi: int
     n_pairs_total: int
     pair_block: int         # padded per-rank pair count used by the (prob, g_prob) all-gather
     pair_cuts: np.ndarray
+    part: Partition | None = None
+    # forward scoring in gather order: [(positions in the local slice, PairList)], first the pairs whose second endpoint
+    # is local, then one list per row chunk of the H all-gather (second endpoint remote, in that chunk)
+    pair_groups: list = field(default_factory=list)
 
     @staticmethod
     def build(rank: int, world: int, n_nodes: int, edge_src, edge_dst, pu, pv, device,
-              seg_len: int = 32, row_bytes: int = 2048) -> "Shard":
-        """edge rows = TRAIN edge rows (directed, duplicates ok); pu/pv = the global pair list, sorted by pu."""
+              seg_len: int = 32, row_bytes: int = 2048, balance: str = "nnz", n_chunks: int = 1,
+              with_backward: bool = True) -> "Shard":
+        """edge rows = TRAIN edge rows (directed, duplicates ok); pu/pv = the global pair list, sorted by pu.
+        balance: "nnz" (blocks of equal work) or "nodes" (equal node counts); n_chunks: row chunks of the asynchronous
+        H all-gather (1 = one blocking all-gather before scoring)."""
         pu = np.asarray(pu, dtype=np.int64)
         pv = np.asarray(pv, dtype=np.int64)
         if pu.size and np.any(np.diff(pu) < 0):
             raise ValueError("the pair list must be sorted by pu (pairs are scored by the owner of u)")
-        n_pad = padded_nodes(n_nodes, world)
-        lo, hi = row_range(n_nodes, world, rank)
-        ts = torch.as_tensor(np.asarray(edge_src), device=device)
-        td = torch.as_tensor(np.asarray(edge_dst), device=device)
+        edge_src, edge_dst = np.asarray(edge_src, dtype=np.int64), np.asarray(edge_dst, dtype=np.int64)
+        part = Partition.build(n_nodes, world, edge_src, edge_dst, balance=balance, n_chunks=max(1, n_chunks))
+        B, n_pad = part.block, part.n_pad
+        lo, hi = rank * B, (rank + 1) * B
+        ts = torch.as_tensor(part.to_padded(edge_src), device=device)
+        td = torch.as_tensor(part.to_padded(edge_dst), device=device)
         graph = Graph.from_edge_rows(ts, td, n_pad, symmetrise=True, seg_len=seg_len, row_range=(lo, hi),
                                      row_bytes=row_bytes)
-        cuts = pair_slices(pu, n_nodes, world)
+        ppu, ppv = part.to_padded(pu), part.to_padded(pv)             # order-preserving: still sorted by u
+        cuts = np.searchsorted(ppu, np.arange(world + 1) * B, side="left")
+        cuts[-1] = ppu.size
         q0, q1 = int(cuts[rank]), int(cuts[rank + 1])
-        tpu, tpv = torch.as_tensor(pu, device=device), torch.as_tensor(pv, device=device)
+        tpu, tpv = torch.as_tensor(ppu, device=device), torch.as_tensor(ppv, device=device)
         pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, row_range=(lo, lo), by_u_range=(lo, hi),
                                row_bytes=row_bytes)
-        inc = _incidence_only(tpu, tpv, n_pad, lo, hi, row_bytes)
+        groups = []
+        if part.n_chunks > 1 and world > 1:
+            lv = ppv[q0:q1]
+            owner = lv // B
+            chunk = (lv % B) // part.chunk_rows
+            sel = [np.flatnonzero(owner == rank)] + [np.flatnonzero((owner != rank) & (chunk == c))
+                                                     for c in range(part.n_chunks)]
+            for idx in sel:
+                ti = torch.as_tensor(idx, device=device)
+                sub = PairList.build(tpu[q0:q1][ti], tpv[q0:q1][ti], n_pad, row_range=(lo, lo), by_u_range=(lo, hi),
+                                     row_bytes=row_bytes) if idx.size else None
+                groups.append((ti, sub))
+        inc = _incidence_only(tpu, tpv, n_pad, lo, hi, row_bytes) if with_backward else None
         block = int(np.max(np.diff(cuts))) if pu.size else 0
-        return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts)
+        return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts,
+                     part, groups)
 
     def pad_rows(self, x_local_real: torch.Tensor) -> torch.Tensor:
         """Feature rows of this rank's block, zero rows for padding nodes."""
@@ -155,7 +292,29 @@ class Shard:
         return out
 
     def local_real_rows(self) -> tuple[int, int]:
-        return min(self.lo, self.n_nodes), min(self.hi, self.n_nodes)
+        """Real node ids [r0, r1) owned by this rank (their rows are the first r1 - r0 of its padded block)."""
+        return self.part.real_rows(self.rank)
+
+    def work(self) -> dict:
+        return dict(rows=self.local_real_rows()[1] - self.local_real_rows()[0], nnz=self.graph.n_edges,
+                    pairs=self.pairs.n_pairs)
+
+
+def score_local_pairs(backend, shard: Shard, Z, H, t, gather: "ChunkedRowGather | None"):
+    """Probabilities of the local pair slice, in list order.  With a chunked gather in flight the pair groups are scored
+    in arrival order (local second endpoints first), each under the transfer of the chunks behind it."""
+    if gather is None or not shard.pair_groups:
+        if gather is not None:
+            gather.wait_all()
+        return backend.score_pairs_fwd(Z, H, shard.pairs, t)
+    prob = torch.empty(shard.pairs.n_pairs, dtype=torch.float32, device=Z.device)
+    for gi, (idx, sub) in enumerate(shard.pair_groups):
+        if gi >= 1:
+            gather.wait(gi - 1)
+        if sub is not None:
+            prob.index_copy_(0, idx, backend.score_pairs_fwd(Z, H, sub, t))
+    gather.wait_all()
+    return prob
 
 
 # --------------------------------------------------------------------------- autograd over the shard
@@ -174,8 +333,11 @@ class ShardedHotPath(torch.autograd.Function):
         all_gather_rows(s, sh.lo, sh.hi, group)
         H = torch.empty_like(Z)
         backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
-        all_gather_rows(H, sh.lo, sh.hi, group)
-        prob = backend.score_pairs_fwd(Z, H, sh.pairs, t)
+        if sh.pair_groups:
+            prob = score_local_pairs(backend, sh, Z, H, t, ChunkedRowGather(H, sh.part, sh.rank, group).start())
+        else:
+            all_gather_rows(H, sh.lo, sh.hi, group)
+            prob = backend.score_pairs_fwd(Z, H, sh.pairs, t)
         ctx.shard, ctx.backend, ctx.beta, ctx.t, ctx.group = sh, backend, beta, t, group
         ctx.save_for_backward(Z, H, s, a, prob)
         ctx.p = p
@@ -212,7 +374,8 @@ class ShardedHotPath(torch.autograd.Function):
 
 
 def sharded_forward(model, x_local: torch.Tensor, shard: Shard, backend=None, group=None):
-    """(emb_local [rows,K*d], prob_local [local pairs]) of the drop-in module on this rank's shard."""
+    """(emb_local [rows,K*d], prob_local [local pairs]) of the drop-in module on this rank's shard; the first
+    r1 - r0 rows of emb_local are the real nodes shard.local_real_rows()."""
     backend = backend or HipBackend()
     Z_loc = model.project(shard.pad_rows(x_local))
     H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group)
@@ -228,120 +391,177 @@ def allreduce_gradients(model, group=None) -> None:
 
 
 # --------------------------------------------------------------------------- bench (bench.py --gpus N)
-def bench_sharded(args, rank: int, world: int, device) -> dict:
-    """Weak scaling: the graph grows with the GPU count (N = world x the 1-GPU node count, same degree
-    law), each rank owns one block of rows.  One step = all-gather Z, route, all-gather s, aggregate,
-    all-gather H, score the local pairs; value = (E_sym + P over all ranks) / max-over-ranks time."""
-    from . import _lib
+def _bench_problem(args, world_for_scale: int):
     from .data import synthetic_graph
-    from .model import Disentangle
     from .splits import make_link_split
-    lib = _lib.load()
-    K, d, beta, t = args.K, args.d, 0.5, 1.0
-    # DL_EMULATE_WORLD=8 on one GPU: build rank 0's shard of the 8-GPU problem and time its compute alone
-    # (the collectives degenerate to no-ops) — a rehearsal of the per-rank work, not a scaling number.
-    import os
-    emu = int(os.environ.get("DL_EMULATE_WORLD", "0"))
-    if emu > 1 and world == 1:
-        return _bench_emulated(args, emu, device)
-    sg = synthetic_graph(args.workload, seed=0, scale=args.scale * world)
+    scale = args.scale * (world_for_scale if args.scaling == "weak" else 1)
+    sg = synthetic_graph(args.workload, seed=0, scale=scale)
     split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
     order = np.lexsort((pv, pu))
-    pu, pv = pu[order], pv[order]
-    shard = Shard.build(rank, world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device, row_bytes=K * d * 4)
+    return sg, split, pu[order], pv[order], scale
+
+
+def bench_sharded(args, rank: int, world: int, device) -> dict:
+    """One step = all-gather Z, route, all-gather s, aggregate, all-gather H (chunked, asynchronous), score the local pairs
+    under it; value = (E_sym + P over all ranks) / max-over-ranks time.  --scaling weak: the graph grows with the GPU
+    count (scale x world, same degree law); strong: the same graph on every GPU count.  --dtype bf16: the gathered Z / H
+    tables — and the bytes of their all-gathers — are bf16, arithmetic fp32."""
+    from . import _lib
+    from .model import Disentangle
+    lib = _lib.load()
+    K, d, beta, t = args.K, args.d, 0.5, 1.0
+    # DL_EMULATE_WORLD=8 on one GPU: build rank 0's shard of the 8-GPU problem and time its compute alone
+    # (the collectives degenerate to no-ops) — a rehearsal of the per-rank work, not a scaling number.
+    emu = int(os.environ.get("DL_EMULATE_WORLD", "0"))
+    if emu > 1 and world == 1:
+        return _bench_emulated(args, emu, device)
+    tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    wb = 2 if args.dtype == "bf16" else 4
+    sg, split, pu, pv, scale = _bench_problem(args, world)
+    shard = Shard.build(rank, world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device, row_bytes=K * d * wb,
+                        n_chunks=DEFAULT_CHUNKS, with_backward=False)
     torch.manual_seed(0)
     model = Disentangle(sg.n_feat, args.nhidden, d, nfactor=K, beta=beta, t=1).to(device)
     r0, r1 = shard.local_real_rows()
     x_loc = torch.from_numpy(sg.features()[r0:r1]).to(device)
     backend = HipBackend()
     with torch.no_grad():
-        Z_loc = model.project(shard.pad_rows(x_loc)).contiguous()
+        Z_loc = model.project(shard.pad_rows(x_loc)).contiguous().to(tab)
 
-    Z = torch.empty((shard.n_pad, K, d), dtype=torch.float32, device=device)
+    Z = torch.empty((shard.n_pad, K, d), dtype=tab, device=device)
     s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
     H = torch.empty_like(Z)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
 
-    def step():
+    def step(timers=None):
+        e = [ev() for _ in range(8)] if timers is not None else None
+        rec = (lambda i: e[i].record()) if e else (lambda i: None)
+        rec(0)
         all_gather_rows(Z, shard.lo, shard.hi, src=Z_loc)
+        rec(1)
         p, a = backend.route_fwd(shard.graph, Z, t, s)
+        rec(2)
         all_gather_rows(s, shard.lo, shard.hi)
+        rec(3)
         backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
-        all_gather_rows(H, shard.lo, shard.hi)
-        return backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        rec(4)
+        gather = ChunkedRowGather(H, shard.part, shard.rank).start() if shard.pair_groups else None
+        if gather is None:
+            all_gather_rows(H, shard.lo, shard.hi)
+        rec(5)
+        prob = score_local_pairs(backend, shard, Z, H, t, gather) if gather is not None else \
+            backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        rec(6)
+        if timers is not None:
+            timers.append(e)
+        return prob
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        blocks.append(time.perf_counter() - t0)
     red_dev = "cpu" if dist.get_backend() == "gloo" else device
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)                          # per block: the slowest rank
+    wall_s = float(wall.median())
     counts = torch.tensor([shard.graph.n_edges, shard.pairs.n_pairs], dtype=torch.int64, device=red_dev)
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    E, P = int(counts[0]), int(counts[1])
-    wall_s = float(wall[0])
-    # roofline of the dominant kernel on THIS rank's shard: HIP events on the launch stream, kernels only
-    # (the collectives are left out of this loop; every rank runs it so nobody waits at the teardown barrier)
-    reps = max(5, min(args.steps, 50))
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
-    for i in range(reps):
-        ev[i][0].record()
-        p, a = backend.route_fwd(shard.graph, Z, t, s)
-        ev[i][1].record()
-        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
-        ev[i][2].record()
-        backend.score_pairs_fwd(Z, H, shard.pairs, t)
-        ev[i][3].record()
+    per_rank = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(per_rank, counts)
+    E, P = int(sum(int(c[0]) for c in per_rank)), int(sum(int(c[1]) for c in per_rank))
+    # where a step goes on THIS rank: HIP events on the launch stream around every collective and every kernel phase
+    # (the scoring phase runs under the chunked H gather: "score" is the span from the first scoring launch to the last
+    # chunk's arrival, "h_gather_exposed" what the gather adds before it)
+    timers = []
+    for _ in range(min(args.steps, 10)):
+        step(timers)
     torch.cuda.synchronize()
-    kt = [float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(reps)])) * 1e-3 for j in range(3)]
-    e_loc, p_loc, rows = shard.graph.n_edges, shard.pairs.n_pairs, shard.hi - shard.lo
-    kb = [e_loc * (K * d * 4 + 9) + rows * (K * d * 4 + K * 4 + 4),            # SURVEY.md §8(d), as bench.algorithmic_bytes
-          e_loc * (d * 4 + 13) + rows * (2 * K * d * 4 + K * 4 + 4),
-          p_loc * (4 * K * d * 4 + 12)]
+    span = lambda i, j: float(np.median([e[i].elapsed_time(e[j]) for e in timers]))
+    phases = dict(z_gather_ms=span(0, 1), route_ms=span(1, 2), s_gather_ms=span(2, 3), aggregate_ms=span(3, 4),
+                  h_gather_start_ms=span(4, 5), score_and_h_gather_ms=span(5, 6))
+    comm_ms = phases["z_gather_ms"] + phases["s_gather_ms"] + phases["h_gather_start_ms"]
+    # kernels alone (no collectives), for the roofline entry and the compute / exposed-communication split
+    reps = max(5, min(args.steps, 20))
+    kev = [[ev() for _ in range(4)] for _ in range(reps)]
+    for i in range(reps):
+        kev[i][0].record()
+        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        kev[i][1].record()
+        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+        kev[i][2].record()
+        backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        kev[i][3].record()
+    torch.cuda.synchronize()
+    kt = [float(np.median([kev[i][j].elapsed_time(kev[i][j + 1]) for i in range(reps)])) * 1e-3 for j in range(3)]
+    compute_ms = sum(kt) * 1e3
+    step_ms = wall_s / args.steps * 1e3
+    mine = torch.tensor([compute_ms, step_ms - compute_ms, comm_ms, phases["score_and_h_gather_ms"], kt[2] * 1e3],
+                        dtype=torch.float64, device=red_dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    import bench as _bench
+    mb = _bench.moved_bytes(shard.graph, shard.pairs, K, d, w=wb)
     j = int(np.argmax(kt))
-    roofline = {"bound": "hbm", "kernel": ("route", "aggregate", "score")[j], "achieved": kb[j] / kt[j] / 1e9,
-                "peak": 8000.0, "unit": "GB/s", "frac": kb[j] / kt[j] / 1e9 / 8000.0, "traffic": None,
-                "algorithmic_bytes": kb[j], "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
+    name = ("route", "aggregate", "score")[j]
+    table_bytes = 2 * shard.n_pad * K * d * wb
+    in_cache = table_bytes <= 128 << 20
+    peak = _bench.L2_PEAK_GBS if in_cache else _bench.HBM_PEAK_GBS
+    roofline = {"bound": "l2" if in_cache else "hbm", "kernel": name, "achieved": mb[name] / kt[j] / 1e9, "peak": peak,
+                "unit": "GB/s", "frac": mb[name] / kt[j] / 1e9 / peak, "traffic": None, "moved_bytes": mb[name],
+                "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
+    nnz = np.array([int(c[0]) for c in per_rank], dtype=np.float64)
+    gather_bytes = (world - 1) * shard.part.block * (2 * K * d * wb + K * 4)       # received per rank and step
     dist.barrier()
     return {
         "metric": "edges/sec (aggregate+score) at K=8 d=64",
         "value": (E + P) * args.steps / wall_s, "unit": "edges/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall_s / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": len(blocks),
+        "ms_per_step": step_ms, "ms_per_step_blocks": [float(b) / args.steps * 1e3 for b in wall.tolist()],
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "roofline": roofline,
-        "config": {"workload": f"{args.workload}-synthetic x{world} (seed 0): N={sg.n_nodes}, edge rows={sg.src.size}, "
-                               f"85/5/10 split, E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}; row-sharded over "
-                               f"{world} GPUs, all-gather of Z, s and H over RCCL each step; forward route+aggregate+score",
+        "per_rank": [dict(rank=r, nnz=int(per_rank[r][0]), pairs=int(per_rank[r][1]), compute_ms=float(allr[r][0]),
+                          exposed_comm_ms=float(allr[r][1]), blocking_gathers_ms=float(allr[r][2]),
+                          score_under_h_gather_ms=float(allr[r][3]), score_alone_ms=float(allr[r][4]))
+                     for r in range(world)],
+        "phases_rank0_ms": phases,
+        "partition": {"balance": "nnz", "block_rows": shard.part.block, "padded_nodes": shard.n_pad,
+                      "nnz_max_over_mean": float(nnz.max() / max(nnz.mean(), 1.0)), "h_gather_chunks": shard.part.n_chunks,
+                      "allgather_bytes_received_per_rank_per_step": int(gather_bytes)},
+        "config": {"workload": f"{args.workload}-synthetic x{scale:g} (seed 0): N={sg.n_nodes}, edge rows={sg.src.size}, "
+                               f"85/5/10 split, E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, {args.dtype} tables; "
+                               f"row-sharded over {world} GPUs by work (nnz), all-gather of Z, s and H over RCCL each step, "
+                               f"the H gather in {shard.part.n_chunks} chunks under the scorer; forward route+aggregate+score",
                    "K": K, "d": d, "n_nodes": sg.n_nodes, "E_sym": E, "P": P,
-                   "parallelism": f"row-shard x{world}", "fast_path": bool(lib.dl_has_fast_path(K, d))},
+                   "parallelism": f"row-shard x{world}", "fast_path": bool(lib.dl_has_fast_path_dtype(K, d, 1 if wb == 2 else 0))},
     }
 
 
 def _bench_emulated(args, emu_world: int, device) -> dict:
-    from .data import synthetic_graph
-    from .splits import make_link_split
+    """Rank 0's shard of the `emu_world`-GPU problem on ONE GPU, compute only: per-phase kernel times, the partition's
+    balance, and how much of the scoring can start before the H all-gather has delivered anything (pairs whose second
+    endpoint is local) or has delivered chunk c."""
     K, d, beta, t = args.K, args.d, 0.5, 1.0
-    sg = synthetic_graph(args.workload, seed=0, scale=args.scale * emu_world)
-    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
-    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
-    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
-    order = np.lexsort((pv, pu))
-    shard = Shard.build(0, emu_world, sg.n_nodes, split.train_src, split.train_dst, pu[order], pv[order], device,
-                        row_bytes=K * d * 4)
+    tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    wb = 2 if args.dtype == "bf16" else 4
+    sg, split, pu, pv, scale = _bench_problem(args, emu_world)
+    shard = Shard.build(0, emu_world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device,
+                        row_bytes=K * d * wb, n_chunks=DEFAULT_CHUNKS, with_backward=False)
     backend = HipBackend()
-    Z = torch.randn((shard.n_pad, K, d), device=device) * 0.24
+    Z = (torch.randn((shard.n_pad, K, d), device=device) * 0.24).to(tab)
     s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
     H = torch.empty_like(Z)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    acc = np.zeros(3)
+    ng = len(shard.pair_groups)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 + ng)]
+    acc = np.zeros(3 + ng)
     for it in range(args.warmup + args.steps):
         ev[0].record()
         p, a = backend.route_fwd(shard.graph, Z, t, s)
@@ -350,11 +570,24 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
         ev[2].record()
         backend.score_pairs_fwd(Z, H, shard.pairs, t)
         ev[3].record()
+        for gi, (_idx, sub) in enumerate(shard.pair_groups):
+            if sub is not None:
+                backend.score_pairs_fwd(Z, H, sub, t)
+            ev[4 + gi].record()
         torch.cuda.synchronize()
         if it >= args.warmup:
-            acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+            acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3 + ng)]
     acc /= args.steps
-    return {"emulated_world": emu_world, "rank0_edges": shard.graph.n_edges, "rank0_pairs": shard.pairs.n_pairs,
-            "n_nodes": sg.n_nodes, "table_MB": shard.n_pad * K * d * 4 / 1e6,
+    w = np.bincount(split.train_src, minlength=sg.n_nodes) + np.bincount(split.train_dst, minlength=sg.n_nodes) + 1
+    cuts = shard.part.cuts
+    share = np.array([w[cuts[r]:cuts[r + 1]].sum() for r in range(emu_world)], dtype=np.float64)
+    groups = [dict(group="second endpoint local" if gi == 0 else f"chunk {gi - 1} of the H gather",
+                   pairs=int(idx.numel()), score_us=float(acc[3 + gi] * 1e3)) for gi, (idx, _s) in enumerate(shard.pair_groups)]
+    return {"emulated_world": emu_world, "scaling": args.scaling, "dtype": args.dtype,
+            "rank0_edges": shard.graph.n_edges, "rank0_pairs": shard.pairs.n_pairs,
+            "n_nodes": sg.n_nodes, "block_rows": shard.part.block, "table_MB": shard.n_pad * K * d * wb / 1e6,
+            "work_share_max_over_mean": float(share.max() / share.mean()),
             "route_us": acc[0] * 1e3, "aggregate_us": acc[1] * 1e3, "score_us": acc[2] * 1e3,
-            "allgather_bytes_per_rank_per_step": 2 * shard.n_pad * K * d * 4 + shard.n_pad * K * 4}
+            "score_in_gather_order": groups,
+            "scored_before_any_chunk_lands": (groups[0]["pairs"] / max(1, shard.pairs.n_pairs)) if groups else 0.0,
+            "allgather_bytes_per_rank_per_step": (emu_world - 1) * shard.part.block * (2 * K * d * wb + K * 4)}

@@ -76,6 +76,7 @@ class Disentangle(nn.Module):
         self.nebed = nebed
         self.beta = beta
         self._graph_cache = None
+        self._dense_plan = ops.DensePairPlanCache()      # backward of the dense link_pred: this module's own cache
         self._stacked = {}
         self._restack()
 
@@ -172,7 +173,17 @@ class Disentangle(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_graph_cache"] = None              # holds a weak reference: not copyable / picklable, and only a cache
+        state["_dense_plan"] = ops.DensePairPlanCache()
+        state["_dense_plan"].static = self._dense_plan.static
         return state
+
+    def assume_static_loss_masks(self, static: bool = True):
+        """The caller promises that the entries of link_pred it takes a loss on are the same every step (the reference's
+        masks are built once per run, main_disentangled.py:167-190).  The backward of the dense [N,N] output then
+        validates its cached pair plan on the device instead of reading two counters back every step: no host sync at
+        all; should the promise be broken the gradients come out NaN, not wrong (ops.DensePairPlanCache)."""
+        self._dense_plan.static = bool(static)
+        return self
 
     def _graph_for(self, adj: torch.Tensor) -> Graph:
         """CSR + plans of a dense adjacency, built once per adjacency tensor: keyed on the tensor OBJECT (weak
@@ -190,7 +201,7 @@ class Disentangle(nn.Module):
         graph = adj if isinstance(adj, Graph) else self._graph_for(adj)
         Z = self.project(x)
         H = ops.RouteAggregate.apply(Z, graph, float(self.beta), float(self.temperature))
-        link_pred = ops.ScoreAllPairs.apply(Z, H, float(self.temperature))
+        link_pred = ops.ScoreAllPairs.apply(Z, H, float(self.temperature), self._dense_plan)
         return H.view(H.shape[0], -1), link_pred
 
     def forward_pairs_loss(self, x, graph: Graph, pairs: PairList, label, weight):

@@ -268,7 +268,35 @@ def route_aggregate_bwd_phase2(g: Graph, Z, beta: float, t: float, p, a, s, dH, 
     return dZ_out
 
 
-_xpad_cache: dict = {}
+class _PaddedFeatures:
+    """Zero-padded copies of feature matrices whose row length is not a multiple of 4, one per source TENSOR and version
+    counter.  Entries are keyed by the tensor OBJECT (its id, checked against a weak reference: an address — or an id —
+    can be reused by another tensor once this one is gone, a live object cannot) and are dropped when their tensor dies.
+    The padded copy is what the kernels — and any captured HIP graph — read, so it must live exactly as long as the
+    caller's x does: with one entry per tensor, a second model, an evaluation on other features or a second run in the
+    same process cannot evict the copy a live graph still replays (train._graphed_epoch also holds it)."""
+
+    def __init__(self):
+        self._by_id: dict = {}
+
+    def get(self, x: torch.Tensor, Fp: int) -> torch.Tensor:
+        key = id(x)
+        hit = self._by_id.get(key)
+        if hit is None or hit[0]() is not x or hit[1] != x._version or hit[2].shape[1] != Fp:
+            ref = weakref.ref(x, lambda _r, k=key, d=self._by_id: d.pop(k, None) if d.get(k, (None,))[0] is _r else None)
+            hit = (ref, x._version, torch.nn.functional.pad(x, (0, Fp - x.shape[1])))
+            self._by_id[key] = hit
+        return hit[2]
+
+
+_xpad = _PaddedFeatures()
+
+
+def padded_features(x: torch.Tensor) -> torch.Tensor:
+    """The tensor project_fwd / project_bwd actually read for x (x itself when its rows are 16-byte aligned)."""
+    F = x.shape[1]
+    Fp = (F + 3) // 4 * 4
+    return x if Fp == F else _xpad.get(x, Fp)
 
 
 def _pad_features(x, W1):
@@ -279,13 +307,7 @@ def _pad_features(x, W1):
     Fp = (F + 3) // 4 * 4
     if Fp == F:
         return x, W1
-    # keyed on the tensor OBJECT (weak reference) and its version counter: an address can be reused by another
-    # tensor of the same shape once this one is freed, an object cannot
-    hit = _xpad_cache.get("x")
-    if hit is None or hit[0]() is not x or hit[1] != x._version:
-        hit = (weakref.ref(x), x._version, torch.nn.functional.pad(x, (0, Fp - F)))
-        _xpad_cache["x"] = hit
-    return hit[2], torch.nn.functional.pad(W1, (0, Fp - F))
+    return padded_features(x), torch.nn.functional.pad(W1, (0, Fp - F))
 
 
 def keep_hidden(N: int, F: int, K: int, nhid: int) -> bool:
@@ -589,41 +611,66 @@ class ScorePairs(torch.autograd.Function):
         return dZ, dH, None, None
 
 
+class DensePairPlanCache:
+    """Pair plan of the entries of the dense [N,N] score gradient that are non-zero — owned by ONE module (no process-wide
+    state).  The reference's caller indexes link_pred with masks that are fixed for a run (main_disentangled.py:134-190),
+    so the set repeats every epoch; autograd only hands the backward the dense gradient, not the masks, so whether the
+    cached set still applies has to be read off the gradient itself:
+
+      * default: one 16-byte device->host read per backward validates the cache (count of non-zeros, count of non-zeros
+        at the cached positions); a changed set rebuilds the plan.  (The reference's own loop reads back the validation
+        scores and the loss every epoch, main_disentangled.py:204,214.)
+      * ``static=True`` (Disentangle.assume_static_loss_masks()): no host read.  The same two counts stay on the device and
+        become a validity factor — 1 if the cache applies, NaN if it does not — multiplied into the gradients: a caller
+        that promised fixed masks and changed them gets NaN gradients at once, never silently wrong ones."""
+
+    def __init__(self):
+        self.pairs = None        # PairList of the cached index set
+        self.flat = None         # int64 [n] row-major positions
+        self.key = None          # (N, device)
+        self.static = False
+
+    def lookup(self, g_prob: torch.Tensor):
+        """-> (pairs, flat, validity factor or None)"""
+        N = g_prob.shape[0]
+        g_flat = g_prob.reshape(-1)
+        key = (N, g_prob.device)
+        if self.pairs is not None and self.key == key:
+            n = self.flat.numel()
+            probe = torch.stack([torch.count_nonzero(g_flat), torch.count_nonzero(g_flat[self.flat])])
+            if self.static:
+                ok = (probe[0] == n) & (probe[1] == n)
+                return self.pairs, self.flat, torch.where(ok, 1.0, float("nan")).to(torch.float32)
+            cnt, kept = probe.tolist()
+            if cnt == n and kept == n:
+                return self.pairs, self.flat, None
+        nz = torch.nonzero(g_prob)
+        self.pairs = PairList.build(nz[:, 0], nz[:, 1], N)
+        self.flat = nz[:, 0] * N + nz[:, 1]
+        self.key = key
+        return self.pairs, self.flat, None
+
+
 class ScoreAllPairs(torch.autograd.Function):
     """(Z, H) -> prob [N,N], the dense output the reference's caller indexes with masks
-    (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero."""
-    _plan_cache = None
+    (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero (``cache``: the calling
+    module's DensePairPlanCache)."""
 
     @staticmethod
-    def forward(ctx, Z, H, t: float):
+    def forward(ctx, Z, H, t: float, cache: "DensePairPlanCache | None" = None):
         Z, H = _f32c(Z), _f32c(H)
         prob = score_allpairs_fwd(Z, H, t)
         ctx.t = t
+        ctx.cache = cache if cache is not None else DensePairPlanCache()
         ctx.save_for_backward(Z, H, prob)
         return prob
 
     @staticmethod
     def backward(ctx, g_prob):
         Z, H, prob = ctx.saved_tensors
-        N = Z.shape[0]
-        # the caller's masks are fixed for a run (main_disentangled.py:134-190), so the set of entries with a
-        # gradient repeats every epoch: keep the last pair plan and reuse it while the index set is unchanged —
-        # same count of non-zeros and every cached position still non-zero (one reduction + one gather instead of
-        # a nonzero() over [N,N] and a plan build)
-        hit = ScoreAllPairs._plan_cache
-        g_flat = g_prob.reshape(-1)
-        same = False
-        if hit is not None and hit[3] == (N, g_prob.device):
-            probe = torch.stack([torch.count_nonzero(g_flat), torch.count_nonzero(g_flat[hit[2]])])
-            cnt, kept = probe.tolist()
-            same = cnt == hit[2].numel() and kept == cnt
-        if same:
-            _nz, pairs, flat, _key = hit
-        else:
-            nz = torch.nonzero(g_prob)
-            pairs = PairList.build(nz[:, 0], nz[:, 1], N)
-            flat = nz[:, 0] * N + nz[:, 1]
-            ScoreAllPairs._plan_cache = (nz, pairs, flat, (N, g_prob.device))
+        pairs, flat, valid = ctx.cache.lookup(g_prob)
         dZ, dH = score_pairs_bwd(Z, H, pairs, ctx.t, prob.reshape(-1)[flat].contiguous(),
                                  g_prob.reshape(-1)[flat].contiguous())
-        return dZ, dH, None
+        if valid is not None:
+            dZ, dH = dZ * valid, dH * valid
+        return dZ, dH, None, None

@@ -9,8 +9,12 @@ Semantics kept from the reference:
   * negatives: m independent draws; for every edge row (i, j) a node k with (i, k) not among the
     edge rows (PyG ``structured_negative_sampling``, call site :160; the PyG version is unpinned in
     the reference, so only this contract is reproduced, not its random stream).
-  * the dense masks collapse duplicate pairs, and labels are read from ``ori_adj`` — :167-190, :195.
-    Pair lists here are therefore unique'd, and labels are membership in the directed edge rows.
+  * labels are read from ``ori_adj`` (membership in the directed edge rows) — :195, :203, :218.
+  * duplicates.  The TRAIN masks ``pos_train_adj`` / ``neg_train_adj`` are ``sparse_coo(...).to_dense()`` and are
+    never binarised (:176-179): duplicate index pairs SUM, and the loss indexes ``a_pred[mask == 1]`` (:195), so a
+    pair that occurs more than once — a repeated edge row, or the same (i, k) drawn by two of the m negative draws —
+    is NOT part of the loss.  The train pair lists here therefore keep exactly the pairs that occur once.  The
+    validation / test masks ``all_val_adj`` / ``all_test_adj`` ARE binarised (:187-190): those lists are unique'd.
 """
 from __future__ import annotations
 
@@ -36,10 +40,15 @@ class LinkSplit:
     val: PairSet           # all_val_adj == 1
     test: PairSet          # all_test_adj == 1
     m: int
+    raw: dict | None = None  # make_link_split(keep_raw=True): the index lists before de-duplication (fixture generators)
 
 
-def _unique_pairs(u, v, n, edge_keys_sorted) -> PairSet:
-    key = np.unique(u.astype(np.int64) * n + v.astype(np.int64))      # row-major order, like mask indexing
+def _pair_set(u, v, n, edge_keys_sorted, only_single: bool) -> PairSet:
+    """Distinct pairs in row-major order (the order mask indexing visits them).  only_single: keep the pairs that occur
+    exactly once (``mask == 1`` on a summed, un-binarised mask); else every distinct pair (a binarised mask)."""
+    key, cnt = np.unique(u.astype(np.int64) * n + v.astype(np.int64), return_counts=True)
+    if only_single:
+        key = key[cnt == 1]
     uu, vv = key // n, key % n
     pos = np.searchsorted(edge_keys_sorted, key)
     pos = np.minimum(pos, max(edge_keys_sorted.size - 1, 0))
@@ -63,7 +72,7 @@ def structured_negatives(src, n, edge_keys_sorted, rng) -> np.ndarray:
     raise RuntimeError("negative sampling did not converge (a node is connected to every node)")
 
 
-def make_link_split(src, dst, n_nodes: int, m: int = 5, seed: int = 0) -> LinkSplit:
+def make_link_split(src, dst, n_nodes: int, m: int = 5, seed: int = 0, keep_raw: bool = False) -> LinkSplit:
     src = np.asarray(src, dtype=np.int64)
     dst = np.asarray(dst, dtype=np.int64)
     E = src.size
@@ -82,11 +91,16 @@ def make_link_split(src, dst, n_nodes: int, m: int = 5, seed: int = 0) -> LinkSp
             neg_u[name].append(src[idx])
             neg_v[name].append(k[idx])
     cat = np.concatenate
-    ps = lambda u, v: _unique_pairs(u, v, n_nodes, edge_keys)
-    return LinkSplit(
+    ps = lambda u, v, single: _pair_set(u, v, n_nodes, edge_keys, single)
+    out = LinkSplit(
         n_nodes=n_nodes, train_src=src[tr], train_dst=dst[tr],
-        pos_train=ps(src[tr], dst[tr]),
-        neg_train=ps(cat(neg_u["tr"]), cat(neg_v["tr"])),
-        val=ps(cat([src[va]] + neg_u["va"]), cat([dst[va]] + neg_v["va"])),
-        test=ps(cat([src[te]] + neg_u["te"]), cat([dst[te]] + neg_v["te"])),
+        pos_train=ps(src[tr], dst[tr], True),
+        neg_train=ps(cat(neg_u["tr"]), cat(neg_v["tr"]), True),
+        val=ps(cat([src[va]] + neg_u["va"]), cat([dst[va]] + neg_v["va"]), False),
+        test=ps(cat([src[te]] + neg_u["te"]), cat([dst[te]] + neg_v["te"]), False),
         m=m)
+    if keep_raw:                                              # fixture generators rebuild the reference's dense masks from these
+        out.raw = dict(neg_train=(cat(neg_u["tr"]), cat(neg_v["tr"])),
+                       val=(cat([src[va]] + neg_u["va"]), cat([dst[va]] + neg_v["va"])),
+                       test=(cat([src[te]] + neg_u["te"]), cat([dst[te]] + neg_v["te"])))
+    return out

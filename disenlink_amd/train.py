@@ -126,7 +126,10 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     # must outlive the graph.  The optimiser (moments, step counters) and the AUC index sets are created here, so they
     # are handed back for the caller to hold for as long as it replays (dropping them frees memory the graph still
     # reads and writes: the next allocation of that size would be corrupted, or an index set would turn to garbage).
-    return graph.replay, out, (graph, opt, val_plan, epoch, label_all, weight_all)
+    # ... and so is the zero-padded copy of x the projection kernels read when F % 4 != 0 (ops.padded_features): it is
+    # cached per source tensor, and held here as well so that nothing but the end of this run can free it
+    from .ops import padded_features
+    return graph.replay, out, (graph, opt, val_plan, epoch, label_all, weight_all, x, padded_features(x))
 
 
 def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 2000, lr: float = 1e-4,

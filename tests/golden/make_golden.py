@@ -16,7 +16,8 @@ Per case:
   alpha0, att                  Disentangle_layer internals returned at model.py:77
   p, a, s                      derived per-pair factor id / weight and per-node normaliser,
                                computed with the same expressions as model.py:59-72
-  ori_adj, pos_mask, neg_mask  a fixed train-positive / train-negative mask pair + labels
+  ori_adj, pos_mask, neg_mask  a fixed train-positive / train-negative mask pair + labels; the masks are SUMMED index
+                               lists like the caller's (duplicates give 2, 3, ...): the loss takes the entries == 1
   loss, grad__<key>            loss of main_disentangled.py:195 and all parameter gradients
 Plus auc_*.npz: scores/labels/roc_auc_score value (sklearn) incl. heavy ties at 1.0.
 """
@@ -57,6 +58,15 @@ def dense01(rows, n):
     return a
 
 
+def summed(rows, n):
+    """torch.sparse_coo_tensor(idx, ones).to_dense() as main_disentangled.py:176-179 builds the TRAIN masks pos_train_adj /
+    neg_train_adj: duplicate index pairs ADD UP and the masks are never binarised, so `a_pred[mask == 1]` (:195) leaves
+    out every pair that occurs more than once."""
+    a = np.zeros((n, n), dtype=np.float32)
+    np.add.at(a, (rows[:, 0], rows[:, 1]), 1.0)
+    return a
+
+
 CASES = [
     # name,      N,  F,  K, d, nhid, beta, t, x_scale, p_edge, isolated, self_loops, hub, m
     ("tiny_k1",   7,  5, 1,  3,   1, 0.5, 1, 1.0, 0.4, (3,), (), None, 2),
@@ -91,8 +101,8 @@ def run_case(model_mod, spec, seed):
             cand = cand[cand != i] if (cand != i).any() else cand
             negs.append((i, int(rng.choice(cand))))
     negs = np.array(negs, dtype=np.int64)
-    pos_mask = dense01(tr, n)
-    neg_mask = dense01(negs, n)
+    pos_mask = summed(tr, n)
+    neg_mask = summed(negs, n)
 
     x = (rng.standard_normal((n, f)) * xs).astype(np.float32)
     model = model_mod.Disentangle(f, nhid, d, nfactor=k, beta=beta, t=t)
@@ -169,7 +179,7 @@ def run_trajectory(model_mod, spec, seed):
                 out.append((i, int(rng.choice(cand))))
         return np.array(out, dtype=np.int64)
 
-    masks = {"pos_train": dense01(tr, n), "neg_train": dense01(negatives(tr), n),
+    masks = {"pos_train": summed(tr, n), "neg_train": summed(negatives(tr), n),
              "val": np.minimum(dense01(va, n) + dense01(negatives(va), n), 1),
              "test": np.minimum(dense01(te, n) + dense01(negatives(te), n), 1)}
     x = (rng.standard_normal((n, f)) * xs).astype(np.float32)

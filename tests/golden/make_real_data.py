@@ -38,6 +38,14 @@ def dense(u, v, n):
     return a
 
 
+def summed(u, v, n):
+    """torch.sparse_coo_tensor(idx, ones).to_dense() as main_disentangled.py:176-179 builds the TRAIN masks: duplicate
+    index pairs add up (and the loss then takes the entries that equal 1)."""
+    a = np.zeros((n, n), dtype=np.float32)
+    np.add.at(a, (u, v), 1.0)
+    return a
+
+
 def run(name, ref_model):
     from sklearn.metrics import roc_auc_score
     from disenlink_amd.datasets import load_planetoid, standardise_rows
@@ -64,12 +72,16 @@ def run(name, ref_model):
         assert np.all(feats[r, c] == 1.0)
         stored = dict(feat_row=r.astype(np.uint16), feat_col=c.astype(np.uint16), feat_shape=np.array(feats.shape))
     n = feats.shape[0]
-    split = make_link_split(edges[:, 0], edges[:, 1], n, m=M, seed=0)
+    split = make_link_split(edges[:, 0], edges[:, 1], n, m=M, seed=0, keep_raw=True)
     ori = dense(edges[:, 0], edges[:, 1], n)
     adj = dense(split.train_src, split.train_dst, n)
     adj_sym = ((adj + adj.T) != 0).astype(np.float32)
-    masks = {"pos": dense(split.pos_train.u, split.pos_train.v, n) == 1, "neg": dense(split.neg_train.u, split.neg_train.v, n) == 1,
-             "val": dense(split.val.u, split.val.v, n) == 1, "test": dense(split.test.u, split.test.v, n) == 1}
+    # the caller's masks, built from the RAW index lists the way main_disentangled.py:167-190 builds them: train masks
+    # summed and never binarised (entries == 1 enter the loss), validation / test masks binarised
+    masks = {"pos": summed(split.train_src, split.train_dst, n) == 1, "neg": summed(*split.raw["neg_train"], n) == 1,
+             "val": dense(*split.raw["val"], n) == 1, "test": dense(*split.raw["test"], n) == 1}
+    for key, ps in (("pos", split.pos_train), ("neg", split.neg_train), ("val", split.val), ("test", split.test)):
+        assert np.array_equal(np.stack(np.nonzero(masks[key])), np.stack([ps.u, ps.v])), key      # the pair lists ARE those masks
     torch.manual_seed(SEED)
     model = ref_model.Disentangle(feats.shape[1], NHID, D, nfactor=K, beta=BETA, t=T)
     opt = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=5e-4)

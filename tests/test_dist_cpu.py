@@ -53,7 +53,7 @@ def _reference(pb, sd):
     return emb.detach().numpy(), prob.detach().numpy(), float(loss.detach()), {k: v.grad.numpy() for k, v in sd.items()}
 
 
-def _worker(rank, world, port, pb, sd, out):
+def _worker(rank, world, port, pb, sd, out, n_chunks=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -65,7 +65,8 @@ def _worker(rank, world, port, pb, sd, out):
         torch.set_num_threads(1)
         model = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"])
         model.load_state_dict(sd)
-        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4)
+        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4,
+                               n_chunks=n_chunks)
         r0, r1 = shard.local_real_rows()
         emb, prob = dd.sharded_forward(model, torch.from_numpy(pb["x"][r0:r1]), shard, backend=OracleBackend())
         lab = torch.from_numpy(pb["label"][shard.pair_lo:shard.pair_hi])
@@ -77,23 +78,47 @@ def _worker(rank, world, port, pb, sd, out):
         tot = loss.detach().clone()
         dist.all_reduce(tot)
         out[rank] = dict(emb=emb.detach().numpy()[: r1 - r0], prob=prob.detach().numpy(), loss=float(tot),
-                         rows=(r0, r1), pairs=(shard.pair_lo, shard.pair_hi),
+                         rows=(r0, r1), pairs=(shard.pair_lo, shard.pair_hi), work=shard.work(),
+                         groups=[int(i.numel()) for i, _ in shard.pair_groups],
                          grads={k: v.grad.numpy().copy() for k, v in model.named_parameters()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_path_matches_unsharded_oracle(world):
+def _skewed_problem(seed=5, N=90, F=7, K=4, d=8, nhid=5):
+    """Heavy-tailed degrees (a few hubs, most nodes with a handful of edges), hubs at low ids."""
+    rng = np.random.default_rng(seed)
+    w = 1.0 / (np.arange(N) + 2.0) ** 0.9
+    w /= w.sum()
+    E = 12 * N
+    src, dst = rng.choice(N, E, p=w), rng.integers(0, N, E)
+    x = (rng.standard_normal((N, F)) * 0.6).astype(np.float32)
+    P = 500
+    pu, pv = np.sort(rng.choice(N, P, p=w)), rng.integers(0, N, P)
+    label = (rng.random(P) < 0.4).astype(np.float32)
+    return dict(N=N, F=F, K=K, d=d, nhid=nhid, src=src, dst=dst, x=x, pu=pu, pv=pv, label=label, beta=0.7, t=1.0)
+
+
+@pytest.mark.parametrize("world,n_chunks,skewed", [(2, 1, False), (3, 1, False), (3, 2, False), (4, 3, True)])
+def test_sharded_path_matches_unsharded_oracle(world, n_chunks, skewed):
+    """2 / 3 / 4 ranks over gloo, work-balanced blocks (padded to the largest, ids relabelled), with the H all-gather
+    blocking (n_chunks = 1) or in asynchronous row chunks with the pairs scored in arrival order."""
     from disenlink_amd.model import Disentangle
-    pb = _problem()
+    pb = _skewed_problem() if skewed else _problem()
     torch.manual_seed(0)
     sd = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"]).state_dict()
     emb_ref, prob_ref, loss_ref, grads_ref = _reference(pb, sd)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), pb, sd, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), pb, sd, out, n_chunks), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
+    if n_chunks > 1:                                        # every local pair sits in exactly one arrival group
+        for r in range(world):
+            q0, q1 = out[r]["pairs"]
+            assert len(out[r]["groups"]) == n_chunks + 1 and sum(out[r]["groups"]) == q1 - q0
+    if skewed:                                              # blocks follow the work, not the node count
+        rows = [out[r]["work"]["rows"] for r in range(world)]
+        assert max(rows) > 2 * min(rows), rows
     covered_rows, covered_pairs = 0, 0
     for r in range(world):
         o = out[r]
@@ -108,6 +133,39 @@ def test_sharded_path_matches_unsharded_oracle(world):
         covered_rows += r1 - r0
         covered_pairs += q1 - q0
     assert covered_rows == pb["N"] and covered_pairs == pb["pu"].size
+
+
+def test_work_balanced_partition_on_hub_skewed_graphs():
+    """contiguous row blocks balanced by nnz, not by node count.  On the squirrel-shaped graph
+    (median degree ~20, hubs beyond 1,000) and on the same graph with its hubs SORTED to the front, the heaviest shard's
+    symmetrised nnz stays within 1.15 x the mean for 2, 4 and 8 ranks; equal node blocks do not."""
+    from disenlink_amd import dist as dd
+    from disenlink_amd.data import synthetic_graph
+    sg = synthetic_graph("squirrel", seed=0)
+    N = sg.n_nodes
+    for relabel in (False, True):
+        src, dst = sg.src, sg.dst
+        if relabel:                                         # hubs first: the worst case for equal node blocks
+            deg = np.bincount(src, minlength=N) + np.bincount(dst, minlength=N)
+            rank_of = np.empty(N, dtype=np.int64)
+            rank_of[np.argsort(-deg, kind="stable")] = np.arange(N)
+            src, dst = rank_of[src], rank_of[dst]
+        key = np.unique(np.concatenate([src * N + dst, dst * N + src]))
+        nnz_row = np.bincount(key // N, minlength=N)        # the symmetrised, binarised adjacency the kernels walk
+        for world in (2, 4, 8):
+            part = dd.Partition.build(N, world, src, dst, balance="nnz", n_chunks=4)
+            assert part.cuts[0] == 0 and part.cuts[-1] == N and (np.diff(part.cuts) >= 0).all()
+            assert part.block % 4 == 0 and part.block >= np.diff(part.cuts).max() and part.n_pad == world * part.block
+            nnz = np.array([nnz_row[part.cuts[r]:part.cuts[r + 1]].sum() for r in range(world)], dtype=np.float64)
+            assert nnz.max() / nnz.mean() <= 1.15, (relabel, world, nnz)
+            ids = np.arange(N)
+            pad = part.to_padded(ids)
+            assert (np.diff(pad) > 0).all() and (pad // part.block == np.searchsorted(part.cuts, ids, side="right") - 1).all()
+            if relabel and world >= 4:
+                eq = dd.Partition.build(N, world, balance="nodes")
+                nnz_eq = np.array([nnz_row[eq.cuts[r]:eq.cuts[r + 1]].sum() for r in range(world)], dtype=np.float64)
+                assert nnz_eq.max() / nnz_eq.mean() > 1.5
+    assert dd.balanced_cuts(np.array([1, 1, 100, 1, 1, 1]), 3).tolist() == [0, 2, 3, 6]      # a hub gets its own block
 
 
 def test_partition_helpers():

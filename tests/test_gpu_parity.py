@@ -58,16 +58,20 @@ def test_forward_kernels_match_reference_golden(name, force_generic):
         assert ok.mean() > 0.95
         assert (p.cpu().numpy()[ok] == g["p"][src, col][ok]).all()
         np.testing.assert_allclose(a.cpu().numpy()[ok], g["a"][src, col][ok], rtol=1e-5)
-        if ok.all():
-            s_h = s.cpu().numpy()
-            np.testing.assert_allclose(np.where(s_h == 0, 1, s_h), g["s"], rtol=1e-5)
+        # A near-tie in the routing of one edge (fp32 may break it either way) changes s of that row, h of that row and of
+        # its neighbours: everything is asserted on the nodes no near-tie can reach — all of them in most cases
+        row_ok = np.bincount(src[~ok], minlength=N) == 0                       # every edge of the row is decisive
+        nb_bad = np.bincount(src, weights=(~row_ok[col]).astype(float), minlength=N) > 0
+        node_ok = row_ok & ~nb_bad                                             # ... and of every neighbour's row
+        assert node_ok.mean() > 0.6, node_ok.mean()
+        s_h = s.cpu().numpy()
+        np.testing.assert_allclose(np.where(s_h == 0, 1, s_h)[row_ok], g["s"][row_ok], rtol=1e-5)
         H = ops.aggregate_fwd(G, Z, m["beta"], p, a, s)
-        if ok.all():
-            np.testing.assert_allclose(H.cpu().numpy().reshape(N, K * d), g["emb"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(H.cpu().numpy().reshape(N, K * d)[node_ok], g["emb"][node_ok], rtol=1e-5, atol=1e-5)
         idx = torch.arange(N, dtype=torch.int32, device=DEV)
         prob = ops.score_pairs_fwd(Z, H, idx.repeat_interleave(N), idx.repeat(N), m["t"]).view(N, N)
-        if ok.all():
-            np.testing.assert_allclose(prob.cpu().numpy(), g["link_pred"], rtol=1e-5, atol=1e-5)
+        both = np.outer(node_ok, node_ok)
+        np.testing.assert_allclose(prob.cpu().numpy()[both], g["link_pred"][both], rtol=1e-5, atol=1e-5)
     finally:
         _lib.load().dl_set_force_generic(old)
 
@@ -435,6 +439,46 @@ def test_caches_follow_tensor_identity_not_addresses():
     z2 = model.project(x2)
     assert torch.allclose(z2, fresh.project(x2), atol=1e-6), ("stale padded features served", x2.data_ptr() == xaddr)
     assert not torch.equal(z1, z2)
+
+
+def test_dense_backward_plan_cache_is_per_module_and_static_masks_never_go_wrong_silently():
+    """The backward of the dense [N,N] link_pred scores only the entries with a gradient, from a pair plan cached per
+    MODULE: two models of equal N with different masks must not disturb each other, a changed mask must be noticed,
+    and in the promised-static mode (no host read) a broken promise must give NaN gradients, not wrong ones."""
+    from disenlink_amd.model import Disentangle
+    torch.manual_seed(5)
+    N, Fdim = 90, 12
+    g = torch.Generator().manual_seed(0)
+    a = (torch.rand(N, N, generator=g) < 0.08).float()
+    adj = ((a + a.t()) > 0).float().to(DEV)
+    x = torch.randn(N, Fdim, device=DEV)
+    masks = [(torch.rand(N, N, generator=g) < 0.05).to(DEV) for _ in range(3)]
+    lab = adj
+
+    def grads(model, mask):
+        model.zero_grad()
+        _emb, pred = model(x, adj)
+        torch.nn.functional.binary_cross_entropy(pred[mask], lab[mask]).backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    def fresh():
+        torch.manual_seed(9)
+        return Disentangle(Fdim, 16, 32, nfactor=4, beta=0.6).to(DEV)
+
+    m1, m2 = fresh(), fresh()
+    want = [grads(fresh(), mk) for mk in masks]                   # a new module (empty cache) per mask
+    for rounds in range(2):                                       # interleaved: each module keeps ITS plan
+        for model, k in ((m1, 0), (m2, 1), (m1, 0), (m2, 1)):
+            for got, ref in zip(grads(model, masks[k]), want[k]):
+                assert torch.equal(got, ref)
+    for got, ref in zip(grads(m1, masks[2]), want[2]):            # the mask changed: noticed, plan rebuilt
+        assert torch.equal(got, ref)
+    assert m1._dense_plan is not m2._dense_plan
+    ms = fresh().assume_static_loss_masks()
+    for _ in range(2):
+        for got, ref in zip(grads(ms, masks[0]), want[0]):        # same bits without the host read
+            assert torch.equal(got, ref)
+    assert all(bool(torch.isnan(gr).all()) for gr in grads(ms, masks[1]))      # promise broken: NaN, not garbage
 
 
 @pytest.mark.parametrize("name", __import__("conftest").trajectory_names())

@@ -85,8 +85,8 @@ def test_sparse_backward_matches_reference_grads(golden):
     N = Z.shape[0]
     rowptr, col, rev = sparse_ref.csr_from_dense(g["adj"])
     H, p, a, s_raw = sparse_ref.forward(Z, rowptr, col, m["beta"], m["t"])
-    pu, pv = np.nonzero(g["pos_mask"])
-    nu, nv = np.nonzero(g["neg_mask"])
+    pu, pv = np.nonzero(g["pos_mask"] == 1)              # the caller takes mask == 1: pairs that occur exactly once
+    nu, nv = np.nonzero(g["neg_mask"] == 1)
     pp = sparse_ref.score_pairs(Z, H, pu, pv, m["t"])
     pn = sparse_ref.score_pairs(Z, H, nu, nv, m["t"])
     lab_p, lab_n = g["ori_adj"][pu, pv], g["ori_adj"][nu, nv]

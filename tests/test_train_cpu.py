@@ -48,8 +48,8 @@ def test_pair_loss_equals_the_references_masked_loss(name):
     from disenlink_amd.metrics import pair_bce_loss
     g = load_golden(name)
     P = torch.from_numpy(g["link_pred"])
-    pu, pv = np.nonzero(g["pos_mask"])
-    nu, nv = np.nonzero(g["neg_mask"])
+    pu, pv = np.nonzero(g["pos_mask"] == 1)              # the caller takes mask == 1: pairs that occur exactly once
+    nu, nv = np.nonzero(g["neg_mask"] == 1)
     ori = g["ori_adj"]
     loss = pair_bce_loss(P[pu, pv], torch.from_numpy(ori[pu, pv]), P[nu, nv], torch.from_numpy(ori[nu, nv]),
                          g["meta"]["m"])
@@ -70,7 +70,8 @@ def test_split_builder_contract():
         assert np.unique(k).size == k.size and (np.diff(k) > 0).all()    # unique, row-major order
         assert (ps.label == want).all()
         assert all(((int(x) in keys) == bool(want)) for x in k.tolist())
-    assert sp.neg_train.u.size <= 3 * n_tr and sp.neg_train.u.size > 2.5 * n_tr
+    # m draws per train row; pairs drawn more than once drop out (summed masks, == 1): a small dense graph loses many
+    assert 1.5 * n_tr < sp.neg_train.u.size <= 3 * n_tr
     # every negative shares its source with a positive edge row
     assert set(sp.neg_train.u.tolist()) <= set(sg.src.tolist())
     # val / test: positives and negatives together, labels from the directed edge rows
@@ -80,6 +81,32 @@ def test_split_builder_contract():
         assert 0 < ps.label.mean() < 0.5
     sp2 = make_link_split(sg.src, sg.dst, N, m=3, seed=5)
     assert np.array_equal(sp.test.u, sp2.test.u) and np.array_equal(sp.neg_train.v, sp2.neg_train.v)
+
+
+def test_train_pair_sets_are_the_callers_summed_masks():
+    """main_disentangled.py:176-179 builds pos_train_adj / neg_train_adj with sparse_coo(...).to_dense() and never
+    binarises them: duplicate index pairs add up, and the loss takes a_pred[mask == 1] (:195) — the pairs that occur
+    EXACTLY once.  all_val_adj / all_test_adj are binarised (:187-190): every distinct pair.  The pair lists must be
+    those mask selections, in mask (row-major) order, on edge rows with duplicates (as chameleon.npz has) and with
+    negatives colliding across the m draws (hub rows)."""
+    from disenlink_amd.splits import make_link_split
+    rng = np.random.default_rng(3)
+    N, E = 40, 400
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    src[:120] = 0                                                         # a hub: many colliding negatives
+    src, dst = np.r_[src, src[:60]], np.r_[dst, dst[:60]]                 # 60 repeated rows
+    sp = make_link_split(src, dst, N, m=5, seed=1, keep_raw=True)
+
+    def summed(u, v):
+        a = np.zeros((N, N))
+        np.add.at(a, (u, v), 1.0)
+        return a
+    pos, neg = summed(sp.train_src, sp.train_dst), summed(*sp.raw["neg_train"])
+    assert (pos > 1).any() and (neg > 1).any()                            # the case is there
+    for ps, mask in ((sp.pos_train, pos == 1), (sp.neg_train, neg == 1), (sp.val, summed(*sp.raw["val"]) >= 1),
+                     (sp.test, summed(*sp.raw["test"]) >= 1)):
+        assert np.array_equal(np.stack([ps.u, ps.v]), np.stack(np.nonzero(mask)))
+    assert sp.pos_train.u.size < np.unique(sp.train_src * N + sp.train_dst).size      # repeated rows dropped, not kept once
 
 
 class OraclePairModule(nn.Module):
