@@ -230,25 +230,30 @@ __device__ __forceinline__ WaveSeg load_wave_seg(const dl_csr_plan& c) {
     const int pos0 = s0 + wg * WAVES_PER_BLOCK;
     const bool in = pos0 < s1;
     const int q = in ? pos0 : 0;                                   // launches have n_seg >= DL_UNIT_SEGS
-    int rows[WAVES_PER_BLOCK];
+    // a unit = a run of positions with the same row AND the same partial slot (plans built with one segment per unit
+    // give the segments of a multi-segment row different slots: each is then its own unit)
+    int rows[WAVES_PER_BLOCK], slots[WAVES_PER_BLOCK];
 #pragma unroll
-    for (int u = 0; u < WAVES_PER_BLOCK; ++u) rows[u] = c.seg_row[q + u];
-    const int beg = c.seg_beg[q + w.wave], end = c.seg_end[q + w.wave], slot = c.seg_slot[q + w.wave];
-    int mine = -1, prev = -1;
+    for (int u = 0; u < WAVES_PER_BLOCK; ++u) {
+        rows[u] = c.seg_row[q + u];
+        slots[u] = c.seg_slot[q + u];
+    }
+    const int beg = c.seg_beg[q + w.wave], end = c.seg_end[q + w.wave];
+    int mine = -1, prev = -1, slot = -1, prev_slot = -1;
 #pragma unroll
     for (int u = 0; u < WAVES_PER_BLOCK; ++u) {
         if (!in) rows[u] = -1;
-        if (u == w.wave) mine = rows[u];
-        if (u + 1 == w.wave) prev = rows[u];
+        if (u == w.wave) { mine = rows[u]; slot = slots[u]; }
+        if (u + 1 == w.wave) { prev = rows[u]; prev_slot = slots[u]; }
     }
     w.active = mine >= 0;
-    w.head = w.active && (w.wave == 0 || prev != mine);
+    w.head = w.active && (w.wave == 0 || prev != mine || prev_slot != slot);
     w.n_unit = 0;
     bool run = true;
 #pragma unroll
     for (int u = 0; u < WAVES_PER_BLOCK; ++u) {
         if (u >= w.wave) {
-            run = run && rows[u] == mine;
+            run = run && rows[u] == mine && slots[u] == slot;
             w.n_unit += run ? 1 : 0;
         }
     }

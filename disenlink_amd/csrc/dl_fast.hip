@@ -163,33 +163,69 @@ __device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
 }
 
 // ---------------------------------------------------------------------------- unit reduction through LDS
-// A segment kernel ends with its per-segment result complete in the lanes of group 0 (lane c: elements
-// kk*D + c*VEC .. of every factor kk).  Every active wave stages it in its own LDS row; after the workgroup barrier the
-// head wave of each unit adds the rows of its unit in wave (= segment) order, all 64 lanes at work: lane l ends up with
-// the float4s x = q*64 + l of the row.
+// A segment kernel ends with per-GROUP partial results: lane c of group g holds elements kk*D + c*VEC .. of every factor
+// kk, summed over the entries its group walked.  Adding the 64/G groups of a wave with cross-lane butterflies costs
+// 2 log2(64/G) moves + adds per VALUE (K*VEC of them, twice that in the scorer backward): a third of all vector
+// instructions of these kernels.  Instead every group stages its partial row in the wave's LDS region and, after the
+// workgroup barrier, the head wave of each unit adds groups and segments straight out of LDS — in a fixed order
+// (segment by segment, group 0 .. NG-1 inside) — with all 64 lanes at work: lane l ends up with the float4s
+// x = q*64 + l of the row.  Where the staged rows would not leave room for two workgroups per CU (K = 16, d = 128 in the
+// scorer backward) the groups are added in registers first and only group 0 is staged.
 template <int K, int D, int VEC>
 __device__ __forceinline__ void stage_row(float* dst, const Chunk<VEC> (&acc)[K], int c) {
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) store_f32<VEC>(dst + kk * D + c * VEC, acc[kk]);
 }
 
-template <int ROWF>
-struct UnitSum {
+template <int K, int D, typename T, int NROWS>
+struct Stage {
+    using GE = Geo<K, D, T>;
+    static constexpr int VEC = GE::VEC, G = GE::G;
+    static constexpr int NG = DL_WAVE / G;                         // lane groups per wave
+    static constexpr int ROWF = NROWS * GE::ROW;                   // floats of one wave's result
+    // budget: four workgroups per CU for the one-row kernels (160 KB LDS per CU), two for the scorer backward
+    static constexpr bool GROUPS_IN_LDS = (size_t)WAVES_PER_BLOCK * NG * ROWF * sizeof(float) <= (NROWS == 1 ? 40 : 64) * 1024;
+    static constexpr int SG = GROUPS_IN_LDS ? NG : 1;              // group rows staged per wave
+    static constexpr int FLOATS = WAVES_PER_BLOCK * SG * ROWF;     // LDS floats of the workgroup
     static constexpr int F4 = ROWF / 4;
     static constexpr int NQ = (F4 + DL_WAVE - 1) / DL_WAVE;
     static_assert(ROWF % 4 == 0, "row length must be a multiple of 4 floats");
-    // red: [WAVES_PER_BLOCK][ROWF] floats, 16-byte aligned
-    static __device__ __forceinline__ void run(const float* red, int wave, int n, int lane, float4 (&r)[NQ]) {
+
+    // this wave's region: [SG][ROWF] floats
+    static __device__ __forceinline__ float* region(float* red, int wave) { return red + (size_t)wave * SG * ROWF; }
+
+    // stage result row `r` (0 .. NROWS-1) of this lane's group
+    static __device__ __forceinline__ void put(float* red, int wave, int grp, int c, Chunk<VEC> (&acc)[K], int r) {
+        if constexpr (GROUPS_IN_LDS) {
+            stage_row<K, D, VEC>(region(red, wave) + grp * ROWF + r * GE::ROW, acc, c);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
+            if (grp == 0) stage_row<K, D, VEC>(region(red, wave) + r * GE::ROW, acc, c);
+        }
+    }
+
+    // head wave, after the barrier: sum of the unit's n waves (segments), groups 0 .. SG-1 inside each
+    static __device__ __forceinline__ void sum(const float* red, int wave, int n, int lane, float4 (&out)[NQ]) {
         const float4* red4 = reinterpret_cast<const float4*>(red);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int x = q * DL_WAVE + lane;
-            r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            out[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (x < F4) {
-                r[q] = red4[wave * F4 + x];
+                const float4* base = red4 + (size_t)wave * SG * F4 + x;
+                out[q] = base[0];
+#pragma unroll
+                for (int g = 1; g < SG; ++g) {
+                    const float4 v = base[g * F4];
+                    out[q].x += v.x; out[q].y += v.y; out[q].z += v.z; out[q].w += v.w;
+                }
                 for (int u = 1; u < n; ++u) {
-                    const float4 v = red4[(wave + u) * F4 + x];
-                    r[q].x += v.x; r[q].y += v.y; r[q].z += v.z; r[q].w += v.w;
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) {
+                        const float4 v = base[(u * SG + g) * F4];
+                        out[q].x += v.x; out[q].y += v.y; out[q].z += v.z; out[q].w += v.w;
+                    }
                 }
             }
         }
@@ -301,10 +337,13 @@ __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, i
     // unit sum: the 4 positions of a workgroup-sized group are the 4 quads of one DPP row; a unit is a run of equal rows
     // among them, added in segment order by its first position (row_shl:4q brings quad +q)
     const int pos_in_grp = (threadIdx.x / ROWSUM_SUB) % WAVES_PER_BLOCK;
+    // (a unit = same row AND same slot: plans with one segment per unit give every segment of a row its own slot)
     const int prev_row = dpp_move_i<0x114>(row);                 // row_shr:4: the previous position's row (-1 at the group's start)
-    const bool head = row >= 0 && (pos_in_grp == 0 || prev_row != row);
+    const int prev_slot = dpp_move_i<0x114>(slot);
+    const bool head = row >= 0 && (pos_in_grp == 0 || prev_row != row || prev_slot != slot);
     const int r1 = dpp_move_i<0x104>(row), r2 = dpp_move_i<0x108>(row), r3 = dpp_move_i<0x10C>(row);   // row_shl:4 / 8 / 12
-    const bool ok1 = r1 == row, ok2 = ok1 && r2 == row, ok3 = ok2 && r3 == row;
+    const int t1 = dpp_move_i<0x104>(slot), t2 = dpp_move_i<0x108>(slot), t3 = dpp_move_i<0x10C>(slot);
+    const bool ok1 = r1 == row && t1 == slot, ok2 = ok1 && r2 == row && t2 == slot, ok3 = ok2 && r3 == row && t3 == slot;
     float tot[KP];
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) {
@@ -355,8 +394,8 @@ __global__ __launch_bounds__(BLOCK, (K * Tab<T>::VEC <= 32 && U <= 2) ? 8 : 1) v
                                                               float* __restrict__ h_part) {
     using GE = Geo<K, D, T>;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
-    using US = UnitSum<ROW>;
-    __shared__ __attribute__((aligned(16))) float red[WAVES_PER_BLOCK][ROW];
+    using US = Stage<K, D, T, 1>;
+    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
     const WaveSeg ws = load_wave_seg(g);
     const SegInfo si = ws.si;
     const int lane = lane_id();
@@ -397,14 +436,12 @@ __global__ __launch_bounds__(BLOCK, (K * Tab<T>::VEC <= 32 && U <= 2) ? 8 : 1) v
                 for (int kk = 0; kk < K; ++kk) fma_chunk(acc[kk], (kk == kx[u]) ? wu : 0.0f, v[u]);
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
-        if (grp == 0) stage_row<K, D, VEC>(red[ws.wave], acc, c);
+        US::put(red, ws.wave, grp, c, acc, 0);
     }
     __syncthreads();
     if (!ws.head) return;
     float4 r[US::NQ];
-    US::run(&red[0][0], ws.wave, ws.n_unit, lane, r);
+    US::sum(red, ws.wave, ws.n_unit, lane, r);
     const float omb = 1.0f - beta;
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {
@@ -553,8 +590,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
-    using US = UnitSum<ROW>;
-    __shared__ __attribute__((aligned(16))) float red[WAVES_PER_BLOCK][ROW];
+    using US = Stage<K, D, T, 1>;
+    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
     const WaveSeg ws = load_wave_seg(g);
     const SegInfo si = ws.si;
     const int lane = lane_id();
@@ -611,14 +648,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
                 fma_chunk(acc[kk], kk == k ? w2 : 0.0f, dhj);
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
-        if (grp == 0) stage_row<K, D, VEC>(red[ws.wave], acc, c);
+        US::put(red, ws.wave, grp, c, acc, 0);
     }
     __syncthreads();
     if (!ws.head) return;
     float4 r[US::NQ];
-    US::run(&red[0][0], ws.wave, ws.n_unit, lane, r);
+    US::sum(red, ws.wave, ws.n_unit, lane, r);
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {
         const int x = q * DL_WAVE + lane;
@@ -787,14 +822,16 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
-    using US = UnitSum<2 * ROW>;
-    // per wave: the u rows of Z and H during the walk, then (the same memory) the wave's [dZ row | dH row] for the unit sum
-    __shared__ __attribute__((aligned(16))) float urow[WAVES_PER_BLOCK][2 * ROW];
+    using US = Stage<K, D, T, 2>;
+    // per wave: the u rows of Z and H during the walk (the first 2 ROW floats of the wave's region), then — the same
+    // memory — the groups' [dZ row | dH row] partials for the unit sum
+    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
     const WaveSeg ws = load_wave_seg(g);
     const SegInfo si = ws.si;
     const int wave = ws.wave, lane = lane_id();
     const bool active = ws.active;
-    if (active) stage_u_rows<K, D, T>(urow[wave], Z, H, (size_t)si.grow);
+    float* const urow_w = US::region(red, wave);
+    if (active) stage_u_rows<K, D, T>(urow_w, Z, H, (size_t)si.grow);
     __syncthreads();
     const int c = lane % G, grp = lane / G;
     if (active) {
@@ -829,8 +866,8 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 const int kk = k < K ? k : 0;
-                pq[k] = k < K ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
-                ps[k] = k < K ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zv[kk]) : 0.0f;
+                pq[k] = k < K ? dot(load_f32<VEC>(&urow_w[ROW + kk * D + c * VEC]), hv[kk]) : 0.0f;
+                ps[k] = k < K ? dot(load_f32<VEC>(&urow_w[kk * D + c * VEC]), zv[kk]) : 0.0f;
             }
             TransposedReduce<KP, G / 2>::run(pq, c);
             TransposedReduce<KP, G / 2>::run(ps, c);
@@ -866,18 +903,14 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
                 fma_chunk(accZ[k], cz, zv[k]);
             }
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k) { across_groups_sum_chunk<G>(accZ[k]); across_groups_sum_chunk<G>(accH[k]); }
         // the wave is done with its u rows (its own LDS region, program order): the region now takes its results
-        if (grp == 0) {
-            stage_row<K, D, VEC>(urow[wave], accZ, c);
-            stage_row<K, D, VEC>(urow[wave] + ROW, accH, c);
-        }
+        US::put(red, wave, grp, c, accZ, 0);
+        US::put(red, wave, grp, c, accH, 1);
     }
     __syncthreads();
     if (!ws.head) return;
     float4 r[US::NQ];
-    US::run(&urow[0][0], wave, ws.n_unit, lane, r);
+    US::sum(red, wave, ws.n_unit, lane, r);
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {
         const int x = q * DL_WAVE + lane;
@@ -903,8 +936,8 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g
                                                                    float* __restrict__ out, float* __restrict__ part) {
     using GE = Geo<K, D, T>;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
-    using US = UnitSum<ROW>;
-    __shared__ __attribute__((aligned(16))) float red[WAVES_PER_BLOCK][ROW];
+    using US = Stage<K, D, T, 1>;
+    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
     const WaveSeg ws = load_wave_seg(g);
     const SegInfo si = ws.si;
     const int lane = lane_id();
@@ -950,14 +983,12 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_coef_seg_kernel(dl_csr_plan g
                     if (b0 + k < K) fma_chunk(acc[b0 + k], gl * ck[b0 + k], xv[k]);
             }
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k) across_groups_sum_chunk<G>(acc[k]);
-        if (grp == 0) stage_row<K, D, VEC>(red[ws.wave], acc, c);
+        US::put(red, ws.wave, grp, c, acc, 0);
     }
     __syncthreads();
     if (!ws.head) return;
     float4 r[US::NQ];
-    US::run(&red[0][0], ws.wave, ws.n_unit, lane, r);
+    US::sum(red, ws.wave, ws.n_unit, lane, r);
     float* o = si.slot < 0 ? out + (size_t)si.grow * ROW : part + (size_t)si.slot * ROW;
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {

@@ -210,13 +210,14 @@ class Disentangle(nn.Module):
         (ops.HotPathPairsLoss).  Falls back to forward_pairs + the fused loss where no tuned kernel exists."""
         Z = self.project(x)
         dt = ops._lib.DL_F32 if self.table_dtype == torch.float32 else ops._lib.DL_BF16
-        # One pass pays where the partner rows come from HBM (it gathers 8 KB per pair instead of 12): measured
-        # snap-patents-sized (2 x 6 GB of tables) epoch 393 -> 337 ms, Penn94-sized K=16 d=128 fp32 (2 x 340 MB) 64 -> 51;
-        # with tables that sit in the 256 MB last-level cache or an L2 the separate kernels are as fast or faster
-        # (Penn94-sized K=8: 13.7 vs 14.1 ms, bf16 K=16: 35 vs 42; squirrel 1.56 vs 1.53).  DL_ONE_PASS_SCORER=0/1 forces.
+        # One pass gathers 8 KB per pair instead of 12.  Measured (tools/score_train_time.py, round 2, after the per-group
+        # partials moved to LDS): fp32 tables — one pass wins or ties at every size (squirrel 536 vs 587 us, chameleon 150
+        # vs 158, Penn94-sized K=8 8.5 vs 8.7 ms, K=16 d=128 33 vs 46 ms); bf16 tables that sit in the caches — the separate
+        # kernels win (Penn94-sized K=16 d=128: 22.3 vs 26.3 ms, K=8: 5.5 vs 5.9: the gathers are half as heavy, the
+        # one-pass kernel's registers are not); bf16 tables in HBM — one pass again.  DL_ONE_PASS_SCORER=0/1 forces.
         mode = os.environ.get("DL_ONE_PASS_SCORER", "auto")
         table_bytes = 2 * Z.shape[0] * Z.shape[1] * Z.shape[2] * (4 if self.table_dtype == torch.float32 else 2)
-        one_pass = mode == "1" or (mode != "0" and table_bytes > (512 << 20))
+        one_pass = mode == "1" or (mode != "0" and (self.table_dtype == torch.float32 or table_bytes > (512 << 20)))
         if one_pass and ops.score_pairs_train_supported(pairs, Z.shape[1], Z.shape[2], dt):
             H, prob, loss = ops.HotPathPairsLoss.apply(Z, graph, pairs, float(self.beta), float(self.temperature),
                                                        self.table_dtype, label, weight)

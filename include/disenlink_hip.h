@@ -53,7 +53,8 @@ typedef enum dl_dtype { DL_F32 = 0, DL_BF16 = 1 } dl_dtype;
  * workgroup (DL_UNIT_SEGS = 4 wavefronts) serves DL_UNIT_SEGS consecutive POSITIONS of the seg_* arrays.
  *
  * Units.  The segments of a row (of one column slice of a row, see below) are grouped, counting from the
- * row's first segment, into UNITS of at most DL_UNIT_SEGS consecutive segments.  A unit never straddles a
+ * row's first segment, into UNITS of at most DL_UNIT_SEGS consecutive segments (the kernels recognise a unit
+ * as a run of positions with the same row AND the same slot inside one group of DL_UNIT_SEGS positions).  A unit never straddles a
  * group of DL_UNIT_SEGS positions (units of 3 are padded to 4, units are stored largest first inside a
  * slice, every slice region is padded to a multiple of DL_UNIT_SEGS; seg_row = -1 marks a padding
  * position), so the workgroup that holds it sums it on chip, in segment order.  Only rows with more than

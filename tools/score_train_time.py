@@ -1,5 +1,5 @@
 """Training step of the scorer on the bench workload: one pass (dl_score_pairs_train) vs forward storing terms +
-fused loss + two backward passes.  usage: python tools/score_train_time.py [workload]"""
+fused loss + two backward passes.  usage: python tools/score_train_time.py [workload] [K] [d] [f32|bf16]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,13 @@ import bench
 from disenlink_amd import ops
 from disenlink_amd.metrics import pair_bce_weights
 dev = torch.device("cuda:0")
-sg, split, graph, pairs, model, x, Z = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "squirrel", dev, 8, 64, 512)
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
+sg, split, graph, pairs, model, x, Z = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "squirrel", dev, K, d, 512,
+                                                            elem_bytes=2 if bf16 else 4)
+if bf16:
+    Z = Z.to(torch.bfloat16)
 t, beta = 1.0, 0.5
 H = ops.aggregate_fwd(graph, Z, beta, *ops.route_fwd(graph, Z, t))
 P = pairs.n_pairs
@@ -26,6 +32,6 @@ for name, fn in (("one pass", one_pass), ("separate", separate), ("one pass", on
     e0.record()
     for _ in range(20): fn()
     e1.record(); e1.synchronize()
-    print(f"{name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+    print(f"{sys.argv[1:]} {name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
 a, b = one_pass(), separate()
 print("max|prob diff|", float((a[0] - b[0]).abs().max()), "max|dZ diff|/max", float((a[1] - b[1]).abs().max() / b[1].abs().max()))
