@@ -55,7 +55,7 @@ class Disentangle(nn.Module):
         layer is written once, transposed, for the backward while it fits a quarter of the device memory (at most
         64 GiB) and recomputed beyond that),
         "library" = library GEMMs (rocBLAS through torch), "auto" = the kernels wherever they support the factor width
-        (d in {32, 64, 128}): measured equal or faster than the library path at every feature width (squirrel epoch
+        (any d <= 128; widths other than 32 / 64 / 128 run at the next of those): measured equal or faster than the library path at every feature width (squirrel epoch
         1.64 vs 1.75 ms at F=128, 1.93 vs 2.06 at 512, 2.17 vs 2.36 at 1024, 2.74 vs 3.20 at 2089; real Cora
         (F=1433) 1.32 vs 1.60; tools/epoch_time.py), and they never materialise the [N,K,nhid] activations."""
         super().__init__()
@@ -138,7 +138,7 @@ class Disentangle(nn.Module):
 
     # ------------------------------------------------------------------ projection (model.py:106)
     def project(self, x: torch.Tensor) -> torch.Tensor:
-        """Z [N,K,d] = K independent MLPs of x.  On the GPU (d in {32,64,128}, see ``projection``): the fused MFMA
+        """Z [N,K,d] = K independent MLPs of x.  On the GPU (d <= 128, see ``projection``): the fused MFMA
         kernels of libdisenlink_hip.so.  Otherwise (CPU tests of the host logic, odd d, projection="library"): one
         wide library GEMM + one K-batched GEMM — plain torch plumbing, the reference's own ops."""
         fs = self.factors

@@ -333,15 +333,46 @@ def _keep_hidden_limit() -> int:
     return _KEEP_LIMIT
 
 
+_TILE_WIDTHS = (32, 64, 128)          # factor widths d the matrix-core projection kernels are instantiated for
+
+
+def project_tile_width(d: int) -> int | None:
+    """The kernels' own widths serve themselves; any other d <= 128 runs at the next width with zero-padded output
+    weights (zero rows of the LAST layer: they add nothing to any product and cost (dp - d) / dp of the smaller GEMM);
+    None beyond 128 (the library GEMMs then)."""
+    for w in _TILE_WIDTHS:
+        if d <= w:
+            return w
+    return None
+
+
+def _pad_out_rows(W, b, dp):
+    """Zero-pad dim 1 of W [K,d,*] and b [K,d] to dp."""
+    d = W.shape[1]
+    return torch.nn.functional.pad(W, (0, 0, 0, dp - d)), torch.nn.functional.pad(b, (0, dp - d))
+
+
 def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True, keep_hid: bool = False):
     """Z [N,K,d] = K MLPs of x on the matrix cores.  Two-layer: W1 [K,nhid,F], b1 [K,nhid], W2 [K,d,nhid],
     b2 [K,d]; single layer: W1 [K,d,F], b1 [K,d], W2 = b2 = None.  model.py:13-15 / 24-27 / 106.
-    keep_hid=True (two-layer): returns (Z, hid) with hid the kept hidden layer for project_bwd."""
+    keep_hid=True (two-layer): returns (Z, hid) with hid the kept hidden layer for project_bwd.
+    Any d <= 128: widths other than 32 / 64 / 128 run at the next of those (project_tile_width)."""
     lib = _lib.load()
     x, W1, b1 = _f32c(x), _f32c(W1), _f32c(b1)
     _need_cuda(x, W1, b1)
     if W1.shape[2] != x.shape[1]:
         raise ValueError("W1 does not match the feature count of x")
+    d_true = W1.shape[1] if W2 is None else W2.shape[1]
+    dp = project_tile_width(d_true)
+    if dp is None:
+        raise _lib.DisenlinkHipError(f"projection kernels serve d <= {_TILE_WIDTHS[-1]}, got {d_true}")
+    if dp != d_true:                                           # run at the tile width, hand back the first d columns
+        if W2 is None:
+            W1p, b1p = _pad_out_rows(W1, b1, dp)
+            return project_fwd(x, W1p, b1p, None, None, pad=pad)[:, :, :d_true].contiguous()
+        W2p, b2p = _pad_out_rows(_f32c(W2), _f32c(b2), dp)
+        out = project_fwd(x, W1, b1, W2p, b2p, pad=pad, keep_hid=keep_hid)
+        return (out[0][:, :, :d_true].contiguous(), out[1]) if keep_hid else out[:, :, :d_true].contiguous()
     if pad:
         x, W1 = _pad_features(x, W1)
     N, F = x.shape
@@ -375,6 +406,21 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
     _need_cuda(x, W1, b1, dZ)
     if W1.shape[2] != x.shape[1]:
         raise ValueError("inconsistent projection shapes")
+    d_true = W1.shape[1] if W2 is None else W2.shape[1]
+    dp = project_tile_width(d_true)
+    if dp is None:
+        raise _lib.DisenlinkHipError(f"projection kernels serve d <= {_TILE_WIDTHS[-1]}, got {d_true}")
+    if dp != d_true:                                           # zero-padded output columns carry zero gradient in
+        if dZ.shape[2] != d_true:
+            raise ValueError("inconsistent projection shapes")
+        dZp = torch.nn.functional.pad(dZ, (0, dp - d_true))
+        if W2 is None:
+            W1p, b1p = _pad_out_rows(W1, b1, dp)
+            dW1, db1, _n1, _n2 = project_bwd(x, W1p, b1p, None, dZp, pad=pad)
+            return dW1[:, :d_true].contiguous(), db1[:, :d_true].contiguous(), None, None
+        W2p = torch.nn.functional.pad(_f32c(W2), (0, 0, 0, dp - d_true))
+        dW1, db1, dW2, db2 = project_bwd(x, W1, b1, W2p, dZp, pad=pad, hid=hid)
+        return dW1, db1, dW2[:, :d_true].contiguous(), db2[:, :d_true].contiguous()
     F_true = x.shape[1]
     if pad:
         x, W1 = _pad_features(x, W1)
@@ -403,7 +449,9 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
 
 
 def project_supported(d: int) -> bool:
-    return bool(_lib.load().dl_project_supported(int(d)))
+    """Do the matrix-core projection kernels serve factor width d?  (Natively 32 / 64 / 128; every other d <= 128 at the
+    next of those widths through zero-padded output weights, project_tile_width.)"""
+    return project_tile_width(int(d)) is not None
 
 
 # ---------------------------------------------------------------------- autograd

@@ -123,6 +123,39 @@ def _backward_checks(graph, pairs, Z, Zh, f, beta, t, seed, grad_rel):
     assert torch.equal(dZ, ops.route_aggregate_bwd(graph, Z, beta, t, f["p"], f["a"], f["s"], dH1))      # reproducible
 
 
+def _one_shard_of_eight(sg, split_rows, pairs, Z, f, beta, t, rank=3, world=8):
+    """configs[3] names the 8-way edge-sharded run: build rank 3's shard exactly as dist.py does on an 8-GPU node
+    (work-balanced blocks, ids relabelled into the padded space), hand it the tables an all-gather would deliver, and
+    require its rows of s, H and its slice of the scores to equal the unsharded run BIT FOR BIT."""
+    from disenlink_amd import dist as dd, ops
+    shard = dd.Shard.build(rank, world, sg.n_nodes, split_rows[0], split_rows[1], pairs.pu.cpu().numpy(),
+                           pairs.pv.cpu().numpy(), torch.device(DEV), n_chunks=4, with_backward=False)
+    part = shard.part
+    pad_of = torch.from_numpy(part.to_padded(np.arange(sg.n_nodes))).to(DEV)
+    Zp = torch.zeros((shard.n_pad,) + tuple(Z.shape[1:]), dtype=Z.dtype, device=DEV)
+    Zp[pad_of] = Z
+    sp = torch.zeros((shard.n_pad, Z.shape[1]), dtype=torch.float32, device=DEV)
+    p_s, a_s, _ = ops.route_fwd(shard.graph, Zp, t, s_out=sp)
+    r0, r1 = shard.local_real_rows()
+    assert torch.equal(sp[shard.lo:shard.lo + (r1 - r0)], f["s"][r0:r1])                   # this rank's normalisers
+    e0, e1 = int(f["rowptr"][r0]), int(f["rowptr"][r1])
+    assert torch.equal(p_s, f["p"][e0:e1]) and torch.equal(a_s, f["a"][e0:e1])             # ... and routing
+    sp[pad_of] = f["s"]                                                                     # "all-gather" of s
+    Hp = torch.zeros_like(Zp)
+    ops.aggregate_fwd(shard.graph, Zp, beta, p_s, a_s, sp, H_out=Hp)
+    assert torch.equal(Hp[shard.lo:shard.lo + (r1 - r0)], f["H"][r0:r1])
+    Hp[pad_of] = f["H"]                                                                     # "all-gather" of H
+    backend = dd.HipBackend()
+    prob_s = dd.score_local_pairs(backend, shard, Zp, Hp, t, None)                          # one launch over the slice ...
+    assert torch.equal(prob_s, f["prob"][shard.pair_lo:shard.pair_hi])
+    prob_g = torch.empty_like(prob_s)                                                       # ... and in gather-arrival groups
+    for idx, sub in shard.pair_groups:
+        if sub is not None:
+            prob_g.index_copy_(0, idx, backend.score_pairs_fwd(Zp, Hp, sub, t))
+    assert torch.equal(prob_g, prob_s)
+    assert sum(int(i.numel()) for i, _ in shard.pair_groups) == shard.pairs.n_pairs
+
+
 def test_snap_patents_full_size_forward_and_backward_match_the_c_oracle():
     """configs[3]: snap_patents-shaped synthetic graph at FULL size (N = 2,923,922, E_sym ~ 23.8M, ~71M scored train
     pairs), K=8, d=64, fp32.  Tables live in HBM (6 GB each), row offsets pass 2^31 bytes."""
@@ -130,6 +163,7 @@ def test_snap_patents_full_size_forward_and_backward_match_the_c_oracle():
     K, d, beta, t = 8, 64, 0.5, 1.0
     t0 = time.time()
     sg, split, graph, pairs, model, x, Z = bench.build_workload("snap_patents", torch.device(DEV), K, d, 512)
+    split_rows = (split.train_src, split.train_dst)
     del model, x, split
     assert graph.n_nodes == 2_923_922 and graph.n_nodes * K * d * 4 > 2 ** 31
     print(f"\n[snap_patents] N={graph.n_nodes} E_sym={graph.n_edges} P={pairs.n_pairs} built in {time.time() - t0:.0f} s")
@@ -138,6 +172,8 @@ def test_snap_patents_full_size_forward_and_backward_match_the_c_oracle():
     print(f"[snap_patents] forward checked at {time.time() - t0:.0f} s")
     _backward_checks(graph, pairs, Z, Zh, f, beta, t, seed=3, grad_rel=1e-4)
     print(f"[snap_patents] backward checked at {time.time() - t0:.0f} s")
+    _one_shard_of_eight(sg, split_rows, pairs, Z, f, beta, t)
+    print(f"[snap_patents] shard 3 of 8 checked at {time.time() - t0:.0f} s")
 
 
 def test_penn94_full_size_bf16_tables_match_the_c_oracle_on_bf16_rounded_tables():

@@ -960,6 +960,43 @@ def test_projection_kernels_at_snap_patents_scale():
         assert float((f - (a + b)).abs().max()) <= 5e-5 * float(f.abs().max()), name
 
 
+@pytest.mark.parametrize("d,nhid", [(3, 1), (8, 24), (16, 1), (48, 40), (100, 16), (5, 7)])
+def test_projection_kernels_serve_any_factor_width_up_to_128(d, nhid):
+    """Factor / Factor2 (model.py:13-15, 24-27) at widths the kernels are not instantiated for: the module must stay on
+    the matrix-core kernels (zero-padded output weights, ops.project_tile_width) — forward against an fp64 MLP, the
+    weight gradients against torch autograd of the same MLP — and never reach a library GEMM."""
+    from disenlink_amd import ops
+    from disenlink_amd.model import Disentangle
+    torch.manual_seed(d * 13 + nhid)
+    N, Fdim, K = 301, 37, 3
+    model = Disentangle(Fdim, nhid, d, nfactor=K, beta=0.5, projection="mfma").to(DEV)
+    x = torch.randn(N, Fdim, device=DEV)
+    assert ops.project_supported(d) and ops.project_tile_width(d) in (32, 64, 128)
+    Z = model.project(x)
+    assert Z.shape == (N, K, d) and Z.is_contiguous()
+    ref = []
+    for f in model.factors:
+        xd = x.double()
+        if nhid == 1:
+            ref.append(xd @ f.mlp.weight.double().t() + f.mlp.bias.double())
+        else:
+            ref.append(torch.relu(xd @ f.mlp1.weight.double().t() + f.mlp1.bias.double()) @ f.mlp2.weight.double().t()
+                       + f.mlp2.bias.double())
+    ref = torch.stack(ref, dim=1)
+    assert float((Z.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    g = torch.randn_like(Z)
+    model.zero_grad()
+    (Z * g).sum().backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    lib = Disentangle(Fdim, nhid, d, nfactor=K, beta=0.5, projection="library").to(DEV)
+    lib.load_state_dict(model.state_dict())
+    (lib.project(x) * g).sum().backward()
+    for k, p in lib.named_parameters():
+        assert float((got[k] - p.grad).abs().max()) <= 1e-4 * max(float(p.grad.abs().max()), 1e-6), k
+    with pytest.raises(Exception):
+        ops.project_fwd(x, torch.randn(K, 130, Fdim, device=DEV), torch.randn(K, 130, device=DEV))    # d > 128: not served
+
+
 def test_projection_backward_rejects_bad_arguments():
     from disenlink_amd import _lib, ops
     x, dZ = torch.randn(10, 8, device=DEV), torch.randn(10, 2, 32, device=DEV)
