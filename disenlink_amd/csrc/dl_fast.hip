@@ -236,7 +236,7 @@ struct Stage {
 // p[e], a[e] for the entries of the plan's segments.  MIRROR: the plan covers col >= row only and
 // every result is also written to the reverse entry (routing is symmetric, bitwise).
 template <int K, int D, typename T, bool MIRROR>
-__global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 6 : 4)) void route_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ rev,
+__global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 6 : (K <= 16 ? 4 : 1))) void route_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ rev,
                                                           const T* __restrict__ Z, float t,
                                                           uint8_t* __restrict__ p, float* __restrict__ a) {
     using GE = Geo<K, D, T>;
@@ -687,7 +687,7 @@ __device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ 
 // One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
 // in LDS, every lane group then scores one pair per iteration from the gathered v rows.
 template <int K, int D, typename T, bool COEF>
-__global__ __launch_bounds__(BLOCK, K <= 10 ? 4 : 2) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
+__global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
                                                               const T* __restrict__ Z, const T* __restrict__ H,
                                                               float t, float* __restrict__ prob,
                                                               float* __restrict__ coef_e,
