@@ -183,8 +183,10 @@ struct Stage {
     static constexpr int VEC = GE::VEC, G = GE::G;
     static constexpr int NG = DL_WAVE / G;                         // lane groups per wave
     static constexpr int ROWF = NROWS * GE::ROW;                   // floats of one wave's result
-    // budget: four workgroups per CU for the one-row kernels (160 KB LDS per CU), two for the scorer backward
-    static constexpr bool GROUPS_IN_LDS = (size_t)WAVES_PER_BLOCK * NG * ROWF * sizeof(float) <= (NROWS == 1 ? 40 : 64) * 1024;
+    // Measured (profiles/r2p vs r2m): the two-row scorer backward gains 5 % from staging the groups (64 cross-lane sums
+    // fewer per wave); the one-row kernels do not — their waves are short, and on low-degree graphs (snap-patents-shaped:
+    // ~8 entries per row) writing four group rows per wave instead of one made the aggregate kernel 29 % slower.
+    static constexpr bool GROUPS_IN_LDS = NROWS == 2 && (size_t)WAVES_PER_BLOCK * NG * ROWF * sizeof(float) <= 64 * 1024;
     static constexpr int SG = GROUPS_IN_LDS ? NG : 1;              // group rows staged per wave
     static constexpr int FLOATS = WAVES_PER_BLOCK * SG * ROWF;     // LDS floats of the workgroup
     static constexpr int F4 = ROWF / 4;
