@@ -266,7 +266,7 @@ class Shard:
         pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, row_range=(lo, lo), by_u_range=(lo, hi),
                                row_bytes=row_bytes)
         groups = []
-        if part.n_chunks > 1 and world > 1:
+        if part.n_chunks > 1:
             lv = ppv[q0:q1]
             owner = lv // B
             chunk = (lv % B) // part.chunk_rows
