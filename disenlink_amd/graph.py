@@ -376,10 +376,14 @@ class PairList:
     def build(pu: torch.Tensor, pv: torch.Tensor, n_nodes: int, seg_len: int = DEFAULT_INC_SEG_LEN,
               run_len: int = DEFAULT_RUN_LEN, row_range: tuple[int, int] | None = None,
               n_slices: int | None = None, by_u_range: tuple[int, int] | None = None,
-              build_by_u: bool = True, row_bytes: int = 2048) -> "PairList":
+              build_by_u: bool = True, row_bytes: int = 2048, inc_slices: int | None = None) -> "PairList":
         """``row_range`` restricts the incidence rows to one shard's nodes (the pair ids in ``inc_pair``
         then index prob / g_prob arrays covering the whole pair list); ``by_u_range`` restricts the rows
-        of the forward plan (every pu must lie inside it)."""
+        of the forward plan (every pu must lie inside it).  ``n_slices`` / ``inc_slices``: column slices of the forward
+        plan / of the incidence plan (default: auto_slices, and half of it for the incidence plan — the backward kernels
+        carry more fixed work per wave (staging, partial rows, the unit sum), so they prefer segments twice as long:
+        one-pass training scorer on squirrel 531 -> 497 us at 4 slices instead of 8, chameleon 150 -> 119, Penn94-sized
+        K=8 8.6 -> 6.3 ms at 16 instead of 32, while the forward scorer is fastest at 8 / 8 / 32)."""
         pu = pu.reshape(-1).to(torch.int64)
         pv = pv.reshape(-1).to(torch.int64)
         if pu.numel() != pv.numel():
@@ -387,6 +391,9 @@ class PairList:
         P = pu.numel()
         if n_slices is None:
             n_slices = auto_slices(n_nodes, row_bytes, entries_per_row=P / max(1, len(torch.unique(pu))))
+        if inc_slices is None:
+            forced = os.environ.get("DL_FORCE_INC_SLICES")                # experiments only
+            inc_slices = int(forced) if forced else max(1, n_slices // 2)
         if 2 * P >= 2 ** 31:
             raise ValueError("too many pairs for int32 incidence")
         if P and (int(torch.minimum(pu.min(), pv.min())) < 0 or int(torch.maximum(pu.max(), pv.max())) >= n_nodes):
@@ -394,14 +401,15 @@ class PairList:
         dev = pu.device
         ids = torch.arange(P, device=dev)
 
-        def csr(node, other, pair, lo, hi, seg, unit_segs=UNIT_SEGS):
+        def csr(node, other, pair, lo, hi, seg, unit_segs=UNIT_SEGS, slices=None):
+            slices = n_slices if slices is None else slices
             keep = (node >= lo) & (node < hi)
             node, other, pair = node[keep], other[keep], pair[keep]
             order = torch.argsort((node - lo) * n_nodes + other, stable=True)   # fixed order -> reproducible sums
             rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
             if node.numel():
                 rowptr[1:] = torch.cumsum(torch.bincount(node - lo, minlength=hi - lo), dim=0)
-            plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=n_slices,
+            plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=slices,
                                  unit_segs=unit_segs)
             return plan, _i32(pair[order])
 
@@ -413,7 +421,7 @@ class PairList:
         else:                                              # backward-only list (sharded runs): empty forward plan
             by_u, by_u_pair = csr(pu[:0], pv[:0], ids[:0], 0, 0, run_len, unit_segs=1)
         lo, hi = (0, n_nodes) if row_range is None else row_range
-        inc, inc_pair = csr(torch.cat([pu, pv]), torch.cat([pv, pu]), ids.repeat(2), lo, hi, seg_len)
+        inc, inc_pair = csr(torch.cat([pu, pv]), torch.cat([pv, pu]), ids.repeat(2), lo, hi, seg_len, slices=inc_slices)
         return PairList(n_nodes, _i32(pu), _i32(pv), by_u, by_u_pair, inc, inc_pair)
 
     def c_struct(self, n_pairs_total: int | None = None):

@@ -227,7 +227,10 @@ def test_pair_incidence_lists_every_slot_once():
         for q, v in zip(uid[uptr[u]:uptr[u + 1]], ucol[uptr[u]:uptr[u + 1]]):
             assert pu[q] == u and pv[q] == v
     _check_plan(pl.by_u, uptr, 4, unit_segs=1)
-    assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 8
+    assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 4          # the incidence plan takes half the forward plan's slices
+    both = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=3, run_len=4, n_slices=8, inc_slices=8)
+    assert both.inc.n_slices == 8
+    _check_plan(both.inc, both.inc.rowptr.numpy(), 3)
     from disenlink_amd.graph import auto_slices
     assert auto_slices(5201, 2048, 200) == 8 and auto_slices(2_900_000, 2048, 24) == 1
     assert auto_slices(41608, 2048, 209) == 32 and auto_slices(41608, 2048, 10) == 1
