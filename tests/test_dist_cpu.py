@@ -99,7 +99,7 @@ def _skewed_problem(seed=5, N=90, F=7, K=4, d=8, nhid=5):
     return dict(N=N, F=F, K=K, d=d, nhid=nhid, src=src, dst=dst, x=x, pu=pu, pv=pv, label=label, beta=0.7, t=1.0)
 
 
-@pytest.mark.parametrize("world,n_chunks,skewed", [(2, 1, False), (3, 1, False), (3, 2, False), (4, 3, True)])
+@pytest.mark.parametrize("world,n_chunks,skewed", [(2, 1, False), (3, 1, False), (3, 2, False), (4, 3, True), (8, 2, True)])
 def test_sharded_path_matches_unsharded_oracle(world, n_chunks, skewed):
     """2 / 3 / 4 ranks over gloo, work-balanced blocks (padded to the largest, ids relabelled), with the H all-gather
     blocking (n_chunks = 1) or in asynchronous row chunks with the pairs scored in arrival order."""
@@ -166,6 +166,22 @@ def test_work_balanced_partition_on_hub_skewed_graphs():
                 nnz_eq = np.array([nnz_row[eq.cuts[r]:eq.cuts[r + 1]].sum() for r in range(world)], dtype=np.float64)
                 assert nnz_eq.max() / nnz_eq.mean() > 1.5
     assert dd.balanced_cuts(np.array([1, 1, 100, 1, 1, 1]), 3).tolist() == [0, 2, 3, 6]      # a hub gets its own block
+
+
+def test_partition_edge_cases():
+    """More ranks than nodes, ranks without rows, chunks that do not divide the block, no edges at all."""
+    from disenlink_amd import dist as dd
+    part = dd.Partition.build(3, 8, np.array([0, 1]), np.array([1, 2]), n_chunks=4)
+    assert part.cuts[0] == 0 and part.cuts[-1] == 3 and (np.diff(part.cuts) >= 0).all() and (np.diff(part.cuts) <= 1).all()
+    assert part.block == 4 and part.n_pad == 32 and part.chunk_rows == 1                # block padded up to the chunk count
+    pad = part.to_padded(np.arange(3))
+    assert len(set(pad.tolist())) == 3 and (pad % part.block == 0).all()                # one real row per owning block
+    none = dd.Partition.build(10, 4, np.zeros(0, np.int64), np.zeros(0, np.int64), n_chunks=3)
+    assert none.cuts.tolist() == [0, 2, 5, 7, 10] and none.block == 3                   # equal weights: near-equal blocks
+    sh = dd.Shard.build(5, 8, 3, [0, 1], [1, 2], [0, 1, 2], [2, 0, 1], "cpu", seg_len=4, n_chunks=2)   # a rank that owns nothing
+    r0, r1 = sh.local_real_rows()
+    assert r1 - r0 == 0 and sh.graph.n_edges == 0 and sh.pairs.n_pairs == 0 and sh.hi - sh.lo == sh.part.block
+    assert [int(i.numel()) for i, _ in sh.pair_groups] == [0, 0, 0]
 
 
 def test_partition_helpers():
