@@ -75,9 +75,12 @@ static int check_workspace(const dl_csr_plan* c, int K, int d, void* ws, size_t 
     return DL_OK;
 }
 
+// A usable segment plan: the arrays are there and the position counts are whole workgroups (a workgroup reads the
+// DL_UNIT_SEGS descriptors of its group unconditionally; plans of another layout take the generic kernels instead).
 static bool has_seg_plan(const dl_csr_plan* c) {
     return c->seg_len > 0 && c->seg_len <= DL_WAVE && c->n_seg > 0 && c->seg_row && c->seg_beg && c->seg_end && c->seg_slot &&
            c->n_slices >= 1 && c->slice_seg0 && c->slice_max_seg > 0 &&
+           c->n_seg % DL_UNIT_SEGS == 0 && c->slice_max_seg % DL_UNIT_SEGS == 0 &&
            (c->n_multi == 0 || (c->multi_row && c->multi_slot0));
 }
 

@@ -238,6 +238,54 @@ def test_empty_and_degenerate_inputs():
     np.testing.assert_allclose(dZ.cpu().numpy(), 0.7, rtol=1e-6)
 
 
+@pytest.mark.parametrize("pad_to_workgroups", [False, True])
+def test_plans_of_another_layout_are_still_served_correctly(pad_to_workgroups):
+    """A C caller may hand over a segment plan it built itself.  Row-major segments with one partial slot per SEGMENT
+    (the round-1 layout) are a valid plan: with whole workgroups of positions the tuned kernels treat every segment as its
+    own unit; with a position count that is not a multiple of DL_UNIT_SEGS the API must not let the tuned kernels read
+    past the arrays — it takes the generic kernels.  Either way the results are those of the library's own plan."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import CsrPlan, Graph
+    K, d, N, beta, t, seg_len = 8, 64, 203, 0.6, 1.0, 8
+    src, dst, Zh, _rng = _random_problem(7, N, K, d, 11)
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N, seg_len=seg_len).to(DEV)
+    Z = torch.from_numpy(Zh).to(DEV)
+    p0, a0, s0 = ops.route_fwd(G, Z, t)
+    H0 = ops.aggregate_fwd(G, Z, beta, p0, a0, s0)
+    rowptr = G.rowptr.cpu().numpy()
+    rows, begs, ends = [], [], []
+    for i in range(N):
+        b, e = int(rowptr[i]), int(rowptr[i + 1])
+        for sb in (range(b, e, seg_len) if e > b else [b]):
+            rows.append(i); begs.append(sb); ends.append(min(sb + seg_len, e) if e > b else b)
+    rows, begs, ends = np.array(rows), np.array(begs), np.array(ends)
+    nseg_row = np.bincount(rows, minlength=N)
+    multi = np.flatnonzero(nseg_row > 1)
+    slot0 = np.zeros(multi.size + 1, dtype=np.int64)
+    slot0[1:] = np.cumsum(nseg_row[multi])
+    row_slot0 = -np.ones(N, dtype=np.int64)
+    row_slot0[multi] = slot0[:-1]
+    idx_in_row = np.arange(rows.size) - np.repeat(np.cumsum(nseg_row) - nseg_row, nseg_row)
+    slots = np.where(row_slot0[rows] >= 0, row_slot0[rows] + idx_in_row, -1)
+    if not pad_to_workgroups and rows.size % 4 == 0:               # make the un-padded case really un-aligned: the generic
+        rows, begs, ends, slots = rows[:-1], begs[:-1], ends[:-1], slots[:-1]      # kernels walk rowptr, not the segments
+    if pad_to_workgroups:
+        padn = -rows.size % 4
+        rows, begs, ends, slots = (np.r_[rows, -np.ones(padn, int)], np.r_[begs, np.zeros(padn, int)],
+                                   np.r_[ends, np.zeros(padn, int)], np.r_[slots, -np.ones(padn, int)])
+    i32 = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.int32, device=DEV)
+    plan = CsrPlan(N, 0, N, G.rowptr, G.col, seg_len, i32(rows), i32(begs), i32(ends), i32(slots), 1, int(rows.size),
+                   i32([0, rows.size]), i32(multi), i32(slot0), int(slot0[-1]))
+    assert (plan.n_seg % 4 == 0) == pad_to_workgroups
+    G1 = Graph(plan, None, None, False)
+    p1, a1, s1 = ops.route_fwd(G1, Z, t)
+    H1 = ops.aggregate_fwd(G1, Z, beta, p1, a1, s1)
+    assert torch.equal(p1, p0)
+    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(H1.cpu().numpy(), H0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_exp_overflow_propagates_like_the_reference():
     """No max-subtraction in the softmax (model.py:56-60): huge dots give inf/inf = NaN, as on the CPU."""
     from disenlink_amd import ops
