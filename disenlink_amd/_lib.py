@@ -67,6 +67,7 @@ EXPORTS = {
     "dl_score_pairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _i, _I, _P, _P, _P]),
     "dl_score_allpairs_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dl_score_allpairs_fwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _P, _P, _z, _P]),
+    "dl_score_allpairs_bwd": (_i, [_P, _P, _i, _i, _i, _i, _f, _I, _P, _P, _i, _P, _P, _P, _P, _P, _z, _P]),
     "dl_auc_pair_counts_supported": (_i, [_i, _i]),
     "dl_auc_pair_counts": (_i, [_P, _P, _i, _P, _i, _P, _P]),
     "dl_score_pairs_train_supported": (_i, [_P, _i, _i, _i]),

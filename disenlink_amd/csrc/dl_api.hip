@@ -103,7 +103,7 @@ using namespace dl;
 
 extern "C" {
 
-const char* dl_version(void) { return "disenlink_hip 0.6 (gfx950)"; }
+const char* dl_version(void) { return "disenlink_hip 0.7 (gfx950)"; }
 const char* dl_last_error(void) { return g_err; }
 int dl_has_fast_path(int K, int d) { return fast_supported(K, d, DL_F32) ? 1 : 0; }
 int dl_has_fast_path_dtype(int K, int d, dl_dtype dtype) { return fast_supported(K, d, (int)dtype) ? 1 : 0; }
@@ -313,6 +313,26 @@ int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtyp
     }
     return generic_score_pairs_bwd(inc, (const float*)Z, (const float*)H, K, d, t, prob, g_prob, dZ, dH,
                                    (hipStream_t)stream);
+}
+
+int dl_score_allpairs_bwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
+                          const dl_pair_incidence* inc, const int32_t* pu, const int32_t* pv, int n_pairs,
+                          const float* prob, const float* g_prob, float* dZ, float* dH, void* ws, size_t ws_bytes,
+                          void* stream) {
+    if (int rc = check_shape(K, d)) return rc;
+    DL_REQUIRE(inc != nullptr, "incidence is NULL");
+    const dl_csr_plan* c = &inc->csr;
+    if (int rc = check_plan(c, "incidence")) return rc;
+    DL_REQUIRE(N >= 0 && N <= 46340, "dense [N,N] scoring needs 0 <= N <= 46340, got %d", N);
+    DL_REQUIRE(c->n_total == N, "incidence.n_total=%d != N=%d", c->n_total, N);
+    DL_REQUIRE(n_pairs >= 0 && inc->n_pairs == n_pairs && c->n_entries == 2 * (long long)n_pairs,
+               "the incidence plan must list each of the %d pairs once per endpoint", n_pairs);
+    if (n_pairs > 0) DL_REQUIRE(pu && pv && prob && g_prob, "NULL pair argument");
+    // the gathered vectors use the per-entry scratch of the plan's workspace (2 x n_entries floats >= 2 x n_pairs)
+    Workspace w;
+    if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
+    if (int rc = gather_dense_pairs(pu, pv, N, n_pairs, prob, g_prob, w.dw, w.dwr, (hipStream_t)stream)) return rc;
+    return dl_score_pairs_bwd(Z, H, K, d, dtype, t, inc, w.dw, w.dwr, nullptr, dZ, dH, ws, ws_bytes, stream);
 }
 
 int dl_score_pairs_train_supported(const dl_pair_incidence* inc, int K, int d, dl_dtype dtype) {

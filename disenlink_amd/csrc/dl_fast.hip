@@ -22,6 +22,7 @@
 //
 // Tables Z and H may be stored as fp32 or bf16 (dl_dtype); all arithmetic and all gradients are fp32.
 #include <stdlib.h>
+#include <string.h>
 #include "dl_common.h"
 #include "dl_kernels.h"
 
@@ -307,15 +308,54 @@ __device__ __forceinline__ int dpp_move_i(int v) {
     return __builtin_amdgcn_update_dpp(-1, v, CTRL, 0xF, 0xF, false);     // lanes shifted in from outside the row keep -1
 }
 
+//
+// Rows of SEVERAL units (slot >= 0; more than DL_UNIT_SEGS segments) are not summed from their units at all (round 2
+// wrote one partial per unit and launched a combine kernel for a handful of rows: 5 us of launch for microseconds of
+// work): the workgroups behind the first n_reg_blocks take one such row per WAVE — lane l adds the entries l, l + 64,
+// ... of the row in order (loads in batches of four), then the 64 lanes are added by the wave butterfly.  One launch;
+// the order depends on the row alone.
 template <int KP>
 __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, int K, const uint8_t* __restrict__ p,
                                                                 const float* __restrict__ a, float* __restrict__ s,
-                                                                float* __restrict__ s_part) {
+                                                                int n_reg_blocks) {
+    if ((int)blockIdx.x >= n_reg_blocks) {
+        const int m = ((int)blockIdx.x - n_reg_blocks) * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
+        if (m >= g.n_multi) return;
+        const int lane = lane_id();
+        const int row = g.multi_row[m];
+        const int beg = g.rowptr[row], end = g.rowptr[row + 1];
+        float acc[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[k] = 0.0f;
+        for (int e = beg + lane; e < end; e += 4 * DL_WAVE) {
+            int k[4];
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(e + j * DL_WAVE, end - 1);
+                k[j] = e + j * DL_WAVE < end ? (int)p[i] : 255;
+                v[j] = a[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kk = 0; kk < KP; ++kk) acc[kk] += k[j] == kk ? v[j] : 0.0f;
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) {
+            const float tot = wave_allreduce_sum(acc[kk]);
+            if (lane == kk) mine = tot;
+        }
+        if (lane < K) s[((size_t)row + g.row_offset) * K + lane] = mine;
+        return;
+    }
     const int seg = blockIdx.x * ROWSUM_POS_PER_BLOCK + (int)(threadIdx.x / ROWSUM_SUB);
     const int sub = threadIdx.x % ROWSUM_SUB;
     const int row = seg < g.n_seg ? g.seg_row[seg] : -1;
     int beg = 0, end = 0, slot = -1;
     if (row >= 0) { beg = g.seg_beg[seg]; end = g.seg_end[seg]; slot = g.seg_slot[seg]; }
+    if (slot >= 0) beg = end = 0;                                 // a row of several units: summed by its own wave (above)
     float acc[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) acc[k] = 0.0f;
@@ -355,8 +395,8 @@ __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, i
         tot[kk] += ok2 ? v2 : 0.0f;
         tot[kk] += ok3 ? v3 : 0.0f;
     }
-    if (!head || sub != 0) return;
-    float* dst = slot < 0 ? s + ((size_t)row + g.row_offset) * K : s_part + (size_t)slot * K;
+    if (!head || sub != 0 || slot >= 0) return;
+    float* dst = s + ((size_t)row + g.row_offset) * K;
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk)
         if (kk < K) dst[kk] = tot[kk];
@@ -454,6 +494,139 @@ __global__ __launch_bounds__(BLOCK, (K * Tab<T>::VEC <= 32 && U <= 2) ? 8 : 1) v
                 const float4 z = load4<T>(Z + o);
                 store4(H + o, make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
                                           beta * z.w + omb * r[q].w));
+            } else {
+                store4(h_part + (size_t)si.slot * ROW + 4 * x, r[q]);
+            }
+        }
+    }
+}
+
+// Bits of m below this lane.
+__device__ __forceinline__ int bits_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Aggregation with CLASS-OWNED accumulators (round 3).  The kernel above lets every lane group take every G-th entry,
+// so each group needs an accumulator for every factor: K * VEC registers per lane, K * VEC FMAs + K selects per gathered
+// entry to add it to the one accumulator of its factor (40 of the ~55 vector instructions per entry at K = 8), a
+// cross-group butterfly at the end — and at 8 waves per SIMD the K = 8 instantiation spilled 4 registers per lane
+// (1 KB of scratch written and read back per WAVE: the 0.8 GB of unexplained WRITE_SIZE per launch at snap-patents
+// size, profiles/r2q).  Here the entries of a segment are sorted by CLASS = factor % NC first (NC = min(K, groups per
+// wave); ballots + a bit count give every entry its slot, the sorted (column, factor, weight) triples live in LDS) and
+// group g walks the entries of class g: a lane accumulates only the factors g, g + NC, ... — ACC = K / NC accumulators
+// (2 at K = 8, d = 64) — and every (factor, chunk) of the result row is owned by exactly one lane of the wave: no
+// cross-group sum, the lane stores its chunks straight into the wave's staged row.  Inside a (segment, factor) the
+// entries are added in ascending entry order by ONE lane group, whatever the lane geometry: the summation order depends
+// on the row alone.  Cost: the walk takes max_g |class g| steps instead of |segment| / groups (a segment routed entirely
+// to one factor is walked by one group).
+template <int K, int D, typename T, int U>
+__global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
+                                                              const uint8_t* __restrict__ p,
+                                                              const float* __restrict__ a,
+                                                              const float* __restrict__ s, T* __restrict__ H,
+                                                              float* __restrict__ h_part) {
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC, G = GE::G, NG = GE::EPW, ROW = GE::ROW;
+    constexpr int NC = K < NG ? K : NG;                           // classes = lane groups at work
+    constexpr int ACC = (K + NC - 1) / NC;                        // factors per class
+    using US = Stage<K, D, T, 1>;
+    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
+    __shared__ int ent_col[WAVES_PER_BLOCK][DL_WAVE];
+    __shared__ int ent_k[WAVES_PER_BLOCK][DL_WAVE];
+    __shared__ float ent_w[WAVES_PER_BLOCK][DL_WAVE];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
+    const int lane = lane_id();
+    const int c = lane % G, grp = lane / G;
+    // the row's own z is needed last, by the head wave of a single-unit row only: fetched first
+    const bool direct = ws.head && si.slot < 0;
+    float4 zrow[US::NQ];
+    if (direct) {
+#pragma unroll
+        for (int q = 0; q < US::NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            if (x < US::F4) zrow[q] = load4<T>(Z + (size_t)si.grow * ROW + 4 * x);
+        }
+    }
+    if (ws.active) {
+        const int cnt = si.end - si.beg;
+        const bool mine = lane < cnt;
+        int my_col = si.grow, my_k = 0;
+        float my_a = 0.0f, my_s = 1.0f;
+        if (mine) {
+            my_col = g.col[si.beg + lane];
+            my_k = p[si.beg + lane];
+            my_a = a[si.beg + lane];
+        }
+        // the neighbour's normaliser stays in flight while the entries are sorted and the first row gathers go out
+        if (mine) my_s = s[(size_t)my_col * K + my_k];
+        const int cls = my_k % NC;
+        int pos = 0, my_off = 0, my_cnt = 0, run = 0, trip = 0;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const unsigned long long m = __ballot(mine && cls == cc);
+            const int n = __popcll(m);
+            if (cls == cc) pos = run + bits_below(m);
+            if (grp == cc) { my_off = run; my_cnt = n; }
+            run += n;
+            trip = n > trip ? n : trip;
+        }
+        int* wcol = ent_col[ws.wave];
+        int* wk = ent_k[ws.wave];
+        float* ww = ent_w[ws.wave];
+        if (mine) { wcol[pos] = my_col; wk[pos] = my_k; }
+        __builtin_amdgcn_wave_barrier();
+        Chunk<VEC> acc[ACC];
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) acc[i] = zero_chunk<VEC>();
+        for (int it = 0; it < trip; it += U) {
+            Chunk<VEC> v[U];
+            int kx[U], ix[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = it + u < my_cnt;
+                ix[u] = live ? my_off + it + u : -1;
+                const int sl = live ? my_off + it + u : 0;        // trip > 0: slot 0 holds a real entry
+                const int j = wcol[sl];
+                kx[u] = wk[sl];
+                v[u] = Tab<T>::load(Z + (size_t)j * ROW + kx[u] * D + c * VEC);
+            }
+            if (it == 0) {                                        // weights: behind the first batch of gathers
+                if (mine) ww[pos] = my_a / one_if_zero(my_s);
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ix[u] >= 0) {
+                    const float w = ww[ix[u]];
+                    const int li = kx[u] / NC;
+#pragma unroll
+                    for (int i = 0; i < ACC; ++i)
+                        if (ACC == 1 || i == li) fma_chunk(acc[i], w, v[u]);
+                }
+            }
+        }
+        float* row = US::region(red, ws.wave);
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) {
+            const int k = i * NC + grp;
+            if (grp < NC && k < K) store_f32<VEC>(row + k * D + c * VEC, acc[i]);
+        }
+    }
+    __syncthreads();
+    if (!ws.head) return;
+    float4 r[US::NQ];
+    US::sum(red, ws.wave, ws.n_unit, lane, r);
+    const float omb = 1.0f - beta;
+#pragma unroll
+    for (int q = 0; q < US::NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < US::F4) {
+            if (direct) {
+                const float4 z = zrow[q];
+                store4(H + (size_t)si.grow * ROW + 4 * x,
+                       make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
+                                   beta * z.w + omb * r[q].w));
             } else {
                 store4(h_part + (size_t)si.slot * ROW + 4 * x, r[q]);
             }
@@ -1046,14 +1219,14 @@ static inline int pow2_at_least(int k) {
     return p;
 }
 
-static void launch_s_rowsum(const dl_csr_plan* g, int K, const uint8_t* p, const float* a, float* s, float* s_part,
-                            hipStream_t st) {
+static void launch_s_rowsum(const dl_csr_plan* g, int K, const uint8_t* p, const float* a, float* s, hipStream_t st) {
     if (g->n_seg <= 0) return;
-    const dim3 grid((unsigned)((g->n_seg + ROWSUM_POS_PER_BLOCK - 1) / ROWSUM_POS_PER_BLOCK)), block(BLOCK);
-    if (K <= 4) hipLaunchKernelGGL(s_rowsum_thread_kernel<4>, grid, block, 0, st, *g, K, p, a, s, s_part);
-    else if (K <= 8) hipLaunchKernelGGL(s_rowsum_thread_kernel<8>, grid, block, 0, st, *g, K, p, a, s, s_part);
-    else if (K <= 16) hipLaunchKernelGGL(s_rowsum_thread_kernel<16>, grid, block, 0, st, *g, K, p, a, s, s_part);
-    else hipLaunchKernelGGL(s_rowsum_thread_kernel<32>, grid, block, 0, st, *g, K, p, a, s, s_part);   // tuned shapes: K <= 32
+    const int reg = (g->n_seg + ROWSUM_POS_PER_BLOCK - 1) / ROWSUM_POS_PER_BLOCK;
+    const dim3 grid((unsigned)reg + wave_blocks(g->n_multi)), block(BLOCK);
+    if (K <= 4) hipLaunchKernelGGL(s_rowsum_thread_kernel<4>, grid, block, 0, st, *g, K, p, a, s, reg);
+    else if (K <= 8) hipLaunchKernelGGL(s_rowsum_thread_kernel<8>, grid, block, 0, st, *g, K, p, a, s, reg);
+    else if (K <= 16) hipLaunchKernelGGL(s_rowsum_thread_kernel<16>, grid, block, 0, st, *g, K, p, a, s, reg);
+    else hipLaunchKernelGGL(s_rowsum_thread_kernel<32>, grid, block, 0, st, *g, K, p, a, s, reg);   // tuned shapes: K <= 32
 }
 
 static void launch_vec_combine(const dl_csr_plan* g, int K, const float* part, int mode, const float* s_raw,
@@ -1078,25 +1251,24 @@ struct Ops {
         else
             hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
                                (const T*)Z, t, p, a);
-        launch_s_rowsum(g, K, p, a, s, s_part, st);
-        launch_vec_combine(g, K, s_part, 0, nullptr, s, st);
+        (void)s_part;
+        launch_s_rowsum(g, K, p, a, s, st);
         return check_launch("route_fwd(fast)");
     }
 
     static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
                              const float* s, void* H, float* h_part, hipStream_t st) {
-        const int unroll = getenv("DL_AGG_UNROLL") ? atoi(getenv("DL_AGG_UNROLL")) : 2;      // experiments
-        if (unroll >= 8)
-            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 8>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                               beta, p, a, s, (T*)H, h_part);
-        else if (unroll >= 4)
-            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                               beta, p, a, s, (T*)H, h_part);
-        else if (unroll >= 2)
+        // DL_AGG_FORM=groups selects the round-2 kernel (every group walks every G-th entry) for A/B timing
+        static const bool old_form = getenv("DL_AGG_FORM") && !strcmp(getenv("DL_AGG_FORM"), "groups");
+        static const int depth = getenv("DL_AGG_DEPTH") ? atoi(getenv("DL_AGG_DEPTH")) : 4;
+        if (old_form)
             hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 2>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
                                beta, p, a, s, (T*)H, h_part);
+        else if (depth >= 4)
+            hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                               beta, p, a, s, (T*)H, h_part);
         else
-            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 1>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+            hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 2>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
                                beta, p, a, s, (T*)H, h_part);
         if (g->n_multi > 0)
             hipLaunchKernelGGL((row_combine_kernel<ROW, T, T>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, ROW,

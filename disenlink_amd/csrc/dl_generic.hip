@@ -287,6 +287,31 @@ int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int
     return check_launch("score_allpairs_fwd(generic)");
 }
 
+namespace generic {
+// prob / g_prob of the dense [N][N] scorer at the listed pairs (the caller's loss entries): the front end of
+// dl_score_allpairs_bwd.  One thread per pair; the two 4-byte reads per pair are scattered by nature.
+__global__ __launch_bounds__(BLOCK) void gather_dense_pairs_kernel(const int32_t* __restrict__ pu,
+                                                                   const int32_t* __restrict__ pv, int N, int P,
+                                                                   const float* __restrict__ prob,
+                                                                   const float* __restrict__ g_prob,
+                                                                   float* __restrict__ prob_q, float* __restrict__ g_q) {
+    const int q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= P) return;
+    const size_t o = (size_t)pu[q] * N + pv[q];
+    prob_q[q] = prob[o];
+    g_q[q] = g_prob[o];
+}
+
+}  // namespace generic
+
+int gather_dense_pairs(const int32_t* pu, const int32_t* pv, int N, int P, const float* prob, const float* g_prob,
+                       float* prob_q, float* g_q, hipStream_t st) {
+    if (P == 0) return DL_OK;
+    hipLaunchKernelGGL(generic::gather_dense_pairs_kernel, dim3((unsigned)((P + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
+                       pu, pv, N, P, prob, g_prob, prob_q, g_q);
+    return check_launch("gather_dense_pairs");
+}
+
 int generic_score_pairs_bwd(const dl_pair_incidence* inc, const float* Z, const float* H, int K, int d, float t,
                             const float* prob, const float* g_prob, float* dZ, float* dH, hipStream_t st) {
     if (int rc = check_lds(K, d, 2)) return rc;

@@ -41,6 +41,10 @@ int fast_score_pairs_bwd(const dl_pair_incidence* inc, const void* Z, const void
                          float t, const float* prob, const float* g_prob, const float* coef, float* dZ, float* dH,
                          float* part, hipStream_t st);
 
+// prob / g_prob of the dense [N][N] scorer at the listed pairs (dl_generic.hip)
+int gather_dense_pairs(const int32_t* pu, const int32_t* pv, int N, int P, const float* prob, const float* g_prob,
+                       float* prob_q, float* g_q, hipStream_t st);
+
 int fast_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, int dtype, float t, float* prob,
                             hipStream_t st);
 int generic_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob,

@@ -173,15 +173,42 @@ class Disentangle(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_graph_cache"] = None              # holds a weak reference: not copyable / picklable, and only a cache
-        state["_dense_plan"] = ops.DensePairPlanCache()
-        state["_dense_plan"].static = self._dense_plan.static
+        state["_dense_plan"] = ops.DensePairPlanCache()     # a copy starts without a plan (declare the masks again)
         return state
 
-    def assume_static_loss_masks(self, static: bool = True):
-        """The caller promises that the entries of link_pred it takes a loss on are the same every step (the reference's
-        masks are built once per run, main_disentangled.py:167-190).  The backward of the dense [N,N] output then
-        validates its cached pair plan on the device instead of reading two counters back every step: no host sync at
-        all; should the promise be broken the gradients come out NaN, not wrong (ops.DensePairPlanCache)."""
+    def set_loss_pairs(self, *supports, n_nodes: int | None = None):
+        """Declare where the caller takes its loss on the dense ``link_pred`` of ``forward(x, adj)``: dense [N,N] masks
+        (the reference's ``pos_train_adj``, ``neg_train_adj``; entries != 0 count, main_disentangled.py:167-190) and / or
+        ``(rows, cols)`` index tuples (then give ``n_nodes`` unless a mask comes along).  Their union becomes the pair
+        plan of the dense backward (dl_score_allpairs_bwd), built once, on the module's device.  Without it the plan is
+        learnt from the gradients (it grows until it covers the masks; ops.DensePairPlanCache).
+        ``set_loss_pairs()`` with no argument forgets a declared set."""
+        if not supports:
+            self._dense_plan.clear()
+            return self
+        for sup in supports:
+            if torch.is_tensor(sup) and sup.dim() == 2 and n_nodes is None:
+                n_nodes = sup.shape[0]
+        if n_nodes is None:
+            raise ValueError("index pairs alone do not say how many nodes there are: pass n_nodes=")
+        self._dense_plan.set_pairs(int(n_nodes), next(self.parameters()).device, *supports)
+        return self
+
+    def assume_static_loss_masks(self, *masks, static: bool = True):
+        """``assume_static_loss_masks(pos_train_adj, neg_train_adj)``: the caller promises that every step's loss is
+        taken inside these masks (the reference builds them once per run, main_disentangled.py:167-190).  The dense
+        backward then runs on their support without any host read: the subset check "no gradient outside the plan"
+        stays on the device and turns the gradients into NaN — not into something silently wrong — should the promise
+        be broken.  The masks are REQUIRED (here or through set_loss_pairs before): the support of a loss cannot be
+        inferred from a gradient, whose non-zero set moves with fp32 sigmoid saturation.
+        ``assume_static_loss_masks(static=False)`` returns to the validated mode (one 16-byte read per backward)."""
+        if len(masks) == 1 and isinstance(masks[0], bool):        # round-2 spelling: assume_static_loss_masks(False)
+            static, masks = masks[0], ()
+        if masks:
+            self.set_loss_pairs(*masks)
+        if static and not self._dense_plan.from_masks:
+            raise ValueError("assume_static_loss_masks needs the loss masks: assume_static_loss_masks(pos_train_adj, "
+                             "neg_train_adj), or call set_loss_pairs(...) first")
         self._dense_plan.static = bool(static)
         return self
 

@@ -660,49 +660,119 @@ class ScorePairs(torch.autograd.Function):
 
 
 class DensePairPlanCache:
-    """Pair plan of the entries of the dense [N,N] score gradient that are non-zero — owned by ONE module (no process-wide
-    state).  The reference's caller indexes link_pred with masks that are fixed for a run (main_disentangled.py:134-190),
-    so the set repeats every epoch; autograd only hands the backward the dense gradient, not the masks, so whether the
-    cached set still applies has to be read off the gradient itself:
+    """Pair plan of the dense [N,N] score gradient's support — owned by ONE module (no process-wide state).
 
-      * default: one 16-byte device->host read per backward validates the cache (count of non-zeros, count of non-zeros
-        at the cached positions); a changed set rebuilds the plan.  (The reference's own loop reads back the validation
-        scores and the loss every epoch, main_disentangled.py:204,214.)
-      * ``static=True`` (Disentangle.assume_static_loss_masks()): no host read.  The same two counts stay on the device and
-        become a validity factor — 1 if the cache applies, NaN if it does not — multiplied into the gradients: a caller
-        that promised fixed masks and changed them gets NaN gradients at once, never silently wrong ones."""
+    The reference's caller takes its loss on ``link_pred[mask == 1]`` with masks that are fixed for a run
+    (main_disentangled.py:167-190,195), so d loss / d link_pred can be non-zero only on the masks' support.  The plan
+    must be keyed on THAT support, not on the entries of the gradient that happen to be non-zero: a saturated positive
+    (p == 1.0 in fp32, y == 1) has exactly zero BCE gradient in one epoch and a non-zero one in the next (SURVEY.md §0
+    finding 4), so the gradient's non-zero set moves under fixed masks.
+
+      * ``set_pairs(masks ...)`` (Disentangle.set_loss_pairs / assume_static_loss_masks(mask, ...)): the plan IS the
+        support of the caller's masks; entries whose gradient is zero cost a little arithmetic and add exactly zero.
+      * no masks given: the plan is learnt from the gradients and only ever GROWS — a backward whose non-zero entries
+        are not all inside the cached set extends it by the new ones (union) and rebuilds; it never shrinks to the
+        current non-zero set.  Once every masked entry has carried gradient the plan is the masks' support.
+      * validation: non-zeros(g) must be a SUBSET of the plan.  Default: two device counters are read back per backward
+        (one 16-byte host read; the reference's own loop reads back the validation scores and the loss every epoch,
+        main_disentangled.py:204,214).  ``static=True`` (needs masks): no host read — the same two counters stay on
+        the device and become a validity factor, 1 if the subset relation holds, NaN if not, multiplied into the
+        gradients: a caller that promised fixed masks and takes a loss elsewhere gets NaN gradients at once, never
+        silently wrong ones."""
 
     def __init__(self):
         self.pairs = None        # PairList of the cached index set
-        self.flat = None         # int64 [n] row-major positions
+        self.flat = None         # int64 [n] row-major positions, ascending
         self.key = None          # (N, device)
         self.static = False
+        self.from_masks = False  # the set is the caller's declared support (never extended behind their back)
 
+    # ---- the caller's declared support
+    def set_pairs(self, N: int, device, *supports):
+        """``supports``: dense [N,N] masks (entries != 0 belong to the support: the caller's summed train masks hold
+        2, 3, ... where index pairs repeat, main_disentangled.py:176-179 — those entries are outside the loss and get
+        zero gradient, which is harmless here) and / or (rows, cols) index tuples.  The plan is the union."""
+        flats = []
+        for sup in supports:
+            if isinstance(sup, (tuple, list)):
+                r, c = (torch.as_tensor(v, device=device).reshape(-1).long() for v in sup)
+                if r.numel() != c.numel():
+                    raise ValueError("(rows, cols) differ in length")
+                if r.numel() and (int(r.min()) < 0 or int(c.min()) < 0 or int(r.max()) >= N or int(c.max()) >= N):
+                    raise ValueError("pair index outside [0, N)")
+                flats.append(r * N + c)
+            else:
+                m = torch.as_tensor(sup, device=device)
+                if m.dim() != 2 or m.shape[0] != N or m.shape[1] != N:
+                    raise ValueError(f"a loss mask must be [N, N] = [{N}, {N}], got {tuple(m.shape)}")
+                flats.append(torch.nonzero(m.reshape(-1)).reshape(-1))
+        if not flats:
+            raise ValueError("no loss masks / pairs given")
+        self._install(torch.unique(torch.cat(flats)), N, device)
+        self.from_masks = True
+
+    def clear(self):
+        self.pairs = self.flat = self.key = None
+        self.from_masks = False
+
+    def _install(self, flat: torch.Tensor, N: int, device):
+        self.flat = flat
+        self.pairs = PairList.build(torch.div(flat, N, rounding_mode="floor"), flat % N, N)
+        self.key = (N, device)
+
+    # ---- per backward
     def lookup(self, g_prob: torch.Tensor):
-        """-> (pairs, flat, validity factor or None)"""
+        """-> (pairs, validity factor or None)"""
         N = g_prob.shape[0]
         g_flat = g_prob.reshape(-1)
         key = (N, g_prob.device)
-        if self.pairs is not None and self.key == key:
-            n = self.flat.numel()
-            probe = torch.stack([torch.count_nonzero(g_flat), torch.count_nonzero(g_flat[self.flat])])
+        if self.pairs is not None and self.key != key:
+            if self.from_masks:
+                raise ValueError(f"the loss pairs were declared for {self.key}, the gradient is for {key}")
+            self.clear()
+        if self.pairs is None:
             if self.static:
-                ok = (probe[0] == n) & (probe[1] == n)
-                return self.pairs, self.flat, torch.where(ok, 1.0, float("nan")).to(torch.float32)
-            cnt, kept = probe.tolist()
-            if cnt == n and kept == n:
-                return self.pairs, self.flat, None
-        nz = torch.nonzero(g_prob)
-        self.pairs = PairList.build(nz[:, 0], nz[:, 1], N)
-        self.flat = nz[:, 0] * N + nz[:, 1]
-        self.key = key
-        return self.pairs, self.flat, None
+                raise RuntimeError("assume_static_loss_masks() needs the masks (or index pairs) the loss is taken on: "
+                                   "the support of a loss cannot be read off one gradient")
+            self._install(torch.nonzero(g_flat).reshape(-1), N, g_prob.device)
+            return self.pairs, None
+        # non-zeros(g) inside the plan == non-zeros(g) anywhere  <=>  subset
+        probe = torch.stack([torch.count_nonzero(g_flat), torch.count_nonzero(g_flat[self.flat])])
+        if self.static:
+            return self.pairs, torch.where(probe[0] == probe[1], 1.0, float("nan")).to(torch.float32)
+        cnt, kept = probe.tolist()
+        if cnt != kept:
+            if self.from_masks:
+                raise RuntimeError(f"{cnt - kept} entries of d loss / d link_pred lie outside the declared loss pairs "
+                                   "(Disentangle.set_loss_pairs): declare every mask the loss indexes link_pred with")
+            self._install(torch.unique(torch.cat([self.flat, torch.nonzero(g_flat).reshape(-1)])), N, g_prob.device)
+        return self.pairs, None
+
+
+def score_allpairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob):
+    """-> dZ, dH f32[N,K,d]: backward of score_allpairs_fwd on the fixed pair plan ``pairs`` (the support of the
+    caller's loss masks); prob and g_prob are the dense [N,N] arrays."""
+    lib = _lib.load()
+    (Z, dt), (H, _dth), prob, g_prob = _tab(Z), _tab(H), _f32c(prob), _f32c(g_prob)
+    _need_cuda(Z, H, prob, g_prob, pairs.inc.rowptr)
+    N, K, d = _nkd(Z)
+    if tuple(prob.shape) != (N, N) or tuple(g_prob.shape) != (N, N):
+        raise ValueError("prob / g_prob must be the dense [N, N] arrays")
+    dZ = _empty(Z.shape, torch.float32, Z.device)
+    dH = _empty(Z.shape, torch.float32, Z.device)
+    P = pairs.n_pairs
+    ws = _workspace(pairs.c_plan(), Z.device, K, d)
+    _lib.check(lib.dl_score_allpairs_bwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), pairs.c_struct(P),
+                                         pairs.pu.data_ptr(), pairs.pv.data_ptr(), P, prob.data_ptr(), g_prob.data_ptr(),
+                                         dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "dl_score_allpairs_bwd")
+    return dZ, dH
 
 
 class ScoreAllPairs(torch.autograd.Function):
     """(Z, H) -> prob [N,N], the dense output the reference's caller indexes with masks
-    (main_disentangled.py:195).  Backward scores only the entries whose gradient is non-zero (``cache``: the calling
-    module's DensePairPlanCache)."""
+    (main_disentangled.py:195).  Backward: dl_score_allpairs_bwd on the pair plan of ``cache`` (the calling module's
+    DensePairPlanCache: the support of the caller's loss masks)."""
 
     @staticmethod
     def forward(ctx, Z, H, t: float, cache: "DensePairPlanCache | None" = None):
@@ -716,9 +786,8 @@ class ScoreAllPairs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_prob):
         Z, H, prob = ctx.saved_tensors
-        pairs, flat, valid = ctx.cache.lookup(g_prob)
-        dZ, dH = score_pairs_bwd(Z, H, pairs, ctx.t, prob.reshape(-1)[flat].contiguous(),
-                                 g_prob.reshape(-1)[flat].contiguous())
+        pairs, valid = ctx.cache.lookup(g_prob)
+        dZ, dH = score_allpairs_bwd(Z, H, pairs, ctx.t, prob, g_prob)
         if valid is not None:
             dZ, dH = dZ * valid, dH * valid
         return dZ, dH, None, None

@@ -229,13 +229,30 @@ int dl_score_pairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dty
  * fp32 [N][N]), the link_pred the reference's caller indexes with dense masks (main_disentangled.py:195).
  * No pair list is materialised.  fp32 tables with d % 32 == 0 go to the matrix cores (two Gram products per
  * factor, six exact bf16 products per term from three bf16 planes per operand; only the tile pairs u <= v are computed and mirrored: prob is symmetric bit for bit);
- * other shapes use the vector kernels.  Its backward is dl_score_pairs_bwd over the entries whose gradient is
- * non-zero (the masked ones).  N*N must stay below 2^31: N <= 46340.
+ * other shapes use the vector kernels.  Its backward is dl_score_allpairs_bwd over the support of the caller's
+ * loss masks.  N*N must stay below 2^31: N <= 46340.
  * ws (optional, dl_score_allpairs_workspace_bytes): the bf16 planes of Z and H, split once per call; without it
  * (NULL / too small) every tile pair splits the rows it stages — same result bit for bit, slower. */
 size_t dl_score_allpairs_workspace_bytes(int N, int K, int d, dl_dtype dtype);
 int dl_score_allpairs_fwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
                           float* prob, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of dl_score_allpairs_fwd (autograd of model.py:109-113 + sigmoid under main_disentangled.py:195-198) on a
+ * FIXED pair plan: the reference's caller takes its loss on link_pred[mask == 1] with masks built once per run
+ * (main_disentangled.py:167-190), so d loss / d link_pred can be non-zero only on the masks' support.  The caller
+ * hands that support over ONCE as a pair list (pu, pv) with its incidence plan `inc` (the one dl_score_pairs_bwd
+ * takes; inc->n_pairs = n_pairs) and every step the dense prob [N][N] of the forward and the dense gradient
+ * g_prob [N][N] autograd produced; the call reads both at the listed entries and writes
+ *   dZ, dH = sum over the listed (u,v) of the scorer's backward terms (see dl_score_pairs_bwd),
+ * for the plan's rows.  Entries of g_prob OUTSIDE the list are not read: the plan must cover every entry that can
+ * carry gradient (keying the plan on the gradient's non-zero entries instead is wrong — a saturated positive,
+ * p == 1.0 with y == 1, has exactly zero BCE gradient one epoch and a non-zero one the next).  Listed entries whose
+ * gradient happens to be zero add exactly zero.  ws: dl_workspace_bytes(&inc->csr, K, d) — the gathered
+ * prob / g_prob vectors live in it. */
+int dl_score_allpairs_bwd(const void* Z, const void* H, int N, int K, int d, dl_dtype dtype, float t,
+                          const dl_pair_incidence* inc, const int32_t* pu, const int32_t* pv, int n_pairs,
+                          const float* prob, const float* g_prob, float* dZ, float* dH,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* Tie-averaged AUC of a score vector against FIXED labels: replaces sklearn.metrics.roc_auc_score at
  * main_disentangled.py:202-204 / 217-219 (validation AUC every epoch, test AUC at the end).  pos_idx / neg_idx

@@ -218,6 +218,47 @@ def run_trajectory(model_mod, spec, seed):
     print(f"{name}: losses {losses[0]:.5f} -> {losses[-1]:.5f}, val auc {aucs[0]:.4f} -> {max(aucs):.4f}, test auc {test_auc:.4f}")
 
 
+ADAM = [("k4_d8", 12, 1e-2), ("k5_d64", 12, 1e-2)]      # (committed case, Adam steps, lr)
+
+
+def run_adam_steps(model_mod, case, steps, lr):
+    """Fixed masks, several optimiser steps (main_disentangled.py:150,194-199 around the reference model, from a
+    committed case's inputs and weights).  Pins what one forward / backward cannot: the set of entries of
+    d loss / d link_pred that are non-zero MOVES from step to step under fixed masks — a saturated positive (p == 1.0 in
+    fp32, y == 1) has exactly zero BCE gradient until the weights move it out of saturation (SURVEY.md §0 finding 4) — so
+    a backward keyed on the gradient's non-zero set instead of the masks goes wrong from the second step on.  Stored:
+    per-step loss, per-step count of non-zero gradient entries (nnz_grad) and of masked entries (n_masked), the
+    gradients of the LAST step and the weights after it."""
+    g = dict(np.load(os.path.join(OUT, f"case_{case}.npz"), allow_pickle=False))
+    m = json.loads(str(g["meta"]))
+    model = model_mod.Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
+    model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")})
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=5e-4)
+    x, adj, ori = (torch.from_numpy(g[k]) for k in ("x", "adj", "ori_adj"))
+    pm, nm = torch.from_numpy(g["pos_mask"]) == 1, torch.from_numpy(g["neg_mask"]) == 1
+    losses, nnz = [], []
+    for _ in range(steps):
+        _emb, a_pred = model(x, adj)
+        a_pred.retain_grad()
+        loss = (F.binary_cross_entropy(a_pred[pm].unsqueeze(0), ori[pm].unsqueeze(0))
+                + F.binary_cross_entropy(a_pred[nm].unsqueeze(0), ori[nm].unsqueeze(0)) / m["m"])
+        opt.zero_grad()
+        loss.backward()
+        losses.append(loss.item())
+        nnz.append(int(torch.count_nonzero(a_pred.grad)))
+        last = {k: prm.grad.detach().numpy().copy() for k, prm in model.named_parameters()}
+        opt.step()
+    out = dict(losses=np.array(losses, np.float64), nnz_grad=np.array(nnz, np.int64),
+               n_masked=np.int64(int((pm | nm).sum())),
+               meta=np.array(json.dumps(dict(case=case, steps=steps, lr=lr, weight_decay=5e-4))))
+    for k, v in last.items():
+        out["grad__" + k] = v
+    for k, v in model.state_dict().items():
+        out["sd__" + k] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"adam_{case}.npz"), **out)
+    print(f"adam_{case}: losses {losses[0]:.6f} -> {losses[-1]:.6f}; non-zero gradient entries per step {nnz} of {int(out['n_masked'])} masked")
+
+
 def auc_cases():
     from sklearn.metrics import roc_auc_score
     rng = np.random.default_rng(7)
@@ -238,13 +279,16 @@ def main():
     sys.path.insert(0, REF)
     import model as model_mod  # the reference's model.py
     torch.set_num_threads(1)
-    only_traj = "--trajectories-only" in sys.argv             # the case_* / auc_* files are already committed
+    only_traj = "--trajectories-only" in sys.argv or "--adam-only" in sys.argv   # the case_* / auc_* files are already committed
     if not only_traj:
         for idx, spec in enumerate(CASES):
             run_case(model_mod, spec, seed=100 + idx)
         auc_cases()
-    for idx, spec in enumerate(TRAJ):
-        run_trajectory(model_mod, spec, seed=300 + idx)
+    if "--adam-only" not in sys.argv:
+        for idx, spec in enumerate(TRAJ):
+            run_trajectory(model_mod, spec, seed=300 + idx)
+    for case, steps, lr in ADAM:
+        run_adam_steps(model_mod, case, steps, lr)
 
 
 if __name__ == "__main__":
