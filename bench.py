@@ -51,7 +51,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: dense bf16 MFMA
 # kernels launched by each phase of the step (names as rocprofv3 reports them, template arguments stripped)
 PHASE_KERNELS = {"route": ("route_seg_kernel", "s_rowsum_thread_kernel", "vec_combine_kernel"),
-                 "aggregate": ("aggregate_seg_kernel", "aggregate_wg_kernel", "row_combine_kernel"),
+                 "aggregate": ("aggregate_cls_kernel", "aggregate_seg_kernel", "row_combine_kernel"),
                  "score": ("score_fwd_seg_kernel",)}
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 NAMES = ("route", "aggregate", "score")
@@ -113,7 +113,7 @@ def moved_bytes(graph, pairs, K, d, w=4):
     mirror = 2 if graph.route_mirror else 1
     route = (walked * (row + 4 + (4 if graph.route_mirror else 0)) + mirror * walked * 5      # gathers, col, rev; p, a out
              + n_rseg * (row + 16)                                                              # z_i + descriptor
-             + E * 5 + plan.n_seg * 16 + N * K * 4 + plan.n_slots * K * 8)                      # row sums of (p, a) -> s
+             + E * 5 + plan.n_seg * 16 + N * K * 4)                                             # row sums of (p, a) -> s
     aggregate = (E * (d * w + 4 + 1 + 4 + 4) + plan.n_seg * 16                                  # slice gather, col, p, a, s[col]
                  + N * 2 * row                                                                  # z_i in, h_i out
                  + plan.n_slots * K * d * 4 * 2)                                                # partial rows: written, read back
