@@ -513,11 +513,12 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     j = int(np.argmax(kt))
     name = ("route", "aggregate", "score")[j]
     table_bytes = 2 * shard.n_pad * K * d * wb
-    in_cache = table_bytes <= 128 << 20
-    peak = _bench.L2_PEAK_GBS if in_cache else _bench.HBM_PEAK_GBS
-    roofline = {"bound": "l2" if in_cache else "hbm", "kernel": name, "achieved": mb[name] / kt[j] / 1e9, "peak": peak,
-                "unit": "GB/s", "frac": mb[name] / kt[j] / 1e9 / peak, "traffic": None, "moved_bytes": mb[name],
-                "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
+    bound, peak, bound_how = _bench.memory_bound(table_bytes, mb, None)     # no PMC passes exist for sharded runs
+    roofline = {"bound": bound, "bound_decided_by": bound_how, "kernel": name, "achieved": mb[name] / kt[j] / 1e9,
+                "peak": peak, "unit": "GB/s", "frac": mb[name] / kt[j] / 1e9 / peak, "traffic": None,
+                "moved_bytes": mb[name], "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
+    if bound == "hbm" and roofline["frac"] > _bench.HBM_ACHIEVABLE_FRAC:
+        roofline["frac_unverified"] = "above what HBM can deliver and not backed by counters: part of the bytes are cache hits"
     nnz = np.array([int(c[0]) for c in per_rank], dtype=np.float64)
     gather_bytes = (world - 1) * shard.part.block * (2 * K * d * wb + K * 4)       # received per rank and step
     dist.barrier()

@@ -354,3 +354,22 @@ def test_bench_pmc_table_covers_every_phase_kernel():
         else:
             assert got is None and entry["kernel_source_hash"] in why
     assert bench.pmc_traffic("no_such_workload")[0] is None
+
+
+def test_bench_prices_against_the_measured_roof():
+    """bench.memory_bound: with PMC passes the roof follows the measured traffic (bytes leaving the L2s below half of the
+    requested bytes: cache-served, else HBM), whatever the table size; without them the table size decides and says so."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    mb = dict(route=400e6, aggregate=130e6, score=4.2e9)
+    b, peak, how = bench.memory_bound(21 << 20, mb, dict(route=100e6, aggregate=80e6, score=210e6))
+    assert (b, peak) == ("l2", bench.L2_PEAK_GBS) and "measured" in how
+    b, peak, how = bench.memory_bound(340 << 20, mb, dict(route=100e6, aggregate=80e6, score=210e6))
+    assert b == "l2" and "measured" in how                          # a 340 MB table served by the caches is NOT HBM-bound
+    b, peak, how = bench.memory_bound(21 << 20, mb, dict(route=390e6, aggregate=150e6, score=4.0e9))
+    assert (b, peak) == ("hbm", bench.HBM_PEAK_GBS)
+    b, _p, how = bench.memory_bound(340 << 20, mb, None)
+    assert b == "hbm" and "no PMC" in how
+    assert bench.memory_bound(21 << 20, mb, None)[0] == "l2"

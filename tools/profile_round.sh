@@ -2,9 +2,11 @@
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 # Everything the bench line's numbers are checked against, into gpurun_out/<tag>_*:
 #   <tag>_bench_line.json                          python bench.py (the driver's command, default flags)
-#   <tag>_headline_kernel_stats.csv                rocprofv3 --kernel-trace --stats -- python3 bench.py --sections headline
-#   <tag>_hbm_bound_kernel_stats.csv               ... --sections hbm_bound   (one workload per trace: averages stay attributable)
-#   <tag>_pmc_traffic.json                         FETCH_SIZE / WRITE_SIZE, separate passes, per section (tools/pmc_traffic.py)
+#   <tag>_<workload>_kernel_stats.csv              rocprofv3 --kernel-trace --stats -- python3 bench.py --sections headline ...
+#                                                  (one workload per trace: a kernel's average belongs to one problem size)
+#   <tag>_pmc_traffic.json                         FETCH_SIZE / WRITE_SIZE, separate passes, per workload (tools/pmc_traffic.py)
+# Workloads: the default headline (squirrel_real), the hbm_bound block (snap_patents x0.25), and the other BASELINE.json
+# configurations on one GPU: chameleon K=8 d=64 fp32 (configs[1]) and Penn94-shaped K=16 d=128 bf16 (configs[4]).
 # Copy the files into profiles/ afterwards (tools/stats_md.py turns a csv into the markdown table).
 set -u
 tag=$1
@@ -12,10 +14,16 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$root"
 bash tools/prof_stats.sh ${tag}_headline bench.py --sections headline --steps 20 --warmup 5 --no-cpu-baseline || exit 1
 bash tools/prof_stats.sh ${tag}_hbm_bound bench.py --sections hbm_bound --no-cpu-baseline || exit 1
-bash tools/pmc_traffic_run.sh $tag squirrelx1_K8_d64_f32 --sections headline --steps 5 --warmup 2 || exit 1
+bash tools/prof_stats.sh ${tag}_chameleon bench.py --workload chameleon --sections headline --steps 20 --warmup 5 --no-cpu-baseline || exit 1
+bash tools/prof_stats.sh ${tag}_penn94_K16_d128_bf16 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 10 --warmup 3 --no-cpu-baseline || exit 1
+bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32 --sections headline --steps 5 --warmup 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag snap_patentsx0.25_K8_d64_f32 --sections hbm_bound --hbm-steps 2 --repeats 2 || exit 1
-# the bench line last, with the fresh PMC summary in place so that its `traffic` fields are this build's
+bash tools/pmc_traffic_run.sh $tag chameleonx1_K8_d64_f32 --workload chameleon --sections headline --steps 5 --warmup 2 || exit 1
+bash tools/pmc_traffic_run.sh $tag penn94x1_K16_d128_bf16 --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 3 --warmup 1 --repeats 2 || exit 1
+# the bench lines last, with the fresh PMC summary in place so that their `traffic` fields are this build's
 cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic_latest.json
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err || { tail -n 5 gpurun_out/${tag}_bench.err; exit 1; }
+python3 bench.py --workload chameleon --sections headline,cpu --steps 20 --warmup 5 > gpurun_out/${tag}_chameleon_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
+python3 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_penn94_K16_d128_bf16_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
 cp profiles/pmc_traffic_latest.json gpurun_out/${tag}_pmc_traffic_latest.json
 echo "profile_round $tag done"
