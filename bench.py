@@ -561,10 +561,12 @@ def main():
         "step_bytes_over_time_GBs": sum(mbytes.values()) / step_s / 1e9,
         "kernel_source_hash": kernel_source_hash(),
     }
-    if bound == "hbm" and traffic is None and kernels[dom]["frac"] > HBM_ACHIEVABLE_FRAC:
+    if bound == "hbm" and kernels[dom]["frac"] > HBM_ACHIEVABLE_FRAC:
         result["roofline"]["frac_unverified"] = (
-            "above the ~6.3 TB/s HBM can deliver and no PMC passes back it: part of these bytes are Infinity-Cache / L2 "
-            "hits; collect tools/pmc_traffic_run.sh for this workload before quoting the fraction")
+            "above the ~6.3 TB/s HBM can deliver: part of these bytes are served by the 256 MiB Infinity Cache " +
+            ("(the fabric-side PMC counters count its hits as traffic: they cannot separate it from HBM)" if traffic is not None
+             else "or the L2s, and no PMC passes exist for this build and workload") +
+            "; this is NOT a fraction of the HBM roofline — the hbm_bound block (tables far beyond every cache) is")
     if fb_ms is not None:
         result["fwd_bwd"] = {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)}
     result["scorer_training_step"] = scorer_train
