@@ -33,12 +33,26 @@ class SyntheticGraph:
     n_feat: int
     seed: int
 
-    def features(self) -> np.ndarray:
-        """x [N,F] ~ N(0,1), then (x - mean_row) / std_row with the unbiased std (main_disentangled.py:99)."""
-        rng = np.random.default_rng(self.seed + 1)
-        x = rng.standard_normal((self.n_nodes, self.n_feat), dtype=np.float32)
-        x = (x - x.mean(axis=1, keepdims=True)) / x.std(axis=1, ddof=1, keepdims=True)
-        return x.astype(np.float32)
+    FEATURE_BLOCK = 16384    # rows per independently seeded block
+
+    def features(self, rows: tuple[int, int] | None = None) -> np.ndarray:
+        """x [N,F] ~ N(0,1), then (x - mean_row) / std_row with the unbiased std (main_disentangled.py:99).
+        ``rows=(r0, r1)``: only those rows.  Every block of FEATURE_BLOCK rows has its own counter-based stream
+        (Philox keyed by seed and block index), so a rank of a sharded run generates exactly its own rows — the values
+        do not depend on who generates them or on how many ranks there are."""
+        r0, r1 = (0, self.n_nodes) if rows is None else rows
+        if not (0 <= r0 <= r1 <= self.n_nodes):
+            raise ValueError("rows outside [0, n_nodes]")
+        out = np.empty((r1 - r0, self.n_feat), dtype=np.float32)
+        B = self.FEATURE_BLOCK
+        for b in range(r0 // B, (r1 + B - 1) // B if r1 > r0 else r0 // B):
+            lo, hi = b * B, min((b + 1) * B, self.n_nodes)
+            rng = np.random.Generator(np.random.Philox(key=[self.seed + 1, b]))
+            x = rng.standard_normal((hi - lo, self.n_feat), dtype=np.float32)
+            x = (x - x.mean(axis=1, keepdims=True)) / x.std(axis=1, ddof=1, keepdims=True)
+            a, e = max(lo, r0), min(hi, r1)
+            out[a - r0:e - r0] = x[a - lo:e - lo]
+        return out
 
 
 def real_edge_graph(name: str, seed: int = 0) -> SyntheticGraph:

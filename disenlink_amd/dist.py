@@ -202,6 +202,25 @@ class HipBackend:
     def score_pairs_bwd(self, Z, H, inc, t, prob, g_prob, dZ_out, dH_out):
         self.ops.score_pairs_bwd(Z, H, inc, t, prob, g_prob, dZ_out=dZ_out, dH_out=dH_out)
 
+    def score_pairs_train_supported(self, inc, K, d, table_dtype) -> bool:
+        dt = self.ops._lib.DL_F32 if table_dtype == torch.float32 else self.ops._lib.DL_BF16
+        return self.ops.score_pairs_train_supported(inc, K, d, dt)
+
+    def score_pairs_train(self, Z, H, inc, t, label, weight):
+        """-> prob [P total] (entries of the pairs touching the plan's rows), dZ, dH [n_pad,K,d] (the plan's rows)"""
+        return self.ops.score_pairs_train(Z, H, inc, t, label, weight)
+
+    def pair_bce_sum(self, prob, label, weight):
+        """sum_q weight BCE(prob, label) with the reference's clamps (no autograd: the gradient came from the scorer)"""
+        lib = self.ops._lib.load()
+        loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+        g = torch.empty_like(prob)
+        ws = self.ops._ws.get(8192, prob.device)
+        self.ops._lib.check(lib.dl_pair_bce(prob.data_ptr(), label.data_ptr(), weight.data_ptr(), prob.numel(),
+                                            loss.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream().cuda_stream), "dl_pair_bce")
+        return loss[0]
+
     def bwd_phase1(self, g, Z, beta, p, a, s, dH, ds_out):
         return self.ops.route_aggregate_bwd_phase1(g, Z, beta, p, a, s, dH, ds_out)
 
@@ -322,12 +341,14 @@ class ShardedHotPath(torch.autograd.Function):
     """Z_loc [rows,K,d] -> (H_loc [rows,K,d], prob_loc [local pairs]) with the collectives inside."""
 
     @staticmethod
-    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group):
+    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype=torch.float32):
+        """table_dtype: storage type of the gathered Z / H tables (torch.bfloat16 halves the bytes of both all-gathers —
+        the step is bound by them on large graphs; arithmetic and every gradient stay fp32)."""
         sh = shard
         K, d = Z_loc.shape[1], Z_loc.shape[2]
         dev = Z_loc.device
-        Z = torch.empty((sh.n_pad, K, d), dtype=torch.float32, device=dev)
-        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().float())
+        Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
+        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().to(table_dtype))
         s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
         p, a = backend.route_fwd(sh.graph, Z, t, s)
         all_gather_rows(s, sh.lo, sh.hi, group)
@@ -341,7 +362,7 @@ class ShardedHotPath(torch.autograd.Function):
         ctx.shard, ctx.backend, ctx.beta, ctx.t, ctx.group = sh, backend, beta, t, group
         ctx.save_for_backward(Z, H, s, a, prob)
         ctx.p = p
-        return H[sh.lo:sh.hi].clone(), prob
+        return H[sh.lo:sh.hi].float(), prob
 
     @staticmethod
     def backward(ctx, gH_loc, g_prob):
@@ -360,26 +381,102 @@ class ShardedHotPath(torch.autograd.Function):
         sizes = np.diff(sh.pair_cuts)
         prob_all = torch.cat([buf[r, 0, :int(sizes[r])] for r in range(sh.world)])
         g_all = torch.cat([buf[r, 1, :int(sizes[r])] for r in range(sh.world)])
-        dZ = torch.zeros_like(Z)
-        dH = torch.zeros_like(Z)
+        dZ = torch.zeros(Z.shape, dtype=torch.float32, device=dev)
+        dH = torch.zeros(Z.shape, dtype=torch.float32, device=dev)
         be.score_pairs_bwd(Z, H, sh.inc, t, prob_all, g_all, dZ, dH)
         if gH_loc is not None:
             dH[sh.lo:sh.hi] += gH_loc
-        all_gather_rows(dH, sh.lo, sh.hi, group)
-        ds = torch.zeros_like(s)
-        dw, dwr = be.bwd_phase1(sh.graph, Z, beta, ctx.p, a, s, dH, ds)
-        all_gather_rows(ds, sh.lo, sh.hi, group)
-        be.bwd_phase2(sh.graph, Z, beta, t, ctx.p, a, s, dH, dw, dwr, ds, dZ, True)
-        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None
+        _route_aggregate_bwd_sharded(be, sh, Z, beta, t, ctx.p, a, s, dH, dZ, group)
+        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None
+
+
+def _route_aggregate_bwd_sharded(be, sh: Shard, Z, beta, t, p, a, s, dH, dZ, group) -> None:
+    """dH holds this rank's rows of d loss / d H; dZ its rows of the scorer's d loss / d Z.  All-gather dH, phase 1 on the
+    local rows, all-gather ds, phase 2 accumulating into dZ's local rows."""
+    all_gather_rows(dH, sh.lo, sh.hi, group)
+    ds = torch.zeros_like(s)
+    dw, dwr = be.bwd_phase1(sh.graph, Z, beta, p, a, s, dH, ds)
+    all_gather_rows(ds, sh.lo, sh.hi, group)
+    be.bwd_phase2(sh.graph, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ, True)
+
+
+class ShardedHotPathLoss(torch.autograd.Function):
+    """Z_loc -> (H_loc, prob_loc, loss_loc) with the scorer's training step in ONE pass over this rank's incidence rows
+    (dl_score_pairs_train): the wave that owns a node's pair slots forms prob itself, applies the weighted-BCE gradient
+    and accumulates that node's dZ / dH rows — so the backward needs NO all-gather of (prob, g_prob), and every partner
+    row is gathered once per direction instead of three times.  label / weight cover the WHOLE pair list (replicated,
+    fixed for a run; weight carries the GLOBAL normaliser, metrics.pair_bce_weights).  loss_loc = this rank's share
+    sum_{q: u local} w BCE — the caller all-reduces it for the value; its gradient factor must be the same on every rank."""
+
+    @staticmethod
+    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype, label, weight):
+        ctx.set_materialize_grads(False)
+        sh = shard
+        K, d = Z_loc.shape[1], Z_loc.shape[2]
+        dev = Z_loc.device
+        Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
+        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().to(table_dtype))
+        s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
+        p, a = backend.route_fwd(sh.graph, Z, t, s)
+        all_gather_rows(s, sh.lo, sh.hi, group)
+        H = torch.empty_like(Z)
+        backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
+        all_gather_rows(H, sh.lo, sh.hi, group)
+        prob_all, dZs, dHs = backend.score_pairs_train(Z, H, sh.inc, t, label, weight)
+        q0, q1 = sh.pair_lo, sh.pair_hi
+        prob = prob_all[q0:q1].clone()                            # the pairs this rank owns (first endpoint local)
+        loss = backend.pair_bce_sum(prob, label[q0:q1].contiguous(), weight[q0:q1].contiguous()) if q1 > q0 else \
+            torch.zeros((), dtype=torch.float32, device=dev)
+        ctx.shard, ctx.backend, ctx.beta, ctx.t, ctx.group, ctx.p = sh, backend, beta, t, group, p
+        ctx.save_for_backward(Z, s, a, dZs, dHs)
+        return H[sh.lo:sh.hi].float(), prob, loss
+
+    @staticmethod
+    def backward(ctx, gH_loc, g_prob, g_loss):
+        if g_prob is not None:
+            raise RuntimeError("ShardedHotPathLoss: a gradient on prob needs the general path (ShardedHotPath)")
+        sh, be = ctx.shard, ctx.backend
+        Z, s, a, dZs, dHs = ctx.saved_tensors
+        if g_loss is None:
+            dZ, dH = torch.zeros_like(dZs), torch.zeros_like(dHs)
+        else:
+            dZ, dH = dZs * g_loss, dHs * g_loss
+        if gH_loc is not None:
+            dH[sh.lo:sh.hi] += gH_loc
+        _route_aggregate_bwd_sharded(be, sh, Z, ctx.beta, ctx.t, ctx.p, a, s, dH, dZ, ctx.group)
+        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None, None, None
 
 
 def sharded_forward(model, x_local: torch.Tensor, shard: Shard, backend=None, group=None):
     """(emb_local [rows,K*d], prob_local [local pairs]) of the drop-in module on this rank's shard; the first
-    r1 - r0 rows of emb_local are the real nodes shard.local_real_rows()."""
+    r1 - r0 rows of emb_local are the real nodes shard.local_real_rows().  The gathered tables take the module's
+    ``table_dtype`` (bf16: half the all-gather bytes)."""
     backend = backend or HipBackend()
     Z_loc = model.project(shard.pad_rows(x_local))
-    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group)
+    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group,
+                                       getattr(model, "table_dtype", torch.float32))
     return H_loc.reshape(H_loc.shape[0], -1), prob
+
+
+def sharded_forward_loss(model, x_local: torch.Tensor, shard: Shard, label: torch.Tensor, weight: torch.Tensor,
+                         backend=None, group=None):
+    """(emb_local, prob_local, loss_local): the training step's forward with the one-pass scorer where the backend has
+    it for this shape (else the general path + the same weighted BCE).  label / weight: the WHOLE pair list; the global
+    loss is the all-reduced sum of loss_local."""
+    backend = backend or HipBackend()
+    tab = getattr(model, "table_dtype", torch.float32)
+    Z_loc = model.project(shard.pad_rows(x_local))
+    K, d = Z_loc.shape[1], Z_loc.shape[2]
+    if shard.inc is not None and hasattr(backend, "score_pairs_train") and \
+            backend.score_pairs_train_supported(shard.inc, K, d, tab):
+        H_loc, prob, loss = ShardedHotPathLoss.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature),
+                                                     group, tab, label, weight)
+        return H_loc.reshape(H_loc.shape[0], -1), prob, loss
+    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group, tab)
+    q0, q1 = shard.pair_lo, shard.pair_hi
+    y, w = label[q0:q1], weight[q0:q1]
+    bce = torch.nn.functional.binary_cross_entropy(prob, y, weight=w, reduction="sum") if q1 > q0 else prob.sum() * 0.0
+    return H_loc.reshape(H_loc.shape[0], -1), prob, bce
 
 
 def allreduce_gradients(model, group=None) -> None:
@@ -391,16 +488,76 @@ def allreduce_gradients(model, group=None) -> None:
 
 
 # --------------------------------------------------------------------------- bench (bench.py --gpus N)
-def _bench_problem(args, world_for_scale: int):
+@dataclass
+class BenchProblem:
+    """What every rank needs of the benchmark graph: the train edge rows, the scored pairs sorted by (u, v) and the
+    generator of the feature rows (any rank can produce exactly its own rows, data.SyntheticGraph.features)."""
+    sg: object                 # SyntheticGraph (its src / dst are empty on the ranks that received the problem)
+    edge_rows: int
+    train_src: np.ndarray
+    train_dst: np.ndarray
+    pu: np.ndarray
+    pv: np.ndarray
+    scale: float
+    prep_s: float = 0.0
+
+
+def _build_problem(args, scale: float, device) -> BenchProblem:
     from .data import synthetic_graph
     from .splits import make_link_split
-    scale = args.scale * (world_for_scale if args.scaling == "weak" else 1)
     sg = synthetic_graph(args.workload, seed=0, scale=scale)
-    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
+    # the sorts and searches of the split run on the GPU when there is one (same split bit for bit, splits.py):
+    # snap-patents full size 104 s -> seconds
+    dev = device if (device is not None and torch.device(device).type == "cuda") else None
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0, device=dev)
     pu = np.concatenate([split.pos_train.u, split.neg_train.u])
     pv = np.concatenate([split.pos_train.v, split.neg_train.v])
-    order = np.lexsort((pv, pu))
-    return sg, split, pu[order], pv[order], scale
+    if dev is not None:
+        order = torch.argsort(torch.as_tensor(pu * sg.n_nodes + pv, device=dev), stable=True).cpu().numpy()
+    else:
+        order = np.lexsort((pv, pu))
+    return BenchProblem(sg, int(sg.src.size), split.train_src, split.train_dst, pu[order], pv[order], scale)
+
+
+def _bench_problem(args, world_for_scale: int, rank: int = 0, world: int = 1, device=None) -> BenchProblem:
+    """The benchmark problem, built ONCE: rank 0 generates the graph, the split and the sorted pair list and writes the
+    four index arrays to /dev/shm; the other ranks read them (round 2: every rank repeated the whole host preparation —
+    104 s for snap-patents, times N ranks on one host).  Feature rows are generated per rank, for its own rows only."""
+    from .data import SyntheticGraph, SPECS
+    scale = args.scale * (world_for_scale if args.scaling == "weak" else 1)
+    t0 = time.perf_counter()
+    shm = os.environ.get("DL_SHARE_DIR", "/dev/shm")
+    if world == 1 or not dist.is_initialized() or not os.path.isdir(shm):
+        prob = _build_problem(args, scale, device)
+        prob.prep_s = time.perf_counter() - t0
+        return prob
+    token = [f"dl_bench_{os.getpid()}_{time.time_ns()}" if rank == 0 else None]
+    dist.broadcast_object_list(token, src=0)
+    base = os.path.join(shm, token[0])
+    names = ("train_src", "train_dst", "pu", "pv")
+    meta = [None]
+    if rank == 0:
+        prob = _build_problem(args, scale, device)
+        for n in names:
+            np.save(f"{base}_{n}.npy", getattr(prob, n))
+        meta = [dict(name=prob.sg.name, n_nodes=prob.sg.n_nodes, n_feat=prob.sg.n_feat, seed=prob.sg.seed,
+                     edge_rows=prob.edge_rows)]
+    dist.broadcast_object_list(meta, src=0)                       # also the "files are complete" signal
+    if rank != 0:
+        m = meta[0]
+        empty = np.zeros(0, dtype=np.int64)
+        sg = SyntheticGraph(m["name"], m["n_nodes"], empty, empty, m["n_feat"], m["seed"])
+        arrs = {n: np.load(f"{base}_{n}.npy") for n in names}
+        prob = BenchProblem(sg, m["edge_rows"], arrs["train_src"], arrs["train_dst"], arrs["pu"], arrs["pv"], scale)
+    dist.barrier()                                                # everyone has read: rank 0 removes the files
+    if rank == 0:
+        for n in names:
+            try:
+                os.remove(f"{base}_{n}.npy")
+            except OSError:
+                pass
+    prob.prep_s = time.perf_counter() - t0
+    return prob
 
 
 def bench_sharded(args, rank: int, world: int, device) -> dict:
@@ -419,13 +576,18 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
         return _bench_emulated(args, emu, device)
     tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     wb = 2 if args.dtype == "bf16" else 4
-    sg, split, pu, pv, scale = _bench_problem(args, world)
-    shard = Shard.build(rank, world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device, row_bytes=K * d * wb,
+    t_prep = time.perf_counter()
+    prob = _bench_problem(args, world, rank, world, device)
+    sg, pu, pv, scale = prob.sg, prob.pu, prob.pv, prob.scale
+    shard = Shard.build(rank, world, sg.n_nodes, prob.train_src, prob.train_dst, pu, pv, device, row_bytes=K * d * wb,
                         n_chunks=DEFAULT_CHUNKS, with_backward=False)
     torch.manual_seed(0)
     model = Disentangle(sg.n_feat, args.nhidden, d, nfactor=K, beta=beta, t=1).to(device)
     r0, r1 = shard.local_real_rows()
-    x_loc = torch.from_numpy(sg.features()[r0:r1]).to(device)
+    x_loc = torch.from_numpy(sg.features(rows=(r0, r1))).to(device)      # this rank's rows only
+    torch.cuda.synchronize()
+    dist.barrier()
+    prep_s = time.perf_counter() - t_prep                                 # launch -> every rank ready for its first collective
     backend = HipBackend()
     with torch.no_grad():
         Z_loc = model.project(shard.pad_rows(x_loc)).contiguous().to(tab)
@@ -537,7 +699,8 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
         "partition": {"balance": "nnz", "block_rows": shard.part.block, "padded_nodes": shard.n_pad,
                       "nnz_max_over_mean": float(nnz.max() / max(nnz.mean(), 1.0)), "h_gather_chunks": shard.part.n_chunks,
                       "allgather_bytes_received_per_rank_per_step": int(gather_bytes)},
-        "config": {"workload": f"{args.workload}-synthetic x{scale:g} (seed 0): N={sg.n_nodes}, edge rows={sg.src.size}, "
+        "prep_s": {"problem_built_once_and_shared": prob.prep_s, "until_first_collective": prep_s},
+        "config": {"workload": f"{args.workload}-synthetic x{scale:g} (seed 0): N={sg.n_nodes}, edge rows={prob.edge_rows}, "
                                f"85/5/10 split, E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, {args.dtype} tables; "
                                f"row-sharded over {world} GPUs by work (nnz), all-gather of Z, s and H over RCCL each step, "
                                f"the H gather in {shard.part.n_chunks} chunks under the scorer; forward route+aggregate+score",
@@ -553,8 +716,11 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
     K, d, beta, t = args.K, args.d, 0.5, 1.0
     tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     wb = 2 if args.dtype == "bf16" else 4
-    sg, split, pu, pv, scale = _bench_problem(args, emu_world)
-    shard = Shard.build(0, emu_world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, device,
+    t_prep = time.perf_counter()
+    prob = _bench_problem(args, emu_world, 0, 1, device)
+    sg, pu, pv, scale = prob.sg, prob.pu, prob.pv, prob.scale
+    train_src, train_dst = prob.train_src, prob.train_dst
+    shard = Shard.build(0, emu_world, sg.n_nodes, train_src, train_dst, pu, pv, device,
                         row_bytes=K * d * wb, n_chunks=DEFAULT_CHUNKS, with_backward=False)
     backend = HipBackend()
     Z = (torch.randn((shard.n_pad, K, d), device=device) * 0.24).to(tab)
@@ -579,7 +745,7 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
         if it >= args.warmup:
             acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3 + ng)]
     acc /= args.steps
-    w = np.bincount(split.train_src, minlength=sg.n_nodes) + np.bincount(split.train_dst, minlength=sg.n_nodes) + 1
+    w = np.bincount(train_src, minlength=sg.n_nodes) + np.bincount(train_dst, minlength=sg.n_nodes) + 1
     cuts = shard.part.cuts
     share = np.array([w[cuts[r]:cuts[r + 1]].sum() for r in range(emu_world)], dtype=np.float64)
     groups = [dict(group="second endpoint local" if gi == 0 else f"chunk {gi - 1} of the H gather",

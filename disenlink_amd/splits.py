@@ -43,27 +43,52 @@ class LinkSplit:
     raw: dict | None = None  # make_link_split(keep_raw=True): the index lists before de-duplication (fixture generators)
 
 
-def _pair_set(u, v, n, edge_keys_sorted, only_single: bool) -> PairSet:
+# The sorts and binary searches of a split are integer work with one right answer: on a large graph (snap-patents: 14M
+# edge rows, 70M negative draws) they take minutes in numpy on one core and seconds with torch on the GPU.  ``device``
+# (optional) moves exactly those steps; every random draw stays in numpy, so the split is the same bit for bit.
+def _unique(a: np.ndarray, counts: bool = False, device=None):
+    if device is None:
+        return np.unique(a, return_counts=counts)
+    import torch
+    t = torch.as_tensor(a, device=device)
+    if counts:
+        k, c = torch.unique(t, sorted=True, return_counts=True)
+        return k.cpu().numpy(), c.cpu().numpy()
+    return torch.unique(t, sorted=True).cpu().numpy()
+
+
+def _member(sorted_keys: np.ndarray, key: np.ndarray, device=None) -> np.ndarray:
+    """key[i] in sorted_keys, elementwise"""
+    if sorted_keys.size == 0:
+        return np.zeros(key.size, dtype=bool)
+    if device is None:
+        pos = np.minimum(np.searchsorted(sorted_keys, key), sorted_keys.size - 1)
+        return sorted_keys[pos] == key
+    import torch
+    sk = sorted_keys if torch.is_tensor(sorted_keys) else torch.as_tensor(sorted_keys, device=device)
+    k = torch.as_tensor(key, device=device)
+    pos = torch.searchsorted(sk, k).clamp_(max=sk.numel() - 1)
+    return (sk[pos] == k).cpu().numpy()
+
+
+def _pair_set(u, v, n, edge_keys_sorted, only_single: bool, device=None) -> PairSet:
     """Distinct pairs in row-major order (the order mask indexing visits them).  only_single: keep the pairs that occur
     exactly once (``mask == 1`` on a summed, un-binarised mask); else every distinct pair (a binarised mask)."""
-    key, cnt = np.unique(u.astype(np.int64) * n + v.astype(np.int64), return_counts=True)
+    key, cnt = _unique(u.astype(np.int64) * n + v.astype(np.int64), counts=True, device=device)
     if only_single:
         key = key[cnt == 1]
     uu, vv = key // n, key % n
-    pos = np.searchsorted(edge_keys_sorted, key)
-    pos = np.minimum(pos, max(edge_keys_sorted.size - 1, 0))
-    label = (edge_keys_sorted[pos] == key).astype(np.float32) if edge_keys_sorted.size else np.zeros(key.size, np.float32)
+    label = _member(edge_keys_sorted, key, device).astype(np.float32)
     return PairSet(uu, vv, label)
 
 
-def structured_negatives(src, n, edge_keys_sorted, rng) -> np.ndarray:
+def structured_negatives(src, n, edge_keys_sorted, rng, device=None) -> np.ndarray:
     """For every row i = src[r] one node k, uniform over [0, n), with (i, k) not an edge row."""
     k = rng.integers(0, n, size=src.size)
     bad = np.ones(src.size, dtype=bool)
     for _ in range(1000):
         key = src[bad] * n + k[bad]
-        pos = np.minimum(np.searchsorted(edge_keys_sorted, key), edge_keys_sorted.size - 1)
-        hit = edge_keys_sorted[pos] == key
+        hit = _member(edge_keys_sorted, key, device)
         idx = np.flatnonzero(bad)
         bad[idx[~hit]] = False
         if not bad.any():
@@ -72,7 +97,8 @@ def structured_negatives(src, n, edge_keys_sorted, rng) -> np.ndarray:
     raise RuntimeError("negative sampling did not converge (a node is connected to every node)")
 
 
-def make_link_split(src, dst, n_nodes: int, m: int = 5, seed: int = 0, keep_raw: bool = False) -> LinkSplit:
+def make_link_split(src, dst, n_nodes: int, m: int = 5, seed: int = 0, keep_raw: bool = False, device=None) -> LinkSplit:
+    """``device`` (optional, a torch device): run the sorts / searches there (same split, bit for bit)."""
     src = np.asarray(src, dtype=np.int64)
     dst = np.asarray(dst, dtype=np.int64)
     E = src.size
@@ -82,16 +108,20 @@ def make_link_split(src, dst, n_nodes: int, m: int = 5, seed: int = 0, keep_raw:
     rest = E - n_train
     n_test = int(rest * 2 / 3)
     tr, te, va = perm[:n_train], perm[n_train:n_train + n_test], perm[n_train + n_test:]
-    edge_keys = np.unique(src * n_nodes + dst)
+    edge_keys = _unique(src * n_nodes + dst, device=device)
+    ek = edge_keys
+    if device is not None:                                    # searched 2 + 5 m times: keep one copy on the device
+        import torch
+        ek = torch.as_tensor(edge_keys, device=device)
     neg_u = {"tr": [], "va": [], "te": []}
     neg_v = {"tr": [], "va": [], "te": []}
     for _ in range(m):
-        k = structured_negatives(src, n_nodes, edge_keys, rng)
+        k = structured_negatives(src, n_nodes, ek, rng, device)
         for name, idx in (("tr", tr), ("va", va), ("te", te)):
             neg_u[name].append(src[idx])
             neg_v[name].append(k[idx])
     cat = np.concatenate
-    ps = lambda u, v, single: _pair_set(u, v, n_nodes, edge_keys, single)
+    ps = lambda u, v, single: _pair_set(u, v, n_nodes, ek, single, device)
     out = LinkSplit(
         n_nodes=n_nodes, train_src=src[tr], train_dst=dst[tr],
         pos_train=ps(src[tr], dst[tr], True),

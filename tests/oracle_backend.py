@@ -18,10 +18,15 @@ def _rows(plan):
     return src, plan.col.numpy().astype(np.int64)
 
 
+def _np(t):
+    """fp32 numpy view of a table in either storage type (bf16 tables: the rounded values, as the kernels read them)"""
+    return t.float().numpy()
+
+
 class OracleBackend:
     def route_fwd(self, g, Z, t, s_out):
         src, dst = _rows(g.plan)
-        Zh = Z.numpy()
+        Zh = _np(Z)
         K = Zh.shape[1]
         with np.errstate(over="ignore", invalid="ignore"):
             ex = np.exp(_edge_dots(Zh, src, dst) / f32(t), dtype=f32)
@@ -35,22 +40,54 @@ class OracleBackend:
 
     def aggregate_fwd(self, g, Z, beta, p, a, s, H_out):
         src, dst = _rows(g.plan)
-        Zh, sh = Z.numpy(), s.numpy()
+        Zh, sh = _np(Z), s.numpy()
         sh = np.where(sh == 0, f32(1), sh)
         pk = p.numpy().astype(np.int64)
         w = (a.numpy() / sh[dst, pk]).astype(f32)
         acc = np.zeros((g.n_rows,) + Zh.shape[1:], dtype=f32)
         np.add.at(acc, (src - g.row_offset, pk), w[:, None] * Zh[dst, pk])
         lo, hi = g.row_offset, g.row_offset + g.n_rows
-        H_out[lo:hi] = torch.from_numpy((f32(beta) * Zh[lo:hi] + f32(1 - beta) * acc).astype(f32))
+        H_out[lo:hi] = torch.from_numpy((f32(beta) * Zh[lo:hi] + f32(1 - beta) * acc).astype(f32)).to(H_out.dtype)
 
     def score_pairs_fwd(self, Z, H, pairs, t):
-        return torch.from_numpy(sparse_ref.score_pairs(Z.numpy(), H.numpy(), pairs.pu.numpy(), pairs.pv.numpy(), t))
+        return torch.from_numpy(sparse_ref.score_pairs(_np(Z), _np(H), pairs.pu.numpy(), pairs.pv.numpy(), t))
+
+    # ---- the training step of the scorer in one pass over the local incidence rows (dl_score_pairs_train)
+    def score_pairs_train_supported(self, inc, K, d, table_dtype) -> bool:
+        return True
+
+    def score_pairs_train(self, Z, H, inc, t, label, weight):
+        u, v = _rows(inc.inc)
+        q = inc.inc_pair.numpy().astype(np.int64)
+        Zh, Hh = _np(Z), _np(H)
+        pr, qk, ex = sparse_ref.score_pairs(Zh, Hh, u, v, t, return_parts=True)
+        y, w = label.numpy()[q], weight.numpy()[q]
+        den = np.maximum(pr * (f32(1) - pr), f32(1e-12))
+        gl = (w * (pr - y) / den * (pr * (f32(1) - pr))).astype(f32)      # dl_pair_bce's gradient times the sigmoid backward
+        prob = np.full(label.numel(), np.nan, dtype=f32)                   # pairs without a local endpoint stay unwritten
+        prob[q] = pr
+        n, lo = inc.inc.n_rows, inc.inc.row_offset
+        dZ = np.full(Zh.shape, np.nan, dtype=f32)
+        dH = np.full(Zh.shape, np.nan, dtype=f32)
+        accZ = np.zeros((n,) + Zh.shape[1:], dtype=f32)
+        accH = np.zeros_like(accZ)
+        np.add.at(accH, u - lo, (gl[:, None] * ex)[:, :, None] * Hh[v])
+        np.add.at(accZ, u - lo, (gl[:, None] * qk * ex / f32(t))[:, :, None] * Zh[v])
+        dZ[lo:lo + n], dH[lo:lo + n] = accZ, accH
+        return torch.from_numpy(prob), torch.from_numpy(dZ), torch.from_numpy(dH)
+
+    def pair_bce_sum(self, prob, label, weight):
+        from oracle import metrics_ref  # noqa: F401
+        pr, y, w = prob.numpy().astype(f32), label.numpy(), weight.numpy()
+        with np.errstate(divide="ignore"):
+            lp = np.maximum(np.log(pr), f32(-100))
+            l1p = np.maximum(np.log(f32(1) - pr), f32(-100))
+        return torch.tensor(float((w * -(y * lp + (f32(1) - y) * l1p)).sum(dtype=np.float64)), dtype=torch.float32)
 
     def score_pairs_bwd(self, Z, H, inc, t, prob, g_prob, dZ_out, dH_out):
         u, v = _rows(inc.inc)
         q = inc.inc_pair.numpy().astype(np.int64)
-        Zh, Hh = Z.numpy(), H.numpy()
+        Zh, Hh = _np(Z), _np(H)
         pr, gq = prob.numpy()[q], g_prob.numpy()[q]
         _prob, qk, ex = sparse_ref.score_pairs(Zh, Hh, u, v, t, return_parts=True)
         gl = (gq * pr * (f32(1) - pr)).astype(f32)
@@ -65,7 +102,7 @@ class OracleBackend:
 
     def bwd_phase1(self, g, Z, beta, p, a, s, dH, ds_out):
         src, dst = _rows(g.plan)
-        Zh, Dh, sh = Z.numpy(), dH.numpy(), s.numpy()
+        Zh, Dh, sh = _np(Z), dH.numpy(), s.numpy()
         pk = p.numpy().astype(np.int64)
         dw = f32(1 - beta) * np.einsum("ed,ed->e", Dh[src, pk], Zh[dst, pk], dtype=f32)
         dwr = f32(1 - beta) * np.einsum("ed,ed->e", Dh[dst, pk], Zh[src, pk], dtype=f32)
@@ -80,7 +117,7 @@ class OracleBackend:
 
     def bwd_phase2(self, g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ_out, accumulate):
         src, dst = _rows(g.plan)
-        Zh, Dh, sh, dsh = Z.numpy(), dH.numpy(), s.numpy(), ds.numpy()
+        Zh, Dh, sh, dsh = _np(Z), dH.numpy(), s.numpy(), ds.numpy()
         sh = np.where(sh == 0, f32(1), sh)
         pk = p.numpy().astype(np.int64)
         ah = a.numpy()

@@ -85,6 +85,67 @@ def _worker(rank, world, port, pb, sd, out, n_chunks=1):
         dist.destroy_process_group()
 
 
+def _loss_worker(rank, world, port, pb, sd, out, table):
+    """The training step through sharded_forward_loss: one-pass scorer over the local incidence rows, no (prob, g_prob)
+    all-gather; `table` = storage type of the gathered tables."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disenlink_amd import dist as dd
+        from disenlink_amd.model import Disentangle
+        from oracle_backend import OracleBackend
+        torch.set_num_threads(1)
+        model = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"],
+                            table_dtype=torch.bfloat16 if table == "bf16" else torch.float32)
+        model.load_state_dict(sd)
+        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4, n_chunks=2)
+        r0, r1 = shard.local_real_rows()
+        P = pb["pu"].size
+        label = torch.from_numpy(pb["label"])
+        weight = torch.full((P,), 1.0 / P)                          # the GLOBAL mean's weights, replicated
+        emb, prob, loss = dd.sharded_forward_loss(model, torch.from_numpy(pb["x"][r0:r1]), shard, label, weight,
+                                                  backend=OracleBackend())
+        model.zero_grad()
+        loss.backward()
+        dd.allreduce_gradients(model)
+        tot = loss.detach().clone()
+        dist.all_reduce(tot)
+        out[rank] = dict(emb=emb.detach().numpy()[: r1 - r0], prob=prob.detach().numpy(), loss=float(tot),
+                         rows=(r0, r1), pairs=(shard.pair_lo, shard.pair_hi),
+                         grads={k: v.grad.numpy().copy() for k, v in model.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,table", [(2, "f32"), (4, "f32"), (4, "bf16")])
+def test_sharded_training_step_with_the_one_pass_scorer(world, table):
+    """sharded_forward_loss over gloo: every rank runs the scorer's forward + loss gradient + backward in one pass over
+    ITS incidence rows (all pairs touching its nodes), so no (prob, g_prob) all-gather exists; the summed replicas'
+    gradients equal the unsharded dense oracle's.  bf16: the gathered Z / H tables are bf16 (half the all-gather bytes);
+    the result follows the fp32 reference within bf16 rounding."""
+    from disenlink_amd.model import Disentangle
+    pb = _skewed_problem()
+    torch.manual_seed(0)
+    sd = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"]).state_dict()
+    emb_ref, prob_ref, loss_ref, grads_ref = _reference(pb, sd)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_loss_worker, args=(world, _free_port(), pb, sd, out, table), nprocs=world, join=True)
+    tol = dict(rtol=1e-5, atol=1e-6) if table == "f32" else dict(rtol=5e-2, atol=2e-2)
+    gtol = 2e-4 if table == "f32" else 8e-2
+    for r in range(world):
+        o = out[r]
+        (r0, r1), (q0, q1) = o["rows"], o["pairs"]
+        np.testing.assert_allclose(o["emb"], emb_ref[r0:r1], **tol)
+        np.testing.assert_allclose(o["prob"], prob_ref[q0:q1], **tol)
+        assert abs(o["loss"] - loss_ref) < (1e-5 if table == "f32" else 3e-2) * max(1.0, abs(loss_ref))
+        for k, gref in grads_ref.items():
+            scale = max(np.abs(gref).max(), 1e-6)
+            assert np.abs(o["grads"][k] - gref).max() <= gtol * scale, (r, k, np.abs(o["grads"][k] - gref).max() / scale)
+
+
 def _skewed_problem(seed=5, N=90, F=7, K=4, d=8, nhid=5):
     """Heavy-tailed degrees (a few hubs, most nodes with a handful of edges), hubs at low ids."""
     rng = np.random.default_rng(seed)

@@ -407,14 +407,25 @@ def test_sharded_training_step_over_rccl_matches_the_unsharded_module():
         model.zero_grad()
         loss_of(prob_s).backward()
         dl_dist.allreduce_gradients(model)
+        got = [p.grad.clone() for p in model.parameters()]
+        # the training step with the one-pass scorer over the rank's incidence rows (no (prob, g_prob) all-gather)
+        wts = torch.where(lab > 0, 1.0 / float(lab.sum()), 0.2 / float((1 - lab).sum())).contiguous()
+        emb_l, prob_l, loss_l = dl_dist.sharded_forward_loss(model, x, shard, lab, wts)
+        model.zero_grad()
+        loss_l.backward()
+        dl_dist.allreduce_gradients(model)
+        got_l = [p.grad.clone() for p in model.parameters()]
         torch.cuda.synchronize()
     finally:
         if own_group:
             tdist.destroy_process_group()
     np.testing.assert_allclose(emb_s.detach().cpu().numpy(), emb.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(prob_s.detach().cpu().numpy(), prob.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
-    for p, w in zip(model.parameters(), want):
-        assert float((p.grad - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-8)
+    np.testing.assert_allclose(prob_l.detach().cpu().numpy(), prob.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(float(loss_l) - float(loss_of(prob.detach()))) <= 1e-5 * abs(float(loss_l))
+    for g1, g2, w in zip(got, got_l, want):
+        assert float((g1 - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-8)
+        assert float((g2 - w).abs().max()) <= 2e-5 * max(float(w.abs().max()), 1e-8)
 
 
 @pytest.mark.parametrize("K,d,N", [(8, 64, 700), (3, 32, 385), (16, 128, 260), (5, 64, 128), (2, 96, 129)])
