@@ -722,6 +722,8 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
     train_src, train_dst = prob.train_src, prob.train_dst
     shard = Shard.build(0, emu_world, sg.n_nodes, train_src, train_dst, pu, pv, device,
                         row_bytes=K * d * wb, n_chunks=DEFAULT_CHUNKS, with_backward=False)
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t_prep
     backend = HipBackend()
     Z = (torch.randn((shard.n_pad, K, d), device=device) * 0.24).to(tab)
     s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
@@ -750,7 +752,9 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
     share = np.array([w[cuts[r]:cuts[r + 1]].sum() for r in range(emu_world)], dtype=np.float64)
     groups = [dict(group="second endpoint local" if gi == 0 else f"chunk {gi - 1} of the H gather",
                    pairs=int(idx.numel()), score_us=float(acc[3 + gi] * 1e3)) for gi, (idx, _s) in enumerate(shard.pair_groups)]
-    return {"emulated_world": emu_world, "scaling": args.scaling, "dtype": args.dtype,
+    return {"emulated_world": emu_world, "scaling": args.scaling, "dtype": args.dtype, "workload": args.workload,
+            "prep_s": {"problem": prob.prep_s, "problem_and_rank0_shard": prep_s,
+                       "note": "graph + split + sorted pair list (sorts / searches on the GPU), then rank 0's shard plans"},
             "rank0_edges": shard.graph.n_edges, "rank0_pairs": shard.pairs.n_pairs,
             "n_nodes": sg.n_nodes, "block_rows": shard.part.block, "table_MB": shard.n_pad * K * d * wb / 1e6,
             "work_share_max_over_mean": float(share.max() / share.mean()),

@@ -46,7 +46,8 @@ class Factor2(nn.Module):
 
 
 class Disentangle(nn.Module):
-    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1, table_dtype=torch.float32, projection="auto"):
+    def __init__(self, nfeat, nhid, nebed, nfactor, beta, t=1, table_dtype=torch.float32, projection="auto",
+                 use_torch_ops=False):
         """Extensions (the reference has neither):
         ``table_dtype``: storage type of the gathered Z / H tables in ``forward_pairs`` — torch.float32
         (reference precision) or torch.bfloat16 (half the gather bytes, fp32 arithmetic and gradients).
@@ -57,8 +58,13 @@ class Disentangle(nn.Module):
         "library" = library GEMMs (rocBLAS through torch), "auto" = the kernels wherever they support the factor width
         (any d <= 128; widths other than 32 / 64 / 128 run at the next of those): measured equal or faster than the library path at every feature width (squirrel epoch
         1.64 vs 1.75 ms at F=128, 1.93 vs 2.06 at 512, 2.17 vs 2.36 at 1024, 2.74 vs 3.20 at 2089; real Cora
-        (F=1433) 1.32 vs 1.60; tools/epoch_time.py), and they never materialise the [N,K,nhid] activations."""
+        (F=1433) 1.32 vs 1.60; tools/epoch_time.py), and they never materialise the [N,K,nhid] activations.
+        ``use_torch_ops``: ``forward_pairs`` goes through the REGISTERED operators ``torch.ops.disenlink.*``
+        (disenlink_amd/torch_ops.py: schema + fake + autograd via torch.library over the same C ABI) instead of the
+        ctypes-calling autograd.Functions — same kernels and bits; what it buys is dispatcher visibility:
+        ``torch.compile(model.forward_pairs)`` traces the whole step without graph breaks."""
         super().__init__()
+        self.use_torch_ops = bool(use_torch_ops)
         if projection not in ("auto", "mfma", "library"):
             raise ValueError("projection must be 'auto', 'mfma' or 'library'")
         self.table_dtype = table_dtype
@@ -254,6 +260,10 @@ class Disentangle(nn.Module):
 
     def forward_pairs(self, x, graph: Graph, pairs: PairList):
         """(emb [N,K*d], prob [P]) — the same model evaluated on a pair list only."""
+        if self.use_torch_ops and not self.single_layer and self.table_dtype == torch.float32 and x.is_cuda \
+                and ops.project_supported(self.nebed):
+            from . import torch_ops
+            return torch_ops.forward_pairs(self, x, torch_ops.register_graph(graph), torch_ops.register_pairs(pairs))
         Z = self.project(x)
         H, prob = ops.HotPathPairs.apply(Z, graph, pairs, float(self.beta), float(self.temperature), self.table_dtype)
         return H.view(H.shape[0], -1), prob

@@ -373,3 +373,36 @@ def test_bench_prices_against_the_measured_roof():
     b, _p, how = bench.memory_bound(340 << 20, mb, None)
     assert b == "hbm" and "no PMC" in how
     assert bench.memory_bound(21 << 20, mb, None)[0] == "l2"
+
+
+def test_torch_library_operators_are_registered_with_schemas_and_shape_functions():
+    """disenlink_amd/torch_ops.py: the C ABI as torch.ops.disenlink.* (schema, fake implementation, autograd).  Without a
+    GPU: the operators exist, carry the documented schemas, and their fake implementations propagate shapes / dtypes for
+    fake CUDA tensors — what torch.compile needs to trace through them."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import disenlink_amd.torch_ops as to
+    from disenlink_amd.graph import Graph, PairList
+    for name in ("route_fwd", "aggregate_fwd", "route_aggregate", "route_aggregate_bwd", "score_pairs_terms",
+                 "score_pairs_bwd", "project_fwd", "project_bwd"):
+        assert hasattr(torch.ops.disenlink, name), name
+    assert str(torch.ops.disenlink.route_aggregate.default._schema) == \
+        "disenlink::route_aggregate(Tensor Z, SymInt graph, float beta, float t) -> (Tensor, Tensor, Tensor, Tensor)"
+    g = Graph.from_edge_rows(torch.tensor([0, 1, 2, 3]), torch.tensor([1, 2, 3, 0]), 5)
+    pl = PairList.build(torch.tensor([0, 1, 2]), torch.tensor([3, 4, 0]), 5)
+    hg, hp = to.register_graph(g), to.register_pairs(pl)
+    assert to.register_graph(g) == hg and to.register_pairs(pl) == hp          # idempotent per object
+    with FakeTensorMode():
+        Z = torch.empty(5, 4, 32, device="cuda")
+        H, p, a, s = torch.ops.disenlink.route_aggregate(Z, hg, 0.5, 1.0)
+        prob, coef = torch.ops.disenlink.score_pairs_terms(Z, H, hp, 1.0)
+        dZ, dH = torch.ops.disenlink.score_pairs_bwd(Z, H, prob, prob, coef, hp, 1.0)
+        assert H.shape == Z.shape and p.shape == (8,) and p.dtype == torch.uint8 and s.shape == (5, 4)
+        assert prob.shape == (3,) and coef.shape == (2, 3, 4) and dZ.shape == Z.shape and dH.dtype == torch.float32
+        x = torch.empty(5, 7, device="cuda")
+        Zp = torch.ops.disenlink.project_fwd(x, torch.empty(4, 16, 7, device="cuda"), torch.empty(4, 16, device="cuda"),
+                                             torch.empty(4, 32, 16, device="cuda"), torch.empty(4, 32, device="cuda"))
+        assert Zp.shape == (5, 4, 32)
+    with pytest.raises(ValueError, match="no graph registered"):
+        to._g(10 ** 9)
+    to.release(hg)
+    to.release(hp)
