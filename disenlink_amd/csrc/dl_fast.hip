@@ -571,25 +571,26 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
             run += n;
             trip = n > trip ? n : trip;
         }
-        int* wcol = ent_col[ws.wave];
-        int* wk = ent_k[ws.wave];
+        // sorted per-entry scalars in LDS: the index of the gathered slice (col * K + factor), the accumulator it goes to
+        // and its weight.  The loop below is branch-free on purpose: with `if (live)` around the accumulation hipcc built a
+        // chain of exec-mask branches with s_waitcnt vmcnt(0) inside — the four gathers of a batch ran one at a time and a
+        // slot cost ~37 vector instructions (tools/kernel_isa.py); dead slots now gather a valid slice with weight 0.
+        int* wsl = ent_col[ws.wave];
+        int* wli = ent_k[ws.wave];
         float* ww = ent_w[ws.wave];
-        if (mine) { wcol[pos] = my_col; wk[pos] = my_k; }
+        if (mine) { wsl[pos] = my_col * K + my_k; wli[pos] = my_k / NC; }
         __builtin_amdgcn_wave_barrier();
         Chunk<VEC> acc[ACC];
 #pragma unroll
         for (int i = 0; i < ACC; ++i) acc[i] = zero_chunk<VEC>();
+        const T* zc = Z + c * VEC;
         for (int it = 0; it < trip; it += U) {
             Chunk<VEC> v[U];
-            int kx[U], ix[U];
+            int sx[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool live = it + u < my_cnt;
-                ix[u] = live ? my_off + it + u : -1;
-                const int sl = live ? my_off + it + u : 0;        // trip > 0: slot 0 holds a real entry
-                const int j = wcol[sl];
-                kx[u] = wk[sl];
-                v[u] = Tab<T>::load(Z + (size_t)j * ROW + kx[u] * D + c * VEC);
+                sx[u] = it + u < my_cnt ? my_off + it + u : -1;
+                v[u] = Tab<T>::load(zc + (size_t)(unsigned)wsl[sx[u] < 0 ? 0 : sx[u]] * D);   // trip > 0: slot 0 holds a real entry
             }
             if (it == 0) {                                        // weights: behind the first batch of gathers
                 if (mine) ww[pos] = my_a / one_if_zero(my_s);
@@ -597,12 +598,14 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (ix[u] >= 0) {
-                    const float w = ww[ix[u]];
-                    const int li = kx[u] / NC;
+                const int sl = sx[u] < 0 ? 0 : sx[u];
+                const float w = sx[u] < 0 ? 0.0f : ww[sl];
+                if constexpr (ACC == 1) {
+                    fma_chunk(acc[0], w, v[u]);
+                } else {
+                    const int li = wli[sl];
 #pragma unroll
-                    for (int i = 0; i < ACC; ++i)
-                        if (ACC == 1 || i == li) fma_chunk(acc[i], w, v[u]);
+                    for (int i = 0; i < ACC; ++i) fma_chunk(acc[i], li == i ? w : 0.0f, v[u]);
                 }
             }
         }
