@@ -76,6 +76,29 @@ __device__ __forceinline__ float add_xor(float v) {
     }
 }
 
+// Value of lane `src` (0 .. G-1, a constant once the caller's loop is unrolled) of this lane's aligned group of G lanes.
+// A group of 16 lanes is a DPP row: row_newbcast:src broadcasts inside it as a modifier of a plain VALU move — no trip
+// through the LDS crossbar (HIP's __shfl is ds_bpermute_b32: the scorer backward did 16 of them per loop iteration).
+template <int CTRL>
+__device__ __forceinline__ float dpp_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int G>
+__device__ __forceinline__ float group_bcast(float v, int src) {
+    if constexpr (G == 16) {
+        switch (src) {
+            case 0: return dpp_bcast<0x150>(v);   case 1: return dpp_bcast<0x151>(v);   case 2: return dpp_bcast<0x152>(v);
+            case 3: return dpp_bcast<0x153>(v);   case 4: return dpp_bcast<0x154>(v);   case 5: return dpp_bcast<0x155>(v);
+            case 6: return dpp_bcast<0x156>(v);   case 7: return dpp_bcast<0x157>(v);   case 8: return dpp_bcast<0x158>(v);
+            case 9: return dpp_bcast<0x159>(v);   case 10: return dpp_bcast<0x15A>(v);  case 11: return dpp_bcast<0x15B>(v);
+            case 12: return dpp_bcast<0x15C>(v);  case 13: return dpp_bcast<0x15D>(v);  case 14: return dpp_bcast<0x15E>(v);
+            default: return dpp_bcast<0x15F>(v);
+        }
+    } else {
+        return __shfl(v, (int)((threadIdx.x & (DL_WAVE - 1)) & ~(G - 1)) + src, DL_WAVE);
+    }
+}
+
 // butterfly v += xor(v, OFF) for OFF = HI, HI/2, ..., LO (compile-time recursion: the masks must be constants)
 template <int HI, int LO>
 __device__ __forceinline__ float butterfly_down(float v) {
@@ -179,7 +202,15 @@ __device__ __forceinline__ void group_argmax_first(float& best, int& win) {
 }
 
 // x / t exactly as the reference divides; t == 1 (the usual temperature) skips the IEEE division
-__device__ __forceinline__ float div_t(float x, float t) { return t == 1.0f ? x : x / t; }
+// (t is wave-uniform — a kernel argument.  Written as `t == 1 ? x : x / t` hipcc computed the ten-instruction IEEE division
+// on every call and selected afterwards; the empty asm cannot be speculated, so the division sits behind a scalar branch.)
+__device__ __forceinline__ float div_t(float x, float t) {
+    if (t != 1.0f) {
+        x = x / t;
+        asm volatile("" : "+v"(x));
+    }
+    return x;
+}
 
 __device__ __forceinline__ float one_if_zero(float s) { return s == 0.0f ? 1.0f : s; }
 

@@ -818,10 +818,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
 #pragma unroll
             for (int i = 0; i < VPL; ++i)
                 ck_lane[i] = cc == 0.0f ? 0.0f : cc * ((kb + i == k ? 1.0f : 0.0f) - ex[i] / S) / t;
-            const int gbase = lane & ~(G - 1);
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                const float ck = __shfl(ck_lane[FL::src_slot(kk)], gbase + FL::src_lane(kk), DL_WAVE);
+                const float ck = group_bcast<G>(ck_lane[FL::src_slot(kk)], FL::src_lane(kk));
                 fma_chunk(acc[kk], ck, zj[kk]);
                 fma_chunk(acc[kk], kk == k ? w2 : 0.0f, dhj);
             }
@@ -865,7 +864,10 @@ __device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ 
 // One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
 // in LDS, every lane group then scores one pair per iteration from the gathered v rows.
 template <int K, int D, typename T, bool COEF>
-__global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
+#ifndef DL_SCORE_WAVES
+#define DL_SCORE_WAVES 4
+#endif
+__global__ __launch_bounds__(BLOCK, K <= 8 ? DL_SCORE_WAVES : 1) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
                                                               const T* __restrict__ Z, const T* __restrict__ H,
                                                               float t, float* __restrict__ prob,
                                                               float* __restrict__ coef_e,
@@ -1072,11 +1074,10 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
                 ch_lane[i] = gl == 0.0f ? 0.0f : gl * ek;
                 cz_lane[i] = gl == 0.0f ? 0.0f : gl * pq[i] * ek / t;
             }
-            const int gbase = lane & ~(G - 1);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float ch = __shfl(ch_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
-                const float cz = __shfl(cz_lane[FL::src_slot(k)], gbase + FL::src_lane(k), DL_WAVE);
+                const float ch = group_bcast<G>(ch_lane[FL::src_slot(k)], FL::src_lane(k));
+                const float cz = group_bcast<G>(cz_lane[FL::src_slot(k)], FL::src_lane(k));
                 fma_chunk(accH[k], ch, hv[k]);
                 fma_chunk(accZ[k], cz, zv[k]);
             }
