@@ -50,8 +50,8 @@ L2_GATHER_REF_GBS = (16800.0, 18800.0)   # ibid. §Indexed rows: L2-resident row
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 256 FLOP/clk/CU x 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: dense bf16 MFMA
 # kernels launched by each phase of the step (names as rocprofv3 reports them, template arguments stripped)
-PHASE_KERNELS = {"route": ("route_seg_kernel", "s_rowsum_thread_kernel", "vec_combine_kernel"),
-                 "aggregate": ("aggregate_cls_kernel", "aggregate_seg_kernel", "row_combine_kernel"),
+PHASE_KERNELS = {"route": ("route_seg_kernel", "s_rowsum_thread_kernel"),
+                 "aggregate": ("aggregate_cls_kernel", "row_combine_kernel"),
                  "score": ("score_fwd_seg_kernel",)}
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 NAMES = ("route", "aggregate", "score")
@@ -411,11 +411,17 @@ def main():
     fb_ms = None
     if want("fwd_bwd"):
         gp = torch.full((P,), 1.0 / P, device=device)
+        yb_ = (torch.rand(P, device=device) < 0.2).float()
+        # the training loop's own choice (model.forward_pairs_loss): fp32 tables take the one-pass scorer
+        one_pass_fb = args.dtype == "f32" and ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32)
         def train_step():
             p, a, s = ops.route_fwd(graph, Z, t)
             H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
-            prob, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
-            dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp, coef=coef)
+            if one_pass_fb:
+                _prob, dZs, dH = ops.score_pairs_train(Z, H, pairs, t, yb_, gp)
+            else:
+                prob, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+                dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp, coef=coef)
             return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
         for _ in range(3):
             train_step()
@@ -568,7 +574,9 @@ def main():
              else "or the L2s, and no PMC passes exist for this build and workload") +
             "; this is NOT a fraction of the HBM roofline — the hbm_bound block (tables far beyond every cache) is")
     if fb_ms is not None:
-        result["fwd_bwd"] = {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3)}
+        result["fwd_bwd"] = {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3),
+                             "scorer": "one pass (dl_score_pairs_train)" if one_pass_fb else
+                             "dl_score_pairs_fwd storing terms + dl_score_pairs_bwd"}
     result["scorer_training_step"] = scorer_train
     result["projection"] = proj
     result["dense_allpairs"] = dense

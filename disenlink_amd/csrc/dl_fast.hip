@@ -22,7 +22,6 @@
 //
 // Tables Z and H may be stored as fp32 or bf16 (dl_dtype); all arithmetic and all gradients are fp32.
 #include <stdlib.h>
-#include <string.h>
 #include "dl_common.h"
 #include "dl_kernels.h"
 
@@ -425,100 +424,24 @@ __global__ __launch_bounds__(BLOCK) void vec_combine_kernel(dl_csr_plan g, int K
 }
 
 // ---------------------------------------------------------------------------- aggregate
-// U = gather batches: the loads of U wave iterations (U * 64/G entries) are issued before the first of them is used, so a
-// segment costs ceil(entries / (U * EPW)) memory round trips instead of one per EPW entries (the kernel is latency-bound:
-// 369k edges on 256 CUs).  The per-group summation order is unchanged (entries grp, grp + EPW, ... ascending).
-template <int K, int D, typename T, int U>
-__global__ __launch_bounds__(BLOCK, (K * Tab<T>::VEC <= 32 && U <= 2) ? 8 : 1) void aggregate_seg_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
-                                                              const uint8_t* __restrict__ p,
-                                                              const float* __restrict__ a,
-                                                              const float* __restrict__ s, T* __restrict__ H,
-                                                              float* __restrict__ h_part) {
-    using GE = Geo<K, D, T>;
-    constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, ROW = GE::ROW;
-    using US = Stage<K, D, T, 1>;
-    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
-    const WaveSeg ws = load_wave_seg(g);
-    const SegInfo si = ws.si;
-    const int lane = lane_id();
-    const int c = lane % G, grp = lane / G;
-    if (ws.active) {
-        Chunk<VEC> acc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = zero_chunk<VEC>();
-        // per-entry scalars are computed once by the entry's own lane, then shuffled to its group
-        int my_col = si.grow, my_k = 0;
-        float my_a = 0.0f, my_w = 0.0f;
-        if (si.beg + lane < si.end) {
-            my_col = g.col[si.beg + lane];
-            my_k = p[si.beg + lane];
-            my_a = a[si.beg + lane];
-        }
-        const int cnt = si.end - si.beg;
-        for (int base = 0; base < cnt; base += EPW * U) {
-            Chunk<VEC> v[U];
-            int kx[U], ix[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * EPW + grp;
-                ix[u] = idx < cnt ? idx : -1;                     // past the end: a valid row, weight 0
-                const int ic = idx < cnt ? idx : 0;
-                const int j = __shfl(my_col, ic, DL_WAVE);
-                kx[u] = __shfl(my_k, ic, DL_WAVE);
-                v[u] = Tab<T>::load(Z + (size_t)j * ROW + kx[u] * D + c * VEC);
-            }
-            // the neighbour's normaliser is fetched BEHIND the first batch of row gathers (which need only col and p):
-            // one round trip to memory fewer in a wave's life
-            if (base == 0 && lane < cnt) my_w = my_a / one_if_zero(s[(size_t)my_col * K + my_k]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float w = __shfl(my_w, ix[u] < 0 ? 0 : ix[u], DL_WAVE);
-                const float wu = ix[u] < 0 ? 0.0f : w;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) fma_chunk(acc[kk], (kk == kx[u]) ? wu : 0.0f, v[u]);
-            }
-        }
-        US::put(red, ws.wave, grp, c, acc, 0);
-    }
-    __syncthreads();
-    if (!ws.head) return;
-    float4 r[US::NQ];
-    US::sum(red, ws.wave, ws.n_unit, lane, r);
-    const float omb = 1.0f - beta;
-#pragma unroll
-    for (int q = 0; q < US::NQ; ++q) {
-        const int x = q * DL_WAVE + lane;
-        if (x < US::F4) {
-            if (si.slot < 0) {
-                const size_t o = (size_t)si.grow * ROW + 4 * x;
-                const float4 z = load4<T>(Z + o);
-                store4(H + o, make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
-                                          beta * z.w + omb * r[q].w));
-            } else {
-                store4(h_part + (size_t)si.slot * ROW + 4 * x, r[q]);
-            }
-        }
-    }
-}
-
 // Bits of m below this lane.
 __device__ __forceinline__ int bits_below(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// Aggregation with CLASS-OWNED accumulators (round 3).  The kernel above lets every lane group take every G-th entry,
-// so each group needs an accumulator for every factor: K * VEC registers per lane, K * VEC FMAs + K selects per gathered
+// Aggregation with CLASS-OWNED accumulators (round 3).  The round-2 kernel let every lane group take every G-th entry,
+// so each group needed an accumulator for every factor: K * VEC registers per lane, K * VEC FMAs + K selects per gathered
 // entry to add it to the one accumulator of its factor (40 of the ~55 vector instructions per entry at K = 8), a
 // cross-group butterfly at the end — and at 8 waves per SIMD the K = 8 instantiation spilled 4 registers per lane
 // (1 KB of scratch written and read back per WAVE: the 0.8 GB of unexplained WRITE_SIZE per launch at snap-patents
 // size, profiles/r2q).  Here the entries of a segment are sorted by CLASS = factor % NC first (NC = min(K, groups per
-// wave); ballots + a bit count give every entry its slot, the sorted (column, factor, weight) triples live in LDS) and
-// group g walks the entries of class g: a lane accumulates only the factors g, g + NC, ... — ACC = K / NC accumulators
-// (2 at K = 8, d = 64) — and every (factor, chunk) of the result row is owned by exactly one lane of the wave: no
-// cross-group sum, the lane stores its chunks straight into the wave's staged row.  Inside a (segment, factor) the
-// entries are added in ascending entry order by ONE lane group, whatever the lane geometry: the summation order depends
-// on the row alone.  Cost: the walk takes max_g |class g| steps instead of |segment| / groups (a segment routed entirely
-// to one factor is walked by one group).
+// wave); ballots + a bit count give every entry its slot, the sorted (slice index, accumulator, weight) triples live in
+// LDS) and group g walks the entries of class g: a lane accumulates only the factors g, g + NC, ... — ACC = K / NC
+// accumulators (2 at K = 8, d = 64) — and every (factor, chunk) of the result row is owned by exactly one lane of the
+// wave: no cross-group sum, the lane stores its chunks straight into the wave's staged row.  Inside a (segment, factor)
+// the entries are added in ascending entry order by ONE lane group, whatever the lane geometry: the summation order
+// depends on the row alone.  Cost: the walk takes max_g |class g| steps instead of |segment| / groups (a segment routed
+// entirely to one factor is walked by one group).  U = gathers in flight per group (4: 2 / 8 measured no better).
 template <int K, int D, typename T, int U>
 __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, const T* __restrict__ Z, float beta,
                                                               const uint8_t* __restrict__ p,
@@ -864,10 +787,10 @@ __device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ 
 // One wave per segment of the "pairs by first endpoint" plan: the u rows of Z and H are staged once
 // in LDS, every lane group then scores one pair per iteration from the gathered v rows.
 template <int K, int D, typename T, bool COEF>
-#ifndef DL_SCORE_WAVES
-#define DL_SCORE_WAVES 4
-#endif
-__global__ __launch_bounds__(BLOCK, K <= 8 ? DL_SCORE_WAVES : 1) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
+// (4 waves per SIMD: pinned at 5 / 6 / 8 hipcc keeps fewer row gathers in flight per wave — 301 / 543 / 612 us against
+// 170 on squirrel; whether the u rows sit in registers or are re-read from LDS every iteration makes no difference:
+// the kernel is bound by the vector-L1 / L2 pipeline, 4.3 GB through 256 x 64 B/clk.)
+__global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
                                                               const T* __restrict__ Z, const T* __restrict__ H,
                                                               float t, float* __restrict__ prob,
                                                               float* __restrict__ coef_e,
@@ -1262,18 +1185,8 @@ struct Ops {
 
     static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
                              const float* s, void* H, float* h_part, hipStream_t st) {
-        // DL_AGG_FORM=groups selects the round-2 kernel (every group walks every G-th entry) for A/B timing
-        static const bool old_form = getenv("DL_AGG_FORM") && !strcmp(getenv("DL_AGG_FORM"), "groups");
-        static const int depth = getenv("DL_AGG_DEPTH") ? atoi(getenv("DL_AGG_DEPTH")) : 4;
-        if (old_form)
-            hipLaunchKernelGGL((aggregate_seg_kernel<K, D, T, 2>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                               beta, p, a, s, (T*)H, h_part);
-        else if (depth >= 4)
-            hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                               beta, p, a, s, (T*)H, h_part);
-        else
-            hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 2>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                               beta, p, a, s, (T*)H, h_part);
+        hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
+                           beta, p, a, s, (T*)H, h_part);
         if (g->n_multi > 0)
             hipLaunchKernelGGL((row_combine_kernel<ROW, T, T>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, ROW,
                                (const T*)Z, beta, 1.0f - beta, (T*)H, 0);
