@@ -6,7 +6,7 @@ from disenlink_amd.model import Disentangle
 from disenlink_amd.splits import make_link_split
 from disenlink_amd.train import prepare_run, run_link_prediction
 dev = torch.device("cuda:0")
-sg = synthetic_graph("chameleon", seed=0)
+sg = synthetic_graph(sys.argv[1] if len(sys.argv) > 1 else "chameleon", seed=0)
 split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
 run = prepare_run(split, dev)
 x = torch.from_numpy(sg.features()).to(dev)
