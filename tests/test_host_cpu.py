@@ -406,3 +406,33 @@ def test_torch_library_operators_are_registered_with_schemas_and_shape_functions
         to._g(10 ** 9)
     to.release(hg)
     to.release(hp)
+
+
+def test_feature_rows_do_not_depend_on_who_generates_them():
+    """SyntheticGraph.features(rows=...): every 16,384-row block has its own counter-based stream, so a rank of a
+    sharded run that generates only its own rows gets exactly the rows of the whole matrix."""
+    from disenlink_amd.data import synthetic_graph
+    sg = synthetic_graph("snap_patents", seed=0, scale=0.02)          # 58k nodes: several blocks
+    assert sg.n_nodes > 3 * sg.FEATURE_BLOCK
+    full = sg.features()
+    assert full.shape == (sg.n_nodes, sg.n_feat) and full.dtype == np.float32
+    np.testing.assert_allclose(full.mean(axis=1), 0.0, atol=1e-5)
+    np.testing.assert_allclose(full.std(axis=1, ddof=1), 1.0, rtol=1e-4)
+    for r0, r1 in ((0, 1), (16383, 16385), (20000, 51234), (sg.n_nodes - 5, sg.n_nodes), (777, 777)):
+        assert np.array_equal(sg.features(rows=(r0, r1)), full[r0:r1])
+    with pytest.raises(ValueError):
+        sg.features(rows=(5, sg.n_nodes + 1))
+
+
+def test_split_on_a_torch_device_is_the_numpy_split():
+    """make_link_split(device=...): the sorts / searches run through torch (on the GPU in the sharded bench), the random
+    draws stay in numpy — the pair sets must come out identical, element for element."""
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.splits import make_link_split
+    sg = synthetic_graph("chameleon", seed=3)
+    a = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=3)
+    b = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=3, device=torch.device("cpu"))
+    assert np.array_equal(a.train_src, b.train_src) and np.array_equal(a.train_dst, b.train_dst)
+    for name in ("pos_train", "neg_train", "val", "test"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert np.array_equal(x.u, y.u) and np.array_equal(x.v, y.v) and np.array_equal(x.label, y.label), name
