@@ -161,6 +161,20 @@ __device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
     q.y = f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16);
     *reinterpret_cast<uint2*>(p) = q;
 }
+// Streaming (non-temporal) store: the line is not kept in the caches for re-use.  For an output table far larger than the
+// caches (the H rows of the aggregation where HBM binds) that leaves the L2 / Infinity Cache to the gathered slices and
+// the normalisers: snap-patents x0.25 aggregation 789 -> 750 us.  On cache-resident graphs the next kernel WANTS the rows
+// in cache (the scorer reads H right away): the caller decides per launch.
+__device__ __forceinline__ void store4_stream(float* p, const float4& v) {
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    vf4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(p));
+}
+__device__ __forceinline__ void store4_stream(bf16_t* p, const float4& v) {
+    typedef unsigned int vu2 __attribute__((ext_vector_type(2)));
+    vu2 q = {f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16), f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16)};
+    __builtin_nontemporal_store(q, reinterpret_cast<vu2*>(p));
+}
 
 // ---------------------------------------------------------------------------- unit reduction through LDS
 // A segment kernel ends with per-GROUP partial results: lane c of group g holds elements kk*D + c*VEC .. of every factor
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
                                                               const uint8_t* __restrict__ p,
                                                               const float* __restrict__ a,
                                                               const float* __restrict__ s, T* __restrict__ H,
-                                                              float* __restrict__ h_part) {
+                                                              float* __restrict__ h_part, int stream_out) {
     using GE = Geo<K, D, T>;
     constexpr int VEC = GE::VEC, G = GE::G, NG = GE::EPW, ROW = GE::ROW;
     constexpr int NC = K < NG ? K : NG;                           // classes = lane groups at work
@@ -550,9 +564,10 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
         if (x < US::F4) {
             if (direct) {
                 const float4 z = zrow[q];
-                store4(H + (size_t)si.grow * ROW + 4 * x,
-                       make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
-                                   beta * z.w + omb * r[q].w));
+                const float4 h = make_float4(beta * z.x + omb * r[q].x, beta * z.y + omb * r[q].y, beta * z.z + omb * r[q].z,
+                                             beta * z.w + omb * r[q].w);
+                if (stream_out) store4_stream(H + (size_t)si.grow * ROW + 4 * x, h);
+                else store4(H + (size_t)si.grow * ROW + 4 * x, h);
             } else {
                 store4(h_part + (size_t)si.slot * ROW + 4 * x, r[q]);
             }
@@ -1167,6 +1182,15 @@ template <int K, int D, typename T>
 struct Ops {
     static constexpr int ROW = K * D;
 
+    // The H rows of the aggregation go out as streaming stores when the table is far beyond the caches (256 MiB Infinity
+    // Cache); on cache-resident graphs the scorer wants them in cache.  (The dZ / dH rows of the training kernels were
+    // tried too: a snap-patents-sized epoch 311 -> 319 ms with all of them streaming — only the forward H store pays.)
+    static int stream_rows(const dl_csr_plan* g, size_t elem = sizeof(float)) {
+        static const char* force = getenv("DL_STREAM_ROWS");      // 0 / 1: measurements only
+        if (force) return force[0] == '1';
+        return (size_t)g->n_total * ROW * elem > ((size_t)256 << 20) ? 1 : 0;
+    }
+
     // `route`: the (possibly sliced / upper-triangle) plan the routing kernel walks, NULL = g itself;
     // mirror: it covers col >= row only and every result is also written through rev
     static int route_fwd(const dl_csr_plan* g, const dl_csr_plan* route, bool mirror, const int32_t* rev,
@@ -1186,7 +1210,7 @@ struct Ops {
     static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
                              const float* s, void* H, float* h_part, hipStream_t st) {
         hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                           beta, p, a, s, (T*)H, h_part);
+                           beta, p, a, s, (T*)H, h_part, stream_rows(g, sizeof(T)));
         if (g->n_multi > 0)
             hipLaunchKernelGGL((row_combine_kernel<ROW, T, T>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, ROW,
                                (const T*)Z, beta, 1.0f - beta, (T*)H, 0);

@@ -12,7 +12,7 @@ epochs = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
 sg = synthetic_graph(name, seed=0)
-split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
+split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0, device=dev)     # sorts / searches on the GPU: same split
 run = prepare_run(split, dev, row_bytes=K * d * (2 if dt == "bf16" else 4))
 x = torch.from_numpy(sg.features()).to(dev)
 print(f"{name}: N={sg.n_nodes} F={sg.n_feat} train pairs {run.n_pos + run.n_neg} prep {time.perf_counter() - t0:.1f} s", flush=True)
