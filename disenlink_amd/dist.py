@@ -523,7 +523,7 @@ def _bench_problem(args, world_for_scale: int, rank: int = 0, world: int = 1, de
     """The benchmark problem, built ONCE: rank 0 generates the graph, the split and the sorted pair list and writes the
     four index arrays to /dev/shm; the other ranks read them (round 2: every rank repeated the whole host preparation —
     104 s for snap-patents, times N ranks on one host).  Feature rows are generated per rank, for its own rows only."""
-    from .data import SyntheticGraph, SPECS
+    from .data import SyntheticGraph
     scale = args.scale * (world_for_scale if args.scaling == "weak" else 1)
     t0 = time.perf_counter()
     shm = os.environ.get("DL_SHARE_DIR", "/dev/shm")
@@ -549,13 +549,15 @@ def _bench_problem(args, world_for_scale: int, rank: int = 0, world: int = 1, de
         sg = SyntheticGraph(m["name"], m["n_nodes"], empty, empty, m["n_feat"], m["seed"])
         arrs = {n: np.load(f"{base}_{n}.npy") for n in names}
         prob = BenchProblem(sg, m["edge_rows"], arrs["train_src"], arrs["train_dst"], arrs["pu"], arrs["pv"], scale)
-    dist.barrier()                                                # everyone has read: rank 0 removes the files
-    if rank == 0:
-        for n in names:
-            try:
-                os.remove(f"{base}_{n}.npy")
-            except OSError:
-                pass
+    try:
+        dist.barrier()                                            # everyone has read: rank 0 removes the files
+    finally:
+        if rank == 0:
+            for n in names:
+                try:
+                    os.remove(f"{base}_{n}.npy")
+                except OSError:
+                    pass
     prob.prep_s = time.perf_counter() - t0
     return prob
 
