@@ -61,6 +61,22 @@ class RunResult:
 
 
 _FUSED_ADAM = os.environ.get("DL_FUSED_ADAM", "1") != "0"
+_STACKED_ADAM = os.environ.get("DL_STACKED_ADAM", "1") != "0"
+
+
+def _make_adam(model, on_gpu: bool, lr: float, weight_decay: float, capturable: bool = False):
+    """The reference's Adam (main_disentangled.py:150).  On the GPU, for the drop-in module: the same fused update over
+    the module's 4 shared parameter buffers instead of its 4K views (optim.StackedAdam: same bits, an eighth of the
+    optimiser's launches' chunks and Python work); otherwise torch's own."""
+    if on_gpu and _FUSED_ADAM and _STACKED_ADAM and getattr(model, "_stacked_params", None) is not None \
+            and model._stacked_params() is not None:
+        from .optim import StackedAdam
+        return StackedAdam(model, lr=lr, weight_decay=weight_decay, capturable=capturable)
+    if capturable:
+        return Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=_FUSED_ADAM)
+    return Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=on_gpu and _FUSED_ADAM)
+
+
 def _scores_and_loss(model, x, run, label_all, weight_all):
     """(prob over [pos | neg | validation], loss) of one training forward on the GPU path; the model decides whether
     the scorer runs forward + loss gradient + backward in one pass (model.forward_pairs_loss, DL_ONE_PASS_SCORER)."""
@@ -86,13 +102,16 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     """Capture one full epoch (forward, fused loss, backward, Adam step, validation AUC) into a HIP graph:
     every launch of the epoch — ours and torch's — is replayed with one host call, which removes the
     launch-bound host time of small graphs.  Returns (replay, out) with out = [loss, auc] on the device."""
-    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=_FUSED_ADAM)
+    opt = _make_adam(model, True, lr, weight_decay, capturable=True)
     out = torch.zeros(2, dtype=torch.float64, device=x.device)
     val_plan = AucPlan(run.label_val)
 
     def epoch():
         prob, loss = _scores_and_loss(model, x, run, label_all, weight_all)
-        opt.zero_grad(set_to_none=False)
+        # gradients are (re)created by the backward inside the capture — they come from the graph's own memory pool, so
+        # replays find them at the same addresses (torch's whole-network capture recipe).  Keeping pre-allocated
+        # gradients instead (zero_grad(set_to_none=False)) cost 4K fills and 4K accumulating adds per epoch.
+        opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         out[0] = loss.detach().double()
@@ -101,8 +120,6 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                                   # warm-up on a side stream, as capture requires
-        for p in model.parameters():
-            p.grad = torch.zeros_like(p)
         snap = model.snapshot_state() if hasattr(model, "snapshot_state") else deepcopy(model.state_dict())
         for _ in range(2):
             epoch()
@@ -140,7 +157,7 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
         return _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log)
     # same update rule as the reference's Adam (main_disentangled.py:150); on the GPU torch's single-kernel
     # ("fused") implementation of it instead of one multi-tensor launch per elementwise step
-    opt = Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=bool(x.is_cuda) and _FUSED_ADAM)
+    opt = _make_adam(model, bool(x.is_cuda), lr, weight_decay)
     snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
     best_auc, stale, weights = 0.0, 0, snapshot()
     res = RunResult(float("nan"), 0.0, 0)

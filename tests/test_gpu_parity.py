@@ -1489,3 +1489,35 @@ def test_training_with_the_one_pass_scorer_follows_the_separate_kernels(use_grap
     np.testing.assert_allclose(out["1"].losses, out["0"].losses, rtol=2e-3)
     np.testing.assert_allclose(out["1"].val_aucs, out["0"].val_aucs, atol=1e-3)
     assert abs(out["1"].test_auc - out["0"].test_auc) <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_stacked_adam_is_torch_adam_bit_for_bit(use_graph, monkeypatch):
+    """optim.StackedAdam (the fused Adam update over the module's 4 shared parameter buffers instead of its 4K views)
+    against torch.optim.Adam(fused=True) over the parameters: the same training run — losses, validation AUCs, final
+    weights — bit for bit, eager and replayed from a HIP graph; and the eager loop really takes the gradients as the
+    stacked tensors the projection's backward produced (no stacking copy)."""
+    from disenlink_amd import optim, train
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    sg = synthetic_graph("chameleon", seed=2)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=2)
+    run = train.prepare_run(split, torch.device(DEV), row_bytes=8 * 64 * 4)
+    x = torch.from_numpy(sg.features()).to(DEV)
+    fast = []
+    orig = optim.StackedAdam._stacked_grad
+    monkeypatch.setattr(optim.StackedAdam, "_stacked_grad",
+                        lambda self, key: (lambda g: (fast.append(g._base is None and g.dim() == self.model._stacked[key].dim()), g)[1])(orig(self, key)))
+    out = {}
+    for stacked in (True, False):
+        monkeypatch.setattr(train, "_STACKED_ADAM", stacked)
+        torch.manual_seed(0)
+        model = Disentangle(sg.n_feat, 64, 64, nfactor=8, beta=0.6, t=1).to(DEV)
+        res = train.run_link_prediction(model, x, run, epochs=12, lr=1e-3, use_graph=use_graph)
+        out[stacked] = (res.losses, res.val_aucs, res.test_auc, [p.detach().clone() for p in model.parameters()])
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1] and out[True][2] == out[False][2]
+    for a_, b_ in zip(out[True][3], out[False][3]):
+        assert torch.equal(a_, b_)
+    assert fast and (use_graph or all(fast)), fast[:8]              # eager: every gradient arrived stacked

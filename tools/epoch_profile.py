@@ -16,4 +16,4 @@ run_link_prediction(model, x, run, epochs=3, lr=1e-4)
 pr = cProfile.Profile(); pr.enable()
 run_link_prediction(model, x, run, epochs=30, lr=1e-4)
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:4500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(32); print(s.getvalue()[:4500])
