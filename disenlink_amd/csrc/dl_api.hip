@@ -293,6 +293,19 @@ int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, 
     return pair_bce(prob, y, w, n_pairs, loss, g, partial, (hipStream_t)stream);
 }
 
+int dl_adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const size_t* numel, float* state, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, void* stream) {
+    DL_REQUIRE(n_bufs >= 0 && n_bufs <= DL_ADAM_MAX_BUFS, "n_bufs=%d outside 0..%d", n_bufs, DL_ADAM_MAX_BUFS);
+    DL_REQUIRE(state != nullptr, "state is NULL");
+    DL_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "bad Adam hyper-parameters");
+    if (n_bufs > 0) DL_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "NULL argument");
+    for (int i = 0; i < n_bufs; ++i)
+        DL_REQUIRE(numel[i] == 0 || (params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i]), "buffer %d: NULL pointer", i);
+    return adam_step(n_bufs, params, grads, exp_avg, exp_avg_sq, numel, state, lr, beta1, beta2, eps, weight_decay,
+                     (hipStream_t)stream);
+}
+
 int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,
                        const dl_pair_incidence* inc, const float* prob, const float* g_prob, const float* coef,
                        float* dZ, float* dH, void* ws, size_t ws_bytes, void* stream) {

@@ -61,6 +61,10 @@ bool auc_counts_supported(int n_pos, int n_neg);           // the smaller class 
 int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
                     unsigned long long* u2, hipStream_t st);
 
+int adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+              const size_t* numel, float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+              hipStream_t st);
+
 int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,
              hipStream_t st);
 

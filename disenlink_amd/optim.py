@@ -2,11 +2,13 @@
 
 The reference trains with ``torch.optim.Adam(model.parameters(), lr, weight_decay=5e-4)`` (main_disentangled.py:150).
 ``Disentangle`` keeps its 4K per-factor Parameters as views of 4 contiguous ``[K, ...]`` buffers (model._restack), and the
-projection's backward produces their gradients as 4 stacked tensors too — so the update can run on 4 tensors instead of
-4K: the same fused elementwise kernel (``torch._fused_adam_``: identical arithmetic per element, hence the same bits as
-``Adam(fused=True)`` over the views), one launch over 4 chunks lists instead of 32, and an eighth of the optimiser's
-per-step Python work (squirrel: 45 -> ~10 us of kernel time per epoch; the eager chameleon epoch is host-bound and gains
-more).  Falls back to a stacking copy of the gradients when they are not views of one buffer.
+projection's backward produces their gradients as 4 stacked tensors too — so the update runs on 4 tensors instead of 4K.
+On the GPU it is ``dl_adam_step`` of libdisenlink_hip.so: torch.optim.Adam's arithmetic (weight decay added to the
+gradient, bias-corrected moments, step counter on the device: no sync, graph-capturable), one float4 per thread in one
+launch — torch's fused Adam walks 65,536-element chunks with one block each, 13 blocks and 44 us of latency for this
+model's 0.8M parameters; this takes a few microseconds.  ``use_torch_kernel=True`` keeps ``torch._fused_adam_`` over the
+4 buffers (bit-identical to ``Adam(fused=True)`` over the views: the test of the stacking itself).  Falls back to a
+stacking copy of the gradients when they are not views of one buffer.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ class StackedAdam:
     ``capturable=True`` keeps the step counters on the device and does nothing that a HIP-graph capture forbids."""
 
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 capturable: bool = False):
+                 capturable: bool = False, use_torch_kernel: bool = False):
         if model._stacked_params() is None:
             raise ValueError("StackedAdam needs a module whose parameters alias its stacked buffers")
         self.model = model
@@ -32,9 +34,20 @@ class StackedAdam:
         # one step counter per buffer, as torch's fused Adam wants them (on the device: no sync, capturable)
         self.steps = [torch.zeros((), dtype=torch.float32, device=dev) for _ in self.bufs]
         self.capturable = capturable
+        self.use_torch_kernel = bool(use_torch_kernel) or not self.bufs[0].is_cuda or \
+            any(b.dtype != torch.float32 for b in self.bufs)
+        self.dl_state = torch.zeros(3, dtype=torch.float32, device=dev)      # dl_adam_step: step, 1-b1^t, sqrt(1-b2^t)
         # what a captured graph replays must stay alive and in place: exposed like torch's optimizer.state
         self.state = {i: {"step": self.steps[i], "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
                       for i in range(len(self.bufs))}
+        self.state["dl"] = {"state": self.dl_state}
+        if not self.use_torch_kernel:
+            import ctypes as C
+            n = len(self.bufs)
+            self._C = C
+            self._ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            self._p, self._m, self._v = self._ptrs(self.bufs), self._ptrs(self.exp_avg), self._ptrs(self.exp_avg_sq)
+            self._numel = (C.c_size_t * n)(*[b.numel() for b in self.bufs])
 
     def zero_grad(self, set_to_none: bool = True):
         for ps in self.groups.values():
@@ -64,6 +77,14 @@ class StackedAdam:
             raise RuntimeError("the module's parameter buffers were rebuilt (.to() / load on another device): "
                                "create the optimiser afterwards")
         grads = [self._stacked_grad(k) for k in self.keys]
+        if not self.use_torch_kernel:
+            from . import _lib
+            self._grads_alive = grads                              # the launch is asynchronous
+            _lib.check(_lib.load().dl_adam_step(len(self.bufs), self._p, self._ptrs([g.contiguous() for g in grads]), self._m,
+                                                self._v, self._numel, self.dl_state.data_ptr(), self.lr, self.betas[0],
+                                                self.betas[1], self.eps, self.weight_decay,
+                                                torch.cuda.current_stream().cuda_stream), "dl_adam_step")
+            return
         torch._foreach_add_(self.steps, 1)
         torch._fused_adam_(self.bufs, grads, self.exp_avg, self.exp_avg_sq, [], self.steps, lr=self.lr,
                            beta1=self.betas[0], beta2=self.betas[1], weight_decay=self.weight_decay, eps=self.eps,

@@ -275,6 +275,20 @@ int dl_auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, co
 int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g,
                 void* ws, size_t ws_bytes, void* stream);
 
+/* The optimiser step of the training loop: torch.optim.Adam's update (main_disentangled.py:150 — weight decay added to
+ * the gradient, bias-corrected first and second moments) over n_bufs <= DL_ADAM_MAX_BUFS contiguous fp32 buffers in one
+ * launch:
+ *   g' = g + weight_decay p;  m = m + (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= (lr / (1 - beta1^step)) * m / ( sqrt(v) / sqrt(1 - beta2^step) + eps )
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_bufs device pointers, numel: host array of element counts.
+ * state: 3 device floats owned by the caller, zero-initialised once: the step counter and the two bias corrections —
+ * the call increments the counter ON THE DEVICE first (no host sync; a captured graph replays it).  Same arithmetic as
+ * torch's fused Adam up to the rounding of the bias corrections. */
+#define DL_ADAM_MAX_BUFS 8
+int dl_adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const size_t* numel, float* state,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
  * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:
  *   gl = g_prob * prob * (1 - prob);  dH[u] += gl e_k H[v][k];  dZ[u] += gl (q_k e_k)/t Z[v][k]
