@@ -294,11 +294,11 @@ int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, 
 }
 
 int dl_adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
-                 float* const* exp_avg_sq, const size_t* numel, float* state, float lr, float beta1, float beta2,
-                 float eps, float weight_decay, void* stream) {
+                 float* const* exp_avg_sq, const size_t* numel, float* state, double lr, double beta1, double beta2,
+                 double eps, double weight_decay, void* stream) {
     DL_REQUIRE(n_bufs >= 0 && n_bufs <= DL_ADAM_MAX_BUFS, "n_bufs=%d outside 0..%d", n_bufs, DL_ADAM_MAX_BUFS);
     DL_REQUIRE(state != nullptr, "state is NULL");
-    DL_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "bad Adam hyper-parameters");
+    DL_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "bad Adam hyper-parameters");
     if (n_bufs > 0) DL_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "NULL argument");
     for (int i = 0; i < n_bufs; ++i)
         DL_REQUIRE(numel[i] == 0 || (params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i]), "buffer %d: NULL pointer", i);

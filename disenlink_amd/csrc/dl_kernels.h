@@ -62,7 +62,7 @@ int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const
                     unsigned long long* u2, hipStream_t st);
 
 int adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-              const size_t* numel, float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+              const size_t* numel, float* state, double lr, double beta1, double beta2, double eps, double weight_decay,
               hipStream_t st);
 
 int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,

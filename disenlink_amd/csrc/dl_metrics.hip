@@ -110,7 +110,7 @@ int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const
 // one 512-thread block each — 13 blocks for this model's 0.8M parameters, 44 us of pure latency per step.  The step
 // counter lives on the device (no host sync, graph-capturable): a one-thread kernel increments it and leaves the bias
 // corrections next to it, then every thread of the update reads those three floats.
-//   state[0] = step (as float), state[1] = 1 - beta1^step, state[2] = sqrt(1 - beta2^step)
+//   state[0] = step (as float), state[1] = lr / (1 - beta1^step), state[2] = sqrt(1 - beta2^step)
 namespace dl {
 
 struct AdamBufs {
@@ -123,22 +123,22 @@ struct AdamBufs {
     int count;
 };
 
-__global__ void adam_advance_kernel(float* __restrict__ state, double beta1, double beta2) {
+__global__ void adam_advance_kernel(float* __restrict__ state, double lr, double beta1, double beta2) {
     const float step = state[0] + 1.0f;
     state[0] = step;
-    state[1] = (float)(1.0 - pow(beta1, (double)step));
+    state[1] = (float)(lr / (1.0 - pow(beta1, (double)step)));               // step size lr / (1 - beta1^step)
     state[2] = (float)sqrt(1.0 - pow(beta2, (double)step));
 }
 
-__global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, const float* __restrict__ state, float lr, float beta1,
-                                                          float beta2, float eps, float weight_decay) {
+// w1 = 1 - beta1, w2 = 1 - beta2 (formed in double on the host, like torch's kernel arguments)
+__global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, const float* __restrict__ state, float w1, float beta2,
+                                                          float w2, float eps, float weight_decay) {
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     int i = 0;
     while (i < b.count && q >= b.n4_end[i]) ++i;
     if (i >= b.count) return;
     const unsigned long long e0 = (q - (i ? b.n4_end[i - 1] : 0ull)) * 4;
-    const float bc1 = state[1], bc2s = state[2];
-    const float step_size = lr / bc1;
+    const float step_size = state[1], bc2s = state[2];
     float* __restrict__ p = b.p[i];
     const float* __restrict__ g = b.g[i];
     float* __restrict__ m = b.m[i];
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, const floa
             const float pe = p[e];
             float ge = g[e];
             if (weight_decay != 0.0f) ge = fmaf(pe, weight_decay, ge);
-            const float me = fmaf(ge - m[e], 1.0f - beta1, m[e]);                    // lerp(m, g, 1 - beta1)
-            const float ve = beta2 * v[e] + (1.0f - beta2) * ge * ge;
+            const float me = fmaf(ge - m[e], w1, m[e]);                              // lerp(m, g, 1 - beta1)
+            const float ve = beta2 * v[e] + w2 * ge * ge;
             m[e] = me;
             v[e] = ve;
             const float denom = sqrtf(ve) / bc2s + eps;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, const floa
 }
 
 int adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-              const size_t* numel, float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+              const size_t* numel, float* state, double lr, double beta1, double beta2, double eps, double weight_decay,
               hipStream_t st) {
     AdamBufs b;
     unsigned long long run = 0;
@@ -172,10 +172,10 @@ int adam_step(int n_bufs, float* const* params, const float* const* grads, float
         b.n4_end[i] = run;
     }
     b.count = n_bufs;
-    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, state, (double)beta1, (double)beta2);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, state, lr, beta1, beta2);
     if (run > 0)
-        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)((run + 255) / 256)), dim3(256), 0, st, b, (const float*)state, lr,
-                           beta1, beta2, eps, weight_decay);
+        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)((run + 255) / 256)), dim3(256), 0, st, b, (const float*)state,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     return check_launch("adam_step");
 }
 

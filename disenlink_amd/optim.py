@@ -36,7 +36,7 @@ class StackedAdam:
         self.capturable = capturable
         self.use_torch_kernel = bool(use_torch_kernel) or not self.bufs[0].is_cuda or \
             any(b.dtype != torch.float32 for b in self.bufs)
-        self.dl_state = torch.zeros(3, dtype=torch.float32, device=dev)      # dl_adam_step: step, 1-b1^t, sqrt(1-b2^t)
+        self.dl_state = torch.zeros(3, dtype=torch.float32, device=dev)      # dl_adam_step: step, lr/(1-b1^t), sqrt(1-b2^t)
         # what a captured graph replays must stay alive and in place: exposed like torch's optimizer.state
         self.state = {i: {"step": self.steps[i], "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
                       for i in range(len(self.bufs))}

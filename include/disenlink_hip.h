@@ -281,13 +281,14 @@ int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, 
  *   g' = g + weight_decay p;  m = m + (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
  *   p -= (lr / (1 - beta1^step)) * m / ( sqrt(v) / sqrt(1 - beta2^step) + eps )
  * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_bufs device pointers, numel: host array of element counts.
- * state: 3 device floats owned by the caller, zero-initialised once: the step counter and the two bias corrections —
- * the call increments the counter ON THE DEVICE first (no host sync; a captured graph replays it).  Same arithmetic as
- * torch's fused Adam up to the rounding of the bias corrections. */
+ * state: 3 device floats owned by the caller, zero-initialised once: the step counter, the step size lr / (1 - beta1^step)
+ * and sqrt(1 - beta2^step) — the call increments the counter ON THE DEVICE first (no host sync; a captured graph replays
+ * it).  Hyper-parameters are doubles like torch's (the bias corrections are formed in double).  Same arithmetic as
+ * torch's fused Adam up to rounding. */
 #define DL_ADAM_MAX_BUFS 8
 int dl_adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const size_t* numel, float* state,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+                 double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
  * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:

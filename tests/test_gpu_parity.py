@@ -1531,3 +1531,40 @@ def test_stacked_adam_is_torch_adam(use_graph, monkeypatch):
     for c_, b_ in zip(c[3], b[3]):
         assert torch.allclose(c_, b_, rtol=1e-3, atol=2e-5), float((c_ - b_).abs().max())
     assert fast and (use_graph or all(fast)), fast[:8]              # eager: every gradient arrived stacked
+
+
+@pytest.mark.gpu
+def test_adam_step_kernel_matches_torch_adam_on_odd_sizes():
+    """dl_adam_step against torch.optim.Adam (the reference's optimiser, main_disentangled.py:150) on buffers whose sizes
+    are not multiples of 4 (the kernel works in float4 units across buffer boundaries), with and without weight decay,
+    over 25 steps: parameters and both moments; the step counter lives on the device."""
+    import ctypes as C
+    from disenlink_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    sizes = [1, 7, 1030, 4096, 65537, 3]
+    for wd in (0.0, 5e-4):
+        ps = [torch.randn(n, device=DEV) for n in sizes]
+        ref = [p.clone().requires_grad_(True) for p in ps]
+        opt = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd)
+        m = [torch.zeros_like(p) for p in ps]
+        v = [torch.zeros_like(p) for p in ps]
+        state = torch.zeros(3, device=DEV)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        numel = (C.c_size_t * len(ps))(*sizes)
+        for step in range(25):
+            gs = [torch.randn(n, device=DEV) * (0.1 + step) for n in sizes]
+            for r, g in zip(ref, gs):
+                r.grad = g.clone()
+            opt.step()
+            _lib.check(lib.dl_adam_step(len(ps), arr(ps), arr(gs), arr(m), arr(v), numel, state.data_ptr(), 1e-2, 0.9, 0.999,
+                                        1e-8, wd, torch.cuda.current_stream().cuda_stream), "dl_adam_step")
+        assert float(state[0]) == 25.0
+        assert abs(float(state[1]) - 1e-2 / (1 - 0.9 ** 25)) < 1e-8 and abs(float(state[2]) - (1 - 0.999 ** 25) ** 0.5) < 1e-7
+        for p, r in zip(ps, ref):
+            assert torch.allclose(p, r.detach(), rtol=5e-6, atol=5e-7), (wd, p.numel(), float((p - r.detach()).abs().max()))
+        for r, mm, vv in zip(ref, m, v):
+            st = opt.state[r]
+            assert torch.allclose(mm, st["exp_avg"], rtol=1e-5, atol=1e-7) and torch.allclose(vv, st["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+    rc = lib.dl_adam_step(9, None, None, None, None, None, state.data_ptr(), 1e-2, 0.9, 0.999, 1e-8, 0.0, None)
+    assert rc == -1 and b"n_bufs" in lib.dl_last_error()
