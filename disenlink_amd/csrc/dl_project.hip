@@ -155,9 +155,20 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     // of the first MFMA block of step s (every wave left that buffer at the barrier before), and the loads of
     // tile s+2 are issued right behind it.
     if (steps > 0) {
-        fetch(0);
-        stash(0);
-        if (steps > 1) fetch(1);
+        if constexpr (SPLIT) {
+            // tiles 0 and 1 in flight together (a second register set while no accumulator is live yet): one global
+            // round trip in the prologue instead of two — a workgroup runs only 8 steps at F = 128
+            PlaneStage<NTHR, SPLIT_COLS> x0, w0;
+            x0.fetch(P.x + plane_tile<SPLIT_COLS>(item.a, 0, P.ncb), tid);
+            w0.fetch(P.w + (size_t)k * P.w_batch + plane_tile<SPLIT_COLS>(hc0, 0, P.ncb), tid);
+            fetch(min(1, steps - 1));
+            x0.stash(xp, tid);
+            w0.stash(wp, tid);
+        } else {
+            fetch(0);
+            stash(0);
+            if (steps > 1) fetch(1);
+        }
     }
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
@@ -501,9 +512,13 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         char* base = static_cast<char*>(ws);
         __bf16* xP = reinterpret_cast<__bf16*>(base + L.off_xp);
         __bf16* wP = reinterpret_cast<__bf16*>(base + L.off_wp);
-        split_rows(W1, K, nhid, F, F, (size_t)nhid * F, wP, st);
         __bf16* w2P = reinterpret_cast<__bf16*>(base + L.off_w2p);
-        split_w2(W2, K * d, nhid, w2P, L.nhid_p, st);
+        if (L.R >= N) {                                     // one node block: all three operand splits in one launch
+            split_fwd_operands(x, N, F, xP, W1, K, nhid, wP, W2, d, w2P, L.nhid_p, st);
+        } else {
+            split_rows(W1, K, nhid, F, F, (size_t)nhid * F, wP, st);
+            split_w2(W2, K * d, nhid, w2P, L.nhid_p, st);
+        }
         P = FwdPlanes{xP, wP, plane_array_elems(nhid, F, SPLIT_COLS), plane_chunks<SPLIT_COLS>(F, SPLIT_COLS),
                       w2P, (size_t)K * d * L.nhid_p, L.nhid_p};
     }
@@ -517,7 +532,7 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         const float* xb = x + (size_t)row0 * F;
         float* ob = out + (size_t)row0 * K * d;
         float* hb = hid_out ? hid_out + row0 : nullptr;
-        if (split) split_rows(xb, 1, rows, F, F, 0, const_cast<__bf16*>(P.x), st);
+        if (split && L.R < N) split_rows(xb, 1, rows, F, F, 0, const_cast<__bf16*>(P.x), st);
 #define DL_P2(DD)                                                                                       \
     if (d == DD) {                                                                                      \
         if (split && vec) launch2_t<DD, true, true>(rows, K, G, cpg, st, xb, F, nhid, W1, b1, W2, bias2, ob, hb, ldh, P);   \

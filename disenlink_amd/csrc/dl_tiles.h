@@ -218,6 +218,9 @@ void split_rows(const float* src, int B, int R, int C, int ld, size_t sb, __bf16
 void split_transposed(const float* src, int R, int C, int ld, __bf16* dst, hipStream_t st);
 // W2 [rows][nhid] -> planes [3][rows][nhid_p] in the k-slot order of the forward's layer 2 (dl_planes.hip)
 void split_w2(const float* W2, int rows, int nhid, __bf16* dst, int nhid_p, hipStream_t st);                 // 16-column tiles, columns (= R) padded to 128
+// x [N][F], W1 [K][nhid][F] and W2 [K*d][nhid] in one launch (the two-layer forward's operands)
+void split_fwd_operands(const float* x, int N, int F, __bf16* xP, const float* W1, int K, int nhid, __bf16* wP,
+                        const float* W2, int d, __bf16* w2P, int nhid_p, hipStream_t st);
 
 }  // namespace project
 }  // namespace dl
