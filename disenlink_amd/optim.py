@@ -58,17 +58,22 @@ class StackedAdam:
                     p.grad.zero_()
 
     def _stacked_grad(self, key) -> torch.Tensor:
+        """The K gradients of one parameter group as ONE [K, ...] tensor.  The projection's backward hands out the K
+        slices of a stacked gradient (ops.ProjectStacked): when the K .grad tensors lie back to back in one storage —
+        checked by address, since views made in a backward (grad mode off) carry no ``_base`` — the stacked tensor is a
+        view over them (no copy); otherwise they are stacked (one copy)."""
         ps = self.groups[key]
         g0 = ps[0].grad
         if g0 is None:
             raise RuntimeError("StackedAdam.step(): a parameter has no gradient")
-        base = g0._base
         buf = self.model._stacked[key]
-        if base is not None and base.shape == buf.shape and base.is_contiguous() and base.dtype == buf.dtype:
-            p0, step = base.data_ptr(), base.stride(0) * base.element_size()
-            if all(p.grad is not None and p.grad._base is base and p.grad.data_ptr() == p0 + i * step
-                   for i, p in enumerate(ps)):
-                return base                                        # the K gradients ARE one stacked tensor
+        if g0.is_contiguous() and g0.dtype == buf.dtype and g0.shape == buf.shape[1:]:
+            p0, step, st0 = g0.data_ptr(), g0.numel() * g0.element_size(), g0.untyped_storage().data_ptr()
+            if all(p.grad is not None and p.grad.shape == g0.shape and p.grad.dtype == g0.dtype and p.grad.is_contiguous()
+                   and p.grad.data_ptr() == p0 + i * step and p.grad.untyped_storage().data_ptr() == st0
+                   for i, p in enumerate(ps)) and \
+                    g0.untyped_storage().nbytes() >= (p0 - st0) + len(ps) * step:
+                return g0.as_strided(tuple(buf.shape), tuple(buf.stride()))     # the K gradients ARE one stacked tensor
         return torch.stack([p.grad for p in ps])
 
     @torch.no_grad()
