@@ -150,6 +150,12 @@ def aggregate_fwd(g: Graph, Z: torch.Tensor, beta: float, p, a, s, H_out: torch.
     return H
 
 
+def score_terms_available(K: int, d: int, dt: int) -> bool:
+    """Whether dl_score_pairs_fwd hands out the per-factor logit terms the backward can reuse (the tuned scorer only)."""
+    lib = _lib.load()
+    return bool(lib.dl_has_fast_path_dtype(K, d, dt)) and not lib.dl_set_force_generic(-1)
+
+
 def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_coef: bool = False):
     """-> prob f32[P].  model.py:109-113 at the listed pairs.  ``pairs`` (the PairList the index arrays
     belong to) enables the LDS-staged, XCD-sliced kernel; without it every pair is scored on its own."""
@@ -166,7 +172,7 @@ def score_pairs_fwd(Z, H, pu, pv, t: float, pairs: PairList | None = None, want_
     by_u = pairs.c_struct_by_u() if pairs is not None else None
     # per-factor logit terms for the backward: only the tuned scorer produces them
     coef = None
-    if want_coef and pairs is not None and lib.dl_has_fast_path_dtype(K, d, dt) and not lib.dl_set_force_generic(-1):
+    if want_coef and pairs is not None and score_terms_available(K, d, dt):
         coef = _empty((2, P, K), torch.float32, Z.device)
     _lib.check(lib.dl_score_pairs_fwd(Z.data_ptr(), H.data_ptr(), N, K, d, dt, float(t), pu.data_ptr(), pv.data_ptr(),
                                       P, by_u, prob.data_ptr(), coef.data_ptr() if coef is not None else None,

@@ -21,7 +21,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
-from . import ops
+from . import _lib, ops
 from .graph import Graph, PairList
 
 _graphs: dict[int, Graph] = {}
@@ -150,7 +150,9 @@ def score_pairs_terms(Z: Tensor, H: Tensor, pairs: int, t: float) -> tuple[Tenso
 @score_pairs_terms.register_fake
 def _(Z, H, pairs, t):
     P = _p(pairs).n_pairs
-    return Z.new_empty(P, dtype=torch.float32), Z.new_empty((2, P, Z.shape[1]), dtype=torch.float32)
+    dt = _lib.DL_BF16 if Z.dtype == torch.bfloat16 else _lib.DL_F32   # the same rule as the real operator (ops.score_pairs_fwd)
+    terms = ops.score_terms_available(Z.shape[1], Z.shape[2], dt)
+    return Z.new_empty(P, dtype=torch.float32), Z.new_empty((2, P, Z.shape[1]) if terms else (0,), dtype=torch.float32)
 
 
 @torch.library.custom_op("disenlink::score_pairs_bwd", mutates_args=(), device_types="cuda")
