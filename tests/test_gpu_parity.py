@@ -858,6 +858,48 @@ def test_tuned_and_generic_kernels_agree_on_random_small_problems():
             assert float((x0 - x1).abs().max()) <= 2e-4 * scale if x0.numel() else True, (name, tag)
 
 
+def test_aggregation_under_skewed_routing():
+    """The aggregation kernel owns accumulators per factor CLASS (factor mod 4) and walks max-class-size steps per
+    segment: the worst cases are routings that send every edge to one factor or to two factors of the same class.
+    Hand-made (p, a, s) on a graph with a hub row (multi-unit partial slots), through the tuned and the generic kernels
+    and against an fp64 sum: same H whatever the routing looks like."""
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    for K, d in ((8, 64), (5, 32), (16, 128), (3, 8)):
+        N = 700
+        src = np.concatenate([rng.integers(0, N, 3000), np.zeros(600, dtype=np.int64)])      # node 0: a hub of ~600 entries
+        dst = np.concatenate([rng.integers(0, N, 3000), rng.integers(1, N, 600)])
+        G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+        E = G.n_edges
+        rowptr = G.plan.rowptr.cpu().numpy().astype(np.int64)
+        col = G.plan.col.cpu().numpy().astype(np.int64)
+        row = np.repeat(np.arange(N), np.diff(rowptr))
+        Zh = (rng.standard_normal((N, K, d)) * 0.5).astype(np.float32)
+        ah = rng.uniform(0.1, 1.0, E).astype(np.float32)
+        sh = rng.uniform(0.5, 2.0, (N, K)).astype(np.float32)
+        patterns = {"all_first": np.zeros(E, np.int64), "all_last": np.full(E, K - 1), "one_class": (np.arange(E) % 2) * (4 if K > 4 else 0),
+                    "by_parity": np.arange(E) % K, "random": rng.integers(0, K, E)}
+        Z, a, sv = (torch.from_numpy(v).to(DEV) for v in (Zh, ah, sh))
+        for name, ph in patterns.items():
+            ph = np.minimum(ph, K - 1)
+            pt = torch.from_numpy(ph.astype(np.uint8)).to(DEV)
+            want = 0.4 * Zh.astype(np.float64)
+            w = ah.astype(np.float64) / sh.astype(np.float64)[col, ph]
+            np.add.at(want, (row, ph), 0.6 * w[:, None] * Zh.astype(np.float64)[col, ph])
+            got = {}
+            for force in (0, 1):
+                old = lib.dl_set_force_generic(force)
+                try:
+                    got[force] = ops.aggregate_fwd(G, Z, 0.4, pt, a, sv).cpu().numpy().astype(np.float64)
+                finally:
+                    lib.dl_set_force_generic(old)
+            scale = float(np.abs(want).max())
+            for force in (0, 1):
+                assert np.abs(got[force] - want).max() <= 2e-5 * scale, (K, d, name, force, float(np.abs(got[force] - want).max()))
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops
