@@ -78,6 +78,7 @@ EXPORTS = {
     "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_aggregate_bwd_phase2": (_i, [_G, _P, _i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
     "dl_route_aggregate_bwd": (_i, [_G, _P, _i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _i, _P, _z, _P]),
+    "dl_route_aggregate_bwd_scaled": (_i, [_G, _P, _i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
 }
 
 DL_F32, DL_BF16 = 0, 1

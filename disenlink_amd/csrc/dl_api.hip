@@ -390,10 +390,10 @@ int dl_route_aggregate_bwd_phase1(const dl_graph* g, const void* Z, int K, int d
     return generic_bwd_phase1(c, (const float*)Z, K, d, beta, p, a, s, dH, dw, dwr, ds, (hipStream_t)stream);
 }
 
-int dl_route_aggregate_bwd_phase2(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
-                                  float t, const uint8_t* p, const float* a, const float* s, const float* dH,
-                                  const float* dw, const float* dwr, const float* ds, float* dZ, int accumulate,
-                                  void* ws, size_t ws_bytes, void* stream) {
+static int bwd_phase2_impl(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
+                           const uint8_t* p, const float* a, const float* s, const float* dH, const float* dw,
+                           const float* dwr, const float* ds, const float* dz_in, const float* scale, float* dZ, void* ws,
+                           size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
     const dl_csr_plan* c = &g->csr;
     if (int rc = check_plan(c, "graph")) return rc;
@@ -406,16 +406,24 @@ int dl_route_aggregate_bwd_phase2(const dl_graph* g, const void* Z, int K, int d
     if (use_fast(c, K, d, dtype)) {
         Workspace w;
         if (int rc = check_workspace(c, K, d, ws, ws_bytes, &w)) return rc;
-        return fast_bwd_phase2(c, Z, K, d, dtype, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, w.row_part,
+        return fast_bwd_phase2(c, Z, K, d, dtype, beta, t, p, a, s, dH, dw, dwr, ds, dz_in, scale, dZ, w.row_part,
                                (hipStream_t)stream);
     }
-    return generic_bwd_phase2(c, (const float*)Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate,
+    return generic_bwd_phase2(c, (const float*)Z, K, d, beta, t, p, a, s, dH, dw, dwr, ds, dz_in, scale, dZ,
                               (hipStream_t)stream);
 }
 
-int dl_route_aggregate_bwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
-                           const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
-                           int accumulate, void* ws, size_t ws_bytes, void* stream) {
+int dl_route_aggregate_bwd_phase2(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta,
+                                  float t, const uint8_t* p, const float* a, const float* s, const float* dH,
+                                  const float* dw, const float* dwr, const float* ds, float* dZ, int accumulate,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    return bwd_phase2_impl(g, Z, K, d, dtype, beta, t, p, a, s, dH, dw, dwr, ds, accumulate ? dZ : nullptr, nullptr, dZ,
+                           ws, ws_bytes, stream);
+}
+
+static int bwd_both_impl(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
+                         const uint8_t* p, const float* a, const float* s, const float* dH, const float* dz_in,
+                         const float* scale, float* dZ, void* ws, size_t ws_bytes, void* stream) {
     DL_REQUIRE(g != nullptr, "graph is NULL");
     const dl_csr_plan* c = &g->csr;
     if (int rc = check_plan(c, "graph")) return rc;
@@ -427,8 +435,21 @@ int dl_route_aggregate_bwd(const dl_graph* g, const void* Z, int K, int d, dl_dt
     if (int rc = dl_route_aggregate_bwd_phase1(g, Z, K, d, dtype, beta, p, a, s, dH, w.dw, w.dwr, w.ds, ws, ws_bytes,
                                                stream))
         return rc;
-    return dl_route_aggregate_bwd_phase2(g, Z, K, d, dtype, beta, t, p, a, s, dH, w.dw, w.dwr, w.ds, dZ, accumulate,
-                                         ws, ws_bytes, stream);
+    return bwd_phase2_impl(g, Z, K, d, dtype, beta, t, p, a, s, dH, w.dw, w.dwr, w.ds, dz_in, scale, dZ, ws, ws_bytes,
+                           stream);
+}
+
+int dl_route_aggregate_bwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
+                           const uint8_t* p, const float* a, const float* s, const float* dH, float* dZ,
+                           int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return bwd_both_impl(g, Z, K, d, dtype, beta, t, p, a, s, dH, accumulate ? dZ : nullptr, nullptr, dZ, ws, ws_bytes,
+                         stream);
+}
+
+int dl_route_aggregate_bwd_scaled(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
+                                  const uint8_t* p, const float* a, const float* s, const float* dH, const float* dZ_in,
+                                  const float* scale, float* dZ, void* ws, size_t ws_bytes, void* stream) {
+    return bwd_both_impl(g, Z, K, d, dtype, beta, t, p, a, s, dH, dZ_in, scale, dZ, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

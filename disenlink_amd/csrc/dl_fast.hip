@@ -583,7 +583,10 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
                                                             const TX* __restrict__ X, float cx, float cp,
                                                             TO* __restrict__ out0, int accumulate,
                                                             const float* __restrict__ part1 = nullptr,
-                                                            TO* __restrict__ out1 = nullptr) {
+                                                            TO* __restrict__ out1 = nullptr,
+                                                            const TO* acc_in = nullptr,
+                                                            const float* __restrict__ scale = nullptr) {
+    // acc_in: the accumulated input read from its own array (may be `out0` itself); scale: a device scalar on the result
     // gridDim.y == 2: two independent (partials, output) pairs over the same plan in one launch
     const float* __restrict__ part = blockIdx.y ? part1 : part0;
     TO* __restrict__ out = blockIdx.y ? out1 : out0;
@@ -623,12 +626,16 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
                 t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
             }
             const size_t o = grow * TOT + 4 * x;
-            float4 r = accumulate ? load4<TO>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 r = acc_in ? load4<TO>(acc_in + o) : accumulate ? load4<TO>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (cx != 0.0f) {
                 const float4 xv = load4<TX>(X + o);
                 r.x += cx * xv.x; r.y += cx * xv.y; r.z += cx * xv.z; r.w += cx * xv.w;
             }
             r.x += cp * t.x; r.y += cp * t.y; r.z += cp * t.z; r.w += cp * t.w;
+            if (scale) {
+                const float g = scale[0];
+                r.x *= g; r.y *= g; r.z *= g; r.w *= g;
+            }
             store4(out + o, r);
         }
     }
@@ -702,7 +709,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     dl_csr_plan g, const T* __restrict__ Z, const float* __restrict__ dH, float beta, float t,
     const uint8_t* __restrict__ p, const float* __restrict__ a, const float* __restrict__ s,
     const float* __restrict__ dw, const float* __restrict__ dwr, const float* __restrict__ ds,
-    float* __restrict__ dZ, int accumulate, float* __restrict__ dz_part) {
+    const float* dz_in, const float* __restrict__ scale, float* dZ, float* __restrict__ dz_part) {
+    // dZ = scale[0] * (dz_in + ...): dz_in may be NULL (0) or dZ itself (accumulate in place), scale may be NULL (1)
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
@@ -776,9 +784,13 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
             if (si.slot < 0) {
                 const size_t o = (size_t)si.grow * ROW + 4 * x;
                 const float4 dh = load4<float>(dH + o);
-                float4 o4 = accumulate ? load4<float>(dZ + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 o4 = dz_in ? load4<float>(dz_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                 o4.x += beta * dh.x + r[q].x; o4.y += beta * dh.y + r[q].y;
                 o4.z += beta * dh.z + r[q].z; o4.w += beta * dh.w + r[q].w;
+                if (scale) {
+                    const float gs = scale[0];
+                    o4.x *= gs; o4.y *= gs; o4.z *= gs; o4.w *= gs;
+                }
                 store4(dZ + o, o4);
             } else {
                 store4(dz_part + (size_t)si.slot * ROW + 4 * x, r[q]);
@@ -1228,12 +1240,12 @@ struct Ops {
 
     static int bwd_phase2(const dl_csr_plan* g, const void* Z, float beta, float t, const uint8_t* p, const float* a,
                           const float* s, const float* dH, const float* dw, const float* dwr, const float* ds,
-                          float* dZ, int accumulate, float* dz_part, hipStream_t st) {
+                          const float* dz_in, const float* scale, float* dZ, float* dz_part, hipStream_t st) {
         hipLaunchKernelGGL((bwd_phase2_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                           dH, beta, t, p, a, s, dw, dwr, ds, dZ, accumulate, dz_part);
+                           dH, beta, t, p, a, s, dw, dwr, ds, dz_in, scale, dZ, dz_part);
         if (g->n_multi > 0)
             hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
-                               dz_part, ROW, dH, beta, 1.0f, dZ, accumulate);
+                               dz_part, ROW, dH, beta, 1.0f, dZ, 0, (const float*)nullptr, (float*)nullptr, dz_in, scale);
         return check_launch("route_aggregate_bwd_phase2(fast)");
     }
 
@@ -1366,9 +1378,10 @@ int fast_bwd_phase1(const dl_csr_plan* g, const void* Z, int K, int d, int dtype
 
 int fast_bwd_phase2(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, float t,
                     const uint8_t* p, const float* a, const float* s, const float* dH, const float* dw,
-                    const float* dwr, const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st) {
-#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, dz_part, st);
-#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZ, accumulate, dz_part, st);
+                    const float* dwr, const float* ds, const float* dz_in, const float* scale, float* dZ, float* dz_part,
+                    hipStream_t st) {
+#define X_F32(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, float>::bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dz_in, scale, dZ, dz_part, st);
+#define X_BF16(KK, DD) if (K == KK && d == DD) return fast::Ops<KK, DD, fast::bf16_t>::bwd_phase2(g, Z, beta, t, p, a, s, dH, dw, dwr, ds, dz_in, scale, dZ, dz_part, st);
     DL_DISPATCH(X)
 #undef X_F32
 #undef X_BF16

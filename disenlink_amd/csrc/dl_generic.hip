@@ -202,8 +202,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_kernel(dl_csr_plan c, const 
                                                            const float* __restrict__ s,
                                                            const float* __restrict__ dw,
                                                            const float* __restrict__ dwr,
-                                                           const float* __restrict__ ds, float* __restrict__ dZ,
-                                                           int accumulate) {
+                                                           const float* __restrict__ ds, const float* dz_in,
+                                                           const float* __restrict__ scale, float* dZ) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6;
     const int row = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -239,7 +239,11 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_kernel(dl_csr_plan c, const 
         }
     }
     float* out = dZ + grow * KD;
-    for (int x = lane; x < KD; x += DL_WAVE) out[x] = (accumulate ? out[x] : 0.0f) + acc[x];
+    const float gs = scale ? scale[0] : 1.0f;
+    for (int x = lane; x < KD; x += DL_WAVE) {
+        const float v = (dz_in ? dz_in[grow * KD + x] : 0.0f) + acc[x];
+        out[x] = scale ? v * gs : v;
+    }
 }
 
 }  // namespace generic
@@ -331,11 +335,11 @@ int generic_bwd_phase1(const dl_csr_plan* c, const float* Z, int K, int d, float
 
 int generic_bwd_phase2(const dl_csr_plan* c, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
                        const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
-                       const float* ds, float* dZ, int accumulate, hipStream_t st) {
+                       const float* ds, const float* dz_in, const float* scale, float* dZ, hipStream_t st) {
     if (int rc = check_lds(K, d, 1)) return rc;
     size_t lds = (size_t)WAVES_PER_BLOCK * K * d * sizeof(float);
     hipLaunchKernelGGL(bwd_phase2_kernel, dim3(wave_blocks(c->n_rows)), dim3(BLOCK), lds, st, *c, Z, dH, K, d, beta, t,
-                       p, a, s, dw, dwr, ds, dZ, accumulate);
+                       p, a, s, dw, dwr, ds, dz_in, scale, dZ);
     return check_launch("route_aggregate_bwd_phase2(generic)");
 }
 

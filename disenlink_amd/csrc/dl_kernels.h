@@ -19,7 +19,7 @@ int generic_bwd_phase1(const dl_csr_plan* c, const float* Z, int K, int d, float
                        hipStream_t st);
 int generic_bwd_phase2(const dl_csr_plan* c, const float* Z, int K, int d, float beta, float t, const uint8_t* p,
                        const float* a, const float* s, const float* dH, const float* dw, const float* dwr,
-                       const float* ds, float* dZ, int accumulate, hipStream_t st);
+                       const float* ds, const float* dz_in, const float* scale, float* dZ, hipStream_t st);
 
 // tuned, per-(K, D, table type) instantiations (dl_fast.hip)
 bool fast_supported(int K, int d, int dtype);
@@ -32,7 +32,7 @@ int fast_bwd_phase1(const dl_csr_plan* g, const void* Z, int K, int d, int dtype
                     float* ds_part, hipStream_t st);
 int fast_bwd_phase2(const dl_csr_plan* g, const void* Z, int K, int d, int dtype, float beta, float t,
                     const uint8_t* p, const float* a, const float* s, const float* dH, const float* dw,
-                    const float* dwr, const float* ds, float* dZ, int accumulate, float* dz_part, hipStream_t st);
+                    const float* dwr, const float* ds, const float* dz_in, const float* scale, float* dZ, float* dz_part, hipStream_t st);
 int fast_score_pairs_fwd(const dl_pair_incidence* by_u, const void* Z, const void* H, int K, int d, int dtype,
                          float t, float* prob, float* coef, hipStream_t st);
 int fast_score_pairs_train(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype, float t,

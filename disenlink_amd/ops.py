@@ -292,6 +292,26 @@ def route_aggregate_bwd_phase2(g: Graph, Z, beta: float, t: float, p, a, s, dH, 
     return dZ_out
 
 
+def route_aggregate_bwd_scaled(g: Graph, Z, beta: float, t: float, p, a, s, dH, dZ_in, scale) -> torch.Tensor:
+    """-> dZ = scale * (dZ_in + backward(dH)), a NEW tensor: dH and dZ_in are only read (they may be an autograd node's
+    saved tensors), scale is a 0-dim / 1-element fp32 tensor on the device (an upstream d/dloss).  dl_route_aggregate_bwd_scaled:
+    the backward is linear in (dH, dZ_in), so a caller holding UNSCALED gradients needs no scaling passes."""
+    lib = _lib.load()
+    (Z, dt), dH, dZ_in = _tab(Z), _f32c(dH), _f32c(dZ_in)
+    scale = scale.to(device=Z.device, dtype=torch.float32).reshape(1)
+    _need_cuda(Z, dH, dZ_in, g.rowptr, p, a, s)
+    N, K, d = _check_rows(g, Z)
+    if dZ_in.shape != Z.shape or dH.shape != Z.shape:
+        raise ValueError("dH and dZ_in must be [N,K,d] like Z")
+    dZ = _empty(Z.shape, torch.float32, Z.device)
+    ws = _workspace(g.c_plan(), Z.device, K, d)
+    _lib.check(lib.dl_route_aggregate_bwd_scaled(g.c_struct(), Z.data_ptr(), K, d, dt, float(beta), float(t), p.data_ptr(),
+                                                 a.data_ptr(), s.data_ptr(), dH.data_ptr(), dZ_in.data_ptr(),
+                                                 scale.data_ptr(), dZ.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "dl_route_aggregate_bwd_scaled")
+    return dZ
+
+
 class _PaddedFeatures:
     """Zero-padded copies of feature matrices whose row length is not a multiple of 4, one per source TENSOR and version
     counter.  Entries are keyed by the tensor OBJECT (its id, checked against a weak reference: an address — or an id —
@@ -649,6 +669,11 @@ class HotPathPairsLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_emb, g_prob, g_loss):
         Zt, H, a, s, prob, dZs, dHs = ctx.saved_tensors
+        if g_loss is not None and g_prob is None and g_emb is None and g_loss.numel() == 1:
+            # the usual case (loss.backward()): everything downstream is linear in the scorer's gradients, so d/dloss
+            # scales the RESULT inside the last kernel — no scaling passes over the two [N,K,d] arrays, which stay unwritten
+            return (route_aggregate_bwd_scaled(ctx.graph, Zt, ctx.beta, ctx.t, ctx.p, a, s, dHs, dZs, g_loss),
+                    None, None, None, None, None, None, None)
         if g_loss is not None:
             dZ, dH = dZs * g_loss, dHs * g_loss
         else:

@@ -334,6 +334,16 @@ int dl_route_aggregate_bwd(const dl_graph* g, const void* Z, int K, int d, dl_dt
                            const float* dH, float* dZ, int accumulate,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* dZ = scale[0] * (dZ_in + the backward above applied to dH): dl_route_aggregate_bwd with the accumulated input read
+ * from its own array (dZ_in: NULL = 0, may be dZ itself) and the result multiplied by a DEVICE scalar (scale: NULL = 1).
+ * For a caller whose incoming gradients are g * dH and g * dZ_in with g = d(total)/d(loss) known only on the device
+ * (autograd of main_disentangled.py:198 through a fused loss): the backward is linear, so the two scaling passes over
+ * [N,K,d] arrays and their copies disappear.  scale[0] == 1 gives the bits of dl_route_aggregate_bwd. */
+int dl_route_aggregate_bwd_scaled(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float beta, float t,
+                                  const uint8_t* p, const float* a, const float* s,
+                                  const float* dH, const float* dZ_in, const float* scale, float* dZ,
+                                  void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

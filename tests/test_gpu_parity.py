@@ -900,6 +900,54 @@ def test_aggregation_under_skewed_routing():
                 assert np.abs(got[force] - want).max() <= 2e-5 * scale, (K, d, name, force, float(np.abs(got[force] - want).max()))
 
 
+def test_scaled_backward_is_the_backward_times_a_device_scalar():
+    """dl_route_aggregate_bwd_scaled: dZ = scale * (dZ_in + backward(dH)) with the inputs only read.  scale == 1 gives the
+    bits of the accumulating entry point; any other scale agrees to rounding; tuned and generic kernels; a graph with hub
+    rows (partial slots + combine).  And through autograd: (c * loss).backward() of the one-pass loss node equals c times
+    the gradients of loss.backward()."""
+    from disenlink_amd import _lib, ops
+    from disenlink_amd.graph import Graph, PairList
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for K, d in ((8, 64), (5, 32), (3, 8)):
+        N = 500
+        src = np.concatenate([rng.integers(0, N, 2500), np.zeros(400, dtype=np.int64)])
+        dst = np.concatenate([rng.integers(0, N, 2500), rng.integers(1, N, 400)])
+        G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+        Z = torch.from_numpy((rng.standard_normal((N, K, d)) * 0.3).astype(np.float32)).to(DEV)
+        dH = torch.from_numpy(rng.standard_normal((N, K, d)).astype(np.float32)).to(DEV)
+        dZ_in = torch.from_numpy(rng.standard_normal((N, K, d)).astype(np.float32)).to(DEV)
+        for force in (0, 1):
+            old = lib.dl_set_force_generic(force)
+            try:
+                p, a, sv = ops.route_fwd(G, Z, 1.0)
+                want = ops.route_aggregate_bwd(G, Z, 0.6, 1.0, p, a, sv, dH, dZ_accum=dZ_in.clone())
+                keep_dH, keep_in = dH.clone(), dZ_in.clone()
+                one = ops.route_aggregate_bwd_scaled(G, Z, 0.6, 1.0, p, a, sv, dH, dZ_in, torch.ones((), device=DEV))
+                assert torch.equal(one, want), (K, d, force)
+                assert torch.equal(dH, keep_dH) and torch.equal(dZ_in, keep_in)            # inputs are only read
+                c = torch.tensor(0.37, device=DEV)
+                got = ops.route_aggregate_bwd_scaled(G, Z, 0.6, 1.0, p, a, sv, dH, dZ_in, c)
+                assert torch.allclose(got, want * 0.37, rtol=1e-6, atol=1e-7 * float(want.abs().max())), (K, d, force)
+            finally:
+                lib.dl_set_force_generic(old)
+    # autograd: a scaled loss
+    N, K, d = 400, 8, 64
+    src, dst = rng.integers(0, N, 3000), rng.integers(0, N, 3000)
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+    pairs = PairList.build(torch.from_numpy(rng.integers(0, N, 5000)).to(DEV), torch.from_numpy(rng.integers(0, N, 5000)).to(DEV), N)
+    label = torch.from_numpy((rng.random(5000) < 0.3).astype(np.float32)).to(DEV)
+    weight = torch.from_numpy(rng.uniform(0.1, 1.0, 5000).astype(np.float32)).to(DEV)
+    grads = {}
+    for c in (1.0, 2.5):
+        Z = torch.from_numpy((np.random.default_rng(9).standard_normal((N, K, d)) * 0.3).astype(np.float32)).to(DEV).requires_grad_()
+        _emb, _prob, loss = ops.HotPathPairsLoss.apply(Z, G, pairs, 0.5, 1.0, torch.float32, label, weight)
+        (loss * c).backward()
+        grads[c] = Z.grad.clone()
+    assert torch.isfinite(grads[1.0]).all() and float(grads[1.0].abs().max()) > 0
+    assert torch.allclose(grads[2.5], grads[1.0] * 2.5, rtol=1e-5, atol=1e-7 * float(grads[1.0].abs().max()))
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops
