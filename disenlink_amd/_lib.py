@@ -48,7 +48,8 @@ EXPORTS = {
     # name: (restype, argtypes) -- one entry per symbol declared in include/disenlink_hip.h
     "dl_host_csr_from_edges": (_i, [_P, _P, C.c_int64, C.c_int32, _i, C.POINTER(DlHostCsr)]),
     "dl_host_csr_free": (None, [C.POINTER(DlHostCsr)]),
-    "dl_host_plan_build": (_i, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(DlHostPlan)]),
+    "dl_host_plan_build": (_i, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32,
+                                C.POINTER(DlHostPlan)]),
     "dl_host_plan_free": (None, [C.POINTER(DlHostPlan)]),
     "dl_version": (C.c_char_p, []),
     "dl_last_error": (C.c_char_p, []),

@@ -72,7 +72,7 @@ void dl_host_csr_free(dl_host_csr* c) {
 }
 
 int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, const int32_t* col, int32_t seg_len,
-                       int32_t n_col_slices, const uint8_t* keep, int32_t unit_segs, dl_host_plan* out) {
+                       int32_t n_col_slices, const uint8_t* keep, int32_t unit_segs, int32_t by_length, dl_host_plan* out) {
     DL_REQUIRE(out != nullptr, "out is NULL");
     memset(out, 0, sizeof(*out));
     DL_REQUIRE(n_rows >= 0 && n_total >= n_rows && seg_len >= 1 && n_col_slices >= 1, "bad plan size");
@@ -98,7 +98,7 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
     // segments in entry order; a unit = up to DL_UNIT_SEGS consecutive segments of one (row, slice) group, counted
     // from the group's first segment (graph.CsrPlan.build does the same with torch index ops)
     struct Seg { int32_t row, beg, end, unit; };
-    struct Unit { int32_t row, slice, first_seg, size, pad, slot; int64_t pos; };
+    struct Unit { int32_t row, slice, first_seg, size, pad, slot; int64_t pos; int32_t entries; };
     std::vector<Seg> segs;
     std::vector<Unit> units;
     std::vector<int32_t> nunit_row((size_t)n_rows, 0);
@@ -106,11 +106,12 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
         int32_t g = 0;
         for (int32_t sb = b; sb < e || (empty_row && g == 0); sb += seg_len, ++g) {
             if (g % unit_segs == 0) {
-                units.push_back({row, q, (int32_t)segs.size(), 0, 0, -1, 0});
+                units.push_back({row, q, (int32_t)segs.size(), 0, 0, -1, 0, 0});
                 nunit_row[row]++;
             }
             segs.push_back({row, sb, std::min(sb + seg_len, e), (int32_t)units.size() - 1});
             units.back().size++;
+            units.back().entries += std::min(sb + seg_len, e) - sb;
             if (empty_row) break;
         }
     };
@@ -154,7 +155,9 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
         seen[u.row]++;
     }
     // storage order: one stream per XCD (slice q -> stream q % 8), slices of a stream in time order; inside a slice
-    // the units by padded size, largest first (stable), so none straddles a group of DL_UNIT_SEGS positions
+    // the units by padded size, largest first (stable), so none straddles a group of DL_UNIT_SEGS positions; by_length:
+    // inside a size class the units with the most entries first (a workgroup's wavefronts finish together; for graphs
+    // whose tables are cache-resident: graph.length_order)
     std::vector<int32_t> uorder(units.size());
     for (size_t x = 0; x < units.size(); ++x) uorder[x] = (int32_t)x;
     std::stable_sort(uorder.begin(), uorder.end(), [&](int32_t a, int32_t b) {
@@ -162,7 +165,8 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
         const int32_t sa = ua.slice % n_streams, sb = ub.slice % n_streams;
         if (sa != sb) return sa < sb;
         if (ua.slice != ub.slice) return ua.slice < ub.slice;
-        return ua.pad > ub.pad;
+        if (ua.pad != ub.pad) return ua.pad > ub.pad;
+        return by_length != 0 && ua.entries > ub.entries;
     });
     std::vector<int64_t> sl_size((size_t)n_col_slices, 0), sl_base((size_t)n_col_slices, 0), sl_fill((size_t)n_col_slices, 0);
     for (const Unit& u : units) sl_size[u.slice] += u.pad;

@@ -30,6 +30,24 @@ UNIT_SEGS = 4               # wavefronts per workgroup = segment positions per w
 L2_BYTES_PER_XCD = 4 << 20
 
 
+CACHE_BYTES = 256 << 20     # Infinity Cache of an MI355X
+
+
+def length_order(n_nodes: int, row_bytes: int, n_tables: int = 2) -> bool:
+    """Whether a plan over these tables should place its units by LENGTH (longest first) inside a slice instead of
+    in entry order.  A workgroup's four wavefronts end together (its LDS and its barrier), so four segments of 3, 60, 7
+    and 31 entries leave most of the group idle; side by side by length they finish together, and longest-first is the
+    better schedule for the tail.  The price is that consecutive workgroups no longer walk consecutive rows: where the
+    row streams come from HBM that costs more than it gains (snap-patents-shaped, 3 GB: route / aggregate +11 %), where
+    the gathered tables (Z and H: n_tables * n_nodes * row_bytes) fit the Infinity Cache it is free — real squirrel
+    step 220 -> 208 us, chameleon 72 -> 62; squirrel-shaped graphs up to 170 MB of tables -5 %, 340 MB and up: even.
+    Results do not depend on it (a unit's segments and its slot stay what they are).  DL_PLAN_SORT=0/1 forces it."""
+    forced = os.environ.get("DL_PLAN_SORT")
+    if forced is not None and forced != "":
+        return forced != "0"
+    return float(n_nodes) * row_bytes * n_tables <= CACHE_BYTES
+
+
 def auto_slices(n_nodes: int, row_bytes: int, entries_per_row: float = 1e9, n_tables: int = 2) -> int:
     """Number of column slices of an XCD-aware plan (a multiple of 8: slice q belongs to XCD stream q % 8,
     the slices of a stream follow each other in time).  Aim: one slice of the gathered tables (Z and H rows
@@ -118,7 +136,7 @@ class CsrPlan:
     @staticmethod
     def build(rowptr: torch.Tensor, col: torch.Tensor, n_total: int, row_offset: int = 0,
               seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1, keep: torch.Tensor | None = None,
-              unit_segs: int = UNIT_SEGS) -> "CsrPlan":
+              unit_segs: int = UNIT_SEGS, by_length: bool = False) -> "CsrPlan":
         """``keep`` (bool per entry, optional): segments cover only the kept entries, which must form one
         contiguous run inside every row (e.g. the upper triangle ``col >= row`` of a sorted row).
         ``unit_segs = 1``: every segment is its own unit — for plans whose kernels reduce nothing across segments
@@ -205,11 +223,17 @@ class CsrPlan:
         u_slot = torch.where(row_slot0[u_row] >= 0, row_slot0[u_row] + u_idx_in_row, row_slot0[u_row])
         # storage: one STREAM of positions per XCD.  Column slice q belongs to stream q % 8 and the slices of a stream
         # follow each other in time (q // 8), so an XCD works on one slice at a time.  Inside a slice the units are placed
-        # by padded size, largest first (stable: entry order among equals), so no unit straddles a group of UNIT_SEGS
-        # positions; every slice region is padded to a multiple of UNIT_SEGS.  Pad positions have seg_row = -1.
+        # by padded size, largest first (stable: entry order among equals — or, with by_length, most entries first: see
+        # length_order), so no unit straddles a group of UNIT_SEGS positions; every slice region is padded to a multiple
+        # of UNIT_SEGS.  Pad positions have seg_row = -1.
         n_streams = min(n_slices, DEFAULT_SLICES)
         u_stream = u_slice % n_streams
-        uperm = torch.argsort((u_stream * (n_slices + 1) + u_slice) * 8 + (UNIT_SEGS - u_pad), stable=True)
+        key = (u_stream * (n_slices + 1) + u_slice) * 8 + (UNIT_SEGS - u_pad)
+        if by_length and n_units:                                  # ... and by entries inside a size class, longest first
+            u_entries = torch.zeros(n_units, dtype=torch.int64, device=dev).index_add_(0, u_of, seg_end - seg_beg)
+            span = int(seg_len) * UNIT_SEGS
+            key = key * (span + 1) + (span - u_entries)
+        uperm = torch.argsort(key, stable=True)
         sl_size = torch.zeros(n_slices, dtype=torch.int64, device=dev).index_add_(0, u_slice, u_pad)
         sl_size = (sl_size + UNIT_SEGS - 1) // UNIT_SEGS * UNIT_SEGS
         sl_order = torch.argsort((ar(n_slices) % n_streams) * (n_slices + 1) + ar(n_slices), stable=True)   # (stream, slice)
@@ -312,7 +336,8 @@ class Graph:
         full_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=key.device)
         full_ptr[1:] = torch.cumsum(counts, dim=0)
         e0, e1 = int(full_ptr[lo]), int(full_ptr[hi])
-        plan = CsrPlan.build(full_ptr[lo:hi + 1] - e0, c[e0:e1], n_nodes, row_offset=lo, seg_len=seg_len)
+        by_len = length_order(n_nodes, row_bytes)
+        plan = CsrPlan.build(full_ptr[lo:hi + 1] - e0, c[e0:e1], n_nodes, row_offset=lo, seg_len=seg_len, by_length=by_len)
         mirror = row_range is None
         lc, lr = c[e0:e1], r[e0:e1] - lo
         # XCD slicing of the routing plan was measured and rejected: hub rows already give the Z gathers a high
@@ -320,7 +345,7 @@ class Graph:
         # 115 -> 107 us).  `row_bytes` is kept for callers that pass the model shape.
         route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo,
                               seg_len=min(seg_len, DEFAULT_ROUTE_SEG_LEN or seg_len), n_slices=1,
-                              keep=(lc >= lr + lo) if mirror else None, unit_segs=1)
+                              keep=(lc >= lr + lo) if mirror else None, unit_segs=1, by_length=by_len)
         route.rowptr, route.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
         return Graph(plan, _i32(rev) if mirror else None, route, mirror)
 
@@ -410,7 +435,7 @@ class PairList:
             if node.numel():
                 rowptr[1:] = torch.cumsum(torch.bincount(node - lo, minlength=hi - lo), dim=0)
             plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=slices,
-                                 unit_segs=unit_segs)
+                                 unit_segs=unit_segs, by_length=length_order(n_nodes, row_bytes))
             return plan, _i32(pair[order])
 
         ulo, uhi = (0, n_nodes) if by_u_range is None else by_u_range

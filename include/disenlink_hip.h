@@ -141,9 +141,14 @@ void dl_host_csr_free(dl_host_csr* csr);
  * n_col_slices column slices (1 = unsliced; a multiple of 8 = XCD streams x time), optionally only over
  * the entries with keep[e] != 0 (one contiguous run per row, e.g. col >= row for symmetric routing).
  * unit_segs = DL_UNIT_SEGS groups the segments of a row into units (plans whose kernels sum over a row);
- * unit_segs = 1 makes every segment its own unit, positions in entry order (routing plan, forward scorer). */
+ * unit_segs = 1 makes every segment its own unit, positions in entry order (routing plan, forward scorer).
+ * by_length != 0 places the units of one size class by their number of entries, most first, instead of in entry order:
+ * the wavefronts of a workgroup then finish together.  Use it when the gathered tables (2 * n_total * K * d * element
+ * size) fit the 256 MiB Infinity Cache; where the row streams come from HBM, entry order is faster.  Results do not
+ * depend on it. */
 int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, const int32_t* col, int32_t seg_len,
-                       int32_t n_col_slices, const uint8_t* keep, int32_t unit_segs, dl_host_plan* out);
+                       int32_t n_col_slices, const uint8_t* keep, int32_t unit_segs, int32_t by_length,
+                       dl_host_plan* out);
 void dl_host_plan_free(dl_host_plan* plan);
 
 const char* dl_version(void);

@@ -289,14 +289,19 @@ def test_c_abi_host_graph_prep_matches_python_builders(seed):
         assert np.array_equal(rowptr, G.rowptr.numpy()) and np.array_equal(col, G.col.numpy())
         assert np.array_equal(_host_arr(hc.rev, hc.n_entries), G.rev.numpy())
         row_of = np.repeat(np.arange(n), np.diff(rowptr))
-        cases = [(8, 1, None, 4, G.plan), (8, 8, None, 4, CsrPlan.build(G.rowptr, G.col, n, seg_len=8, n_slices=8)),
-                 (5, 24, None, 4, CsrPlan.build(G.rowptr, G.col, n, seg_len=5, n_slices=24)),
-                 (3, 8, None, 1, CsrPlan.build(G.rowptr, G.col, n, seg_len=3, n_slices=8, unit_segs=1)),
-                 (8, 1, (col >= row_of).astype(np.uint8), 1, G.route)]
-        for seg_len, slices, keep, unit_segs, ref in cases:
+        # (a graph this small has cache-resident tables: Graph.from_edge_rows orders its plans by length)
+        cases = [(8, 1, None, 4, 1, G.plan), (8, 8, None, 4, 0, CsrPlan.build(G.rowptr, G.col, n, seg_len=8, n_slices=8)),
+                 (8, 1, None, 4, 0, CsrPlan.build(G.rowptr, G.col, n, seg_len=8)),
+                 (5, 24, None, 4, 0, CsrPlan.build(G.rowptr, G.col, n, seg_len=5, n_slices=24)),
+                 (5, 24, None, 4, 1, CsrPlan.build(G.rowptr, G.col, n, seg_len=5, n_slices=24, by_length=True)),
+                 (3, 8, None, 1, 0, CsrPlan.build(G.rowptr, G.col, n, seg_len=3, n_slices=8, unit_segs=1)),
+                 (3, 8, None, 1, 1, CsrPlan.build(G.rowptr, G.col, n, seg_len=3, n_slices=8, unit_segs=1, by_length=True)),
+                 (8, 1, (col >= row_of).astype(np.uint8), 1, 1, G.route)]
+        for seg_len, slices, keep, unit_segs, by_length, ref in cases:
             hp = _lib.DlHostPlan()
             kp = keep.ctypes.data if keep is not None else None
-            rc = lib.dl_host_plan_build(n, n, rowptr.ctypes.data, col.ctypes.data, seg_len, slices, kp, unit_segs, C.byref(hp))
+            rc = lib.dl_host_plan_build(n, n, rowptr.ctypes.data, col.ctypes.data, seg_len, slices, kp, unit_segs, by_length,
+                                        C.byref(hp))
             assert rc == 0, lib.dl_last_error()
             try:
                 got = (hp.n_seg, hp.n_slices, hp.slice_max_seg, hp.n_multi, hp.n_slots)

@@ -48,7 +48,7 @@ def test_graph_and_plans_on_random_edge_rows(rows, seg_len, n_slices):
         hp = _lib.DlHostPlan()
         rp32, c32 = rowptr.astype(np.int32), col.astype(np.int32)
         assert lib.dl_host_plan_build(n, n, rp32.ctypes.data, c32.ctypes.data if col.size else None, seg_len, n_slices,
-                                      None, 4, C.byref(hp)) == 0, lib.dl_last_error()
+                                      None, 4, 0, C.byref(hp)) == 0, lib.dl_last_error()
         try:
             for name, cnt in (("seg_row", hp.n_seg), ("seg_beg", hp.n_seg), ("seg_end", hp.n_seg), ("seg_slot", hp.n_seg)):
                 assert np.array_equal(_host_arr(getattr(hp, name), cnt), getattr(sliced, name).numpy()), name
