@@ -68,12 +68,20 @@ class StackedAdam:
             raise RuntimeError("StackedAdam.step(): a parameter has no gradient")
         buf = self.model._stacked[key]
         if g0.is_contiguous() and g0.dtype == buf.dtype and g0.shape == buf.shape[1:]:
-            p0, step, st0 = g0.data_ptr(), g0.numel() * g0.element_size(), g0.untyped_storage().data_ptr()
-            if all(p.grad is not None and p.grad.shape == g0.shape and p.grad.dtype == g0.dtype and p.grad.is_contiguous()
-                   and p.grad.data_ptr() == p0 + i * step and p.grad.untyped_storage().data_ptr() == st0
-                   for i, p in enumerate(ps)) and \
-                    g0.untyped_storage().nbytes() >= (p0 - st0) + len(ps) * step:
-                return g0.as_strided(tuple(buf.shape), tuple(buf.stride()))     # the K gradients ARE one stacked tensor
+            # (autograd hands every parameter a gradient of its own shape and dtype, and the K parameters of a group are
+            # alike: what is left to check per gradient is its address and that it is dense; this runs every step)
+            p0, step, gl = g0.data_ptr(), g0.numel() * g0.element_size(), ps[-1].grad
+            st0 = g0.untyped_storage()
+            if gl is not None and gl.untyped_storage().data_ptr() == st0.data_ptr() and \
+                    st0.nbytes() >= (p0 - st0.data_ptr()) + len(ps) * step:
+                i = 0
+                for p in ps:
+                    g = p.grad
+                    if g is None or g.data_ptr() != p0 + i * step or not g.is_contiguous():
+                        break
+                    i += 1
+                else:
+                    return g0.as_strided(tuple(buf.shape), tuple(buf.stride()))     # the K gradients ARE one stacked tensor
         return torch.stack([p.grad for p in ps])
 
     @torch.no_grad()
