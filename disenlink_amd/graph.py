@@ -22,7 +22,16 @@ from . import _lib
 DEFAULT_SEG_LEN = int(os.environ.get("DL_SEG_LEN", "32"))        # adjacency rows (DL_SEG_LEN: experiments only)
 # routing plan (no per-row reduction, hence no partials: shorter segments only add waves in flight — squirrel route
 # phase 46.6 -> 42.9 us, real chameleon 33.4 -> 25.2, Penn94-sized unchanged); 0 = the adjacency plan's
-DEFAULT_ROUTE_SEG_LEN = int(os.environ.get("DL_ROUTE_SEG_LEN", "16"))
+DEFAULT_ROUTE_SEG_LEN = int(os.environ.get("DL_ROUTE_SEG_LEN", "0"))      # 0 = route_seg_len() decides (16, or 8 on small graphs)
+
+
+def route_seg_len(n_entries: int) -> int:
+    """Entries per wavefront of the routing plan (its kernel sums nothing across a row, so this is a pure grain choice;
+    the per-entry results do not depend on it).  16 on graphs that fill the chip; 8 where 16 would leave fewer segments
+    than the 4,096 wavefront slots of the 256 CUs (chameleon: routing phase 15.5 -> 13.6 us, Cora 14.3 -> 11.5)."""
+    if DEFAULT_ROUTE_SEG_LEN:
+        return DEFAULT_ROUTE_SEG_LEN
+    return 16 if n_entries >= 16 * 4096 else 8
 DEFAULT_INC_SEG_LEN = 64    # pair-incidence rows (backward of the scorer)
 DEFAULT_RUN_LEN = 64        # pairs-by-first-endpoint rows (forward scorer)
 DEFAULT_SLICES = 8          # XCDs of an MI355X
@@ -344,7 +353,7 @@ class Graph:
         # L2 hit rate, and the extra segments cost more than they save (squirrel 50 -> 72 us; 41.6k-node shard
         # 115 -> 107 us).  `row_bytes` is kept for callers that pass the model shape.
         route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo,
-                              seg_len=min(seg_len, DEFAULT_ROUTE_SEG_LEN or seg_len), n_slices=1,
+                              seg_len=min(seg_len, route_seg_len((e1 - e0 + 1) // 2 if mirror else e1 - e0)), n_slices=1,
                               keep=(lc >= lr + lo) if mirror else None, unit_segs=1, by_length=by_len)
         route.rowptr, route.col = plan.rowptr, plan.col        # the SAME arrays: only the segments differ
         return Graph(plan, _i32(rev) if mirror else None, route, mirror)
