@@ -191,7 +191,7 @@ __device__ __forceinline__ void stage_row(float* dst, const Chunk<VEC> (&acc)[K]
     for (int kk = 0; kk < K; ++kk) store_f32<VEC>(dst + kk * D + c * VEC, acc[kk]);
 }
 
-template <int K, int D, typename T, int NROWS>
+template <int K, int D, typename T, int NROWS, bool NO_GROUP_ROWS = false>
 struct Stage {
     using GE = Geo<K, D, T>;
     static constexpr int VEC = GE::VEC, G = GE::G;
@@ -200,7 +200,7 @@ struct Stage {
     // Measured (profiles/r2p vs r2m): the two-row scorer backward gains 5 % from staging the groups (64 cross-lane sums
     // fewer per wave); the one-row kernels do not — their waves are short, and on low-degree graphs (snap-patents-shaped:
     // ~8 entries per row) writing four group rows per wave instead of one made the aggregate kernel 29 % slower.
-    static constexpr bool GROUPS_IN_LDS = NROWS == 2 && (size_t)WAVES_PER_BLOCK * NG * ROWF * sizeof(float) <= 64 * 1024;
+    static constexpr bool GROUPS_IN_LDS = !NO_GROUP_ROWS && NROWS == 2 && (size_t)WAVES_PER_BLOCK * NG * ROWF * sizeof(float) <= 64 * 1024;
     static constexpr int SG = GROUPS_IN_LDS ? NG : 1;              // group rows staged per wave
     static constexpr int FLOATS = WAVES_PER_BLOCK * SG * ROWF;     // LDS floats of the workgroup
     static constexpr int F4 = ROWF / 4;
@@ -939,8 +939,17 @@ __global__ __launch_bounds__(BLOCK) void score_allpairs_kernel(const T* __restri
 // (g = w (p - y) / max(p (1 - p), 1e-12) as in dl_pair_bce, folded with the sigmoid backward) and writes prob[q] (both directions of a pair
 // compute the same bits and both write them).  prob_in / g_prob are then unused, y / w / prob_out are used instead:
 // one pass that gathers the partner rows once per direction, instead of a forward pass plus two backward passes.
+// The one-pass training kernel at K = 8, d = 64 runs THREE waves per SIMD: 165 registers without a spill once the groups' partial
+// rows are added in registers (one staged row per wave: 16 KB of LDS per workgroup instead of 64, so LDS does not cap the
+// occupancy at two either) — squirrel 478 -> 457 us, chameleon 99 -> 96; four waves (128 registers) spill 46 and take 3x;
+// d = 32 / 8 would spill a few registers at three waves and stay at two.
+#ifndef DL_TRAIN_WAVES
+#define DL_TRAIN_WAVES 3              // -DDL_TRAIN_WAVES=1 (DL_CXXFLAGS): the two-wave form with the groups' rows in LDS, for A/B runs
+#endif
+template <int K_, int D_, bool FUSED_>
+struct TrainWaves { static constexpr int value = (FUSED_ && K_ == 8 && D_ == 64) ? DL_TRAIN_WAVES : 1; };
 template <int K, int D, typename T, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
+__global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score_bwd_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ inc_pair,
                                                               const T* __restrict__ Z, const T* __restrict__ H,
                                                               float t, const float* __restrict__ prob,
                                                               const float* __restrict__ g_prob,
@@ -952,7 +961,7 @@ __global__ __launch_bounds__(BLOCK) void score_bwd_seg_kernel(dl_csr_plan g, con
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
     constexpr int VEC = GE::VEC, G = GE::G, EPW = GE::EPW, KP = FL::KP, VPL = FL::VPL, ROW = GE::ROW;
-    using US = Stage<K, D, T, 2>;
+    using US = Stage<K, D, T, 2, (TrainWaves<K, D, FUSED>::value > 1)>;
     // per wave: the u rows of Z and H during the walk (the first 2 ROW floats of the wave's region), then — the same
     // memory — the groups' [dZ row | dH row] partials for the unit sum
     __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
