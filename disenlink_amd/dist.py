@@ -182,6 +182,64 @@ class ChunkedRowGather:
         self._keep.clear()
 
 
+class PeerRowGather:
+    """All-gather of a node table PEER BLOCK by peer block, asynchronously: W broadcasts (block q from its owner), so that
+    `wait(q)` makes the current stream wait for peer q's rows only — the routing of the entries whose column lies in block
+    q runs under the transfer of the blocks behind it (Shard.route_by_peer).  The own block is already in place."""
+
+    def __init__(self, full: torch.Tensor, part: Partition, rank: int, group=None):
+        self.full, self.part, self.rank, self.group = full, part, rank, group
+        self.works, self._host = [], []
+
+    def start(self):
+        B, W = self.part.block, self.part.world
+        host_path = _gloo_on_device(self.full, self.group)
+        for q in range(W):
+            src = dist.get_global_rank(self.group, q) if self.group is not None else q
+            blk = self.full[q * B:(q + 1) * B]
+            if host_path:
+                h = blk.cpu() if q == self.rank else torch.empty(blk.shape, dtype=blk.dtype)
+                self._host.append(h)
+                self.works.append(dist.broadcast(h, src=src, group=self.group, async_op=True))
+            else:
+                self.works.append(dist.broadcast(blk, src=src, group=self.group, async_op=True))
+        return self
+
+    def wait(self, q: int):
+        self.works[q].wait()
+        if self._host and q != self.rank:
+            B = self.part.block
+            self.full[q * B:(q + 1) * B].copy_(self._host[q])
+
+    def wait_all(self):
+        for q in range(len(self.works)):
+            self.wait(q)
+        self._host.clear()
+
+
+def route_in_arrival_order(backend, shard: "Shard", Z, t, s, gather):
+    """p, a (per local entry) and this rank's rows of s, routing the entries peer block by peer block: first those whose
+    neighbour is local, then, as `gather.wait(q)` returns, those whose neighbour lives on peer q.  Entry results do not
+    depend on the order, and the row sums are taken over the finished arrays by the last call: the same bits as one
+    routing pass after a blocking all-gather."""
+    dev = Z.device
+    p = torch.zeros(shard.graph.n_edges, dtype=torch.uint8, device=dev)
+    a = torch.zeros(shard.graph.n_edges, dtype=torch.float32, device=dev)
+    s[shard.lo:shard.hi] = 0                                   # (rows without any entry on any peer keep this)
+    order = [shard.rank] + [q for q in range(shard.world) if q != shard.rank]
+    last = max((i for i, q in enumerate(order) if shard.route_by_peer[q] is not None), default=-1)
+    for i, q in enumerate(order):
+        if q != shard.rank:
+            gather.wait(q)
+        g = shard.route_by_peer[q]
+        if g is not None:
+            backend.route_fwd(g, Z, t, s, p_out=p, a_out=a)
+    gather.wait_all()
+    if last < 0:                                               # no entries at all: the row sums of empty rows are zero
+        pass
+    return p, a
+
+
 # --------------------------------------------------------------------------- backends
 class HipBackend:
     """The product backend: libdisenlink_hip.so through disenlink_amd.ops."""
@@ -190,8 +248,8 @@ class HipBackend:
         from . import ops
         self.ops = ops
 
-    def route_fwd(self, g, Z, t, s_out):
-        return self.ops.route_fwd(g, Z, t, s_out=s_out)[:2]
+    def route_fwd(self, g, Z, t, s_out, p_out=None, a_out=None):
+        return self.ops.route_fwd(g, Z, t, s_out=s_out, p_out=p_out, a_out=a_out)[:2]
 
     def aggregate_fwd(self, g, Z, beta, p, a, s, H_out):
         self.ops.aggregate_fwd(g, Z, beta, p, a, s, H_out=H_out)
@@ -257,14 +315,20 @@ class Shard:
     # forward scoring in gather order: [(positions in the local slice, PairList)], first the pairs whose second endpoint
     # is local, then one list per row chunk of the H all-gather (second endpoint remote, in that chunk)
     pair_groups: list = field(default_factory=list)
+    # routing under the Z gather: one Graph per peer block q (the same CSR arrays; its routing plan covers only the
+    # entries whose column lies in block q — one contiguous run per row, columns being sorted), None where a peer has
+    # none; empty list = one routing pass after a blocking all-gather
+    route_by_peer: list = field(default_factory=list)
 
     @staticmethod
     def build(rank: int, world: int, n_nodes: int, edge_src, edge_dst, pu, pv, device,
               seg_len: int = 32, row_bytes: int = 2048, balance: str = "nnz", n_chunks: int = 1,
-              with_backward: bool = True) -> "Shard":
+              with_backward: bool = True, z_by_peer: bool | None = None) -> "Shard":
         """edge rows = TRAIN edge rows (directed, duplicates ok); pu/pv = the global pair list, sorted by pu.
         balance: "nnz" (blocks of equal work) or "nodes" (equal node counts); n_chunks: row chunks of the asynchronous
-        H all-gather (1 = one blocking all-gather before scoring)."""
+        H all-gather (1 = one blocking all-gather before scoring).  z_by_peer: route the local-column entries first and
+        every peer's entries when ITS block of Z has arrived (None: when a (row, peer) run holds >= 4 entries on average —
+        shorter runs are a wavefront per entry or two; DL_Z_BY_PEER=0/1 forces it)."""
         pu = np.asarray(pu, dtype=np.int64)
         pv = np.asarray(pv, dtype=np.int64)
         if pu.size and np.any(np.diff(pu) < 0):
@@ -298,8 +362,28 @@ class Shard:
                 groups.append((ti, sub))
         inc = _incidence_only(tpu, tpv, n_pad, lo, hi, row_bytes) if with_backward else None
         block = int(np.max(np.diff(cuts))) if pu.size else 0
+        forced = os.environ.get("DL_Z_BY_PEER")
+        if forced is not None and forced != "":
+            z_by_peer = forced != "0"
+        if z_by_peer is None:
+            z_by_peer = world > 1 and graph.n_edges >= 4 * world * max(1, hi - lo)
+        by_peer = []
+        if z_by_peer and world > 1:
+            from .graph import CsrPlan, length_order, route_seg_len
+            col = graph.col.to(torch.int64)
+            for q in range(world):
+                keep = (col >= q * B) & (col < (q + 1) * B)
+                n_q = int(keep.sum())
+                if n_q == 0:
+                    by_peer.append(None)
+                    continue
+                route = CsrPlan.build(graph.rowptr.to(torch.int64), col, n_pad, row_offset=lo,
+                                      seg_len=min(seg_len, route_seg_len(n_q)), n_slices=1, keep=keep, unit_segs=1,
+                                      by_length=length_order(n_pad, row_bytes))
+                route.rowptr, route.col = graph.plan.rowptr, graph.plan.col       # the SAME arrays: only the segments differ
+                by_peer.append(Graph(graph.plan, None, route, False))
         return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts,
-                     part, groups)
+                     part, groups, by_peer)
 
     def pad_rows(self, x_local_real: torch.Tensor) -> torch.Tensor:
         """Feature rows of this rank's block, zero rows for padding nodes."""
@@ -336,6 +420,22 @@ def score_local_pairs(backend, shard: Shard, Z, H, t, gather: "ChunkedRowGather 
     return prob
 
 
+def _gather_and_route(sh: "Shard", backend, Z_loc, t, group, table_dtype):
+    """The gathered Z table, this rank's rows of s (raw sums) and (p, a) of its entries: one blocking all-gather and one
+    routing pass, or — Shard.route_by_peer — the per-peer gather with the routing in arrival order."""
+    K, d = Z_loc.shape[1], Z_loc.shape[2]
+    dev = Z_loc.device
+    Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
+    s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
+    if sh.route_by_peer:
+        Z[sh.lo:sh.hi] = Z_loc.detach().to(table_dtype)
+        p, a = route_in_arrival_order(backend, sh, Z, t, s, PeerRowGather(Z, sh.part, sh.rank, group).start())
+    else:
+        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().to(table_dtype))
+        p, a = backend.route_fwd(sh.graph, Z, t, s)
+    return Z, s, p, a
+
+
 # --------------------------------------------------------------------------- autograd over the shard
 class ShardedHotPath(torch.autograd.Function):
     """Z_loc [rows,K,d] -> (H_loc [rows,K,d], prob_loc [local pairs]) with the collectives inside."""
@@ -347,10 +447,7 @@ class ShardedHotPath(torch.autograd.Function):
         sh = shard
         K, d = Z_loc.shape[1], Z_loc.shape[2]
         dev = Z_loc.device
-        Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
-        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().to(table_dtype))
-        s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
-        p, a = backend.route_fwd(sh.graph, Z, t, s)
+        Z, s, p, a = _gather_and_route(sh, backend, Z_loc, t, group, table_dtype)
         all_gather_rows(s, sh.lo, sh.hi, group)
         H = torch.empty_like(Z)
         backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
@@ -414,10 +511,7 @@ class ShardedHotPathLoss(torch.autograd.Function):
         sh = shard
         K, d = Z_loc.shape[1], Z_loc.shape[2]
         dev = Z_loc.device
-        Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
-        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().to(table_dtype))
-        s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
-        p, a = backend.route_fwd(sh.graph, Z, t, s)
+        Z, s, p, a = _gather_and_route(sh, backend, Z_loc, t, group, table_dtype)
         all_gather_rows(s, sh.lo, sh.hi, group)
         H = torch.empty_like(Z)
         backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
@@ -603,9 +697,15 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
         e = [ev() for _ in range(8)] if timers is not None else None
         rec = (lambda i: e[i].record()) if e else (lambda i: None)
         rec(0)
-        all_gather_rows(Z, shard.lo, shard.hi, src=Z_loc)
-        rec(1)
-        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        if shard.route_by_peer:                                 # Z peer block by peer block, routing in arrival order
+            Z[shard.lo:shard.hi] = Z_loc
+            gz = PeerRowGather(Z, shard.part, shard.rank).start()
+            rec(1)
+            p, a = route_in_arrival_order(backend, shard, Z, t, s, gz)
+        else:
+            all_gather_rows(Z, shard.lo, shard.hi, src=Z_loc)
+            rec(1)
+            p, a = backend.route_fwd(shard.graph, Z, t, s)
         rec(2)
         all_gather_rows(s, shard.lo, shard.hi)
         rec(3)
@@ -698,6 +798,8 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
                           score_under_h_gather_ms=float(allr[r][3]), score_alone_ms=float(allr[r][4]))
                      for r in range(world)],
         "phases_rank0_ms": phases,
+        "z_gather": ("by peer block, routing in arrival order (route_ms spans the gather)" if shard.route_by_peer
+                     else "one blocking all-gather before the routing"),
         "partition": {"balance": "nnz", "block_rows": shard.part.block, "padded_nodes": shard.n_pad,
                       "nnz_max_over_mean": float(nnz.max() / max(nnz.mean(), 1.0)), "h_gather_chunks": shard.part.n_chunks,
                       "allgather_bytes_received_per_rank_per_step": int(gather_bytes)},

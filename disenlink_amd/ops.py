@@ -118,15 +118,23 @@ def _check_rows(g: Graph, Z: torch.Tensor):
 
 
 # ---------------------------------------------------------------------- raw wrappers
-def route_fwd(g: Graph, Z: torch.Tensor, t: float, s_out: torch.Tensor | None = None):
+def route_fwd(g: Graph, Z: torch.Tensor, t: float, s_out: torch.Tensor | None = None, p_out: torch.Tensor | None = None,
+              a_out: torch.Tensor | None = None):
     """-> p uint8[E], a f32[E], s f32[N,K] (raw sums; only the graph's rows are written).
-    model.py:56-72 on the edges of adj."""
+    model.py:56-72 on the edges of adj.  p_out / a_out: write into existing per-entry arrays (a graph whose routing plan
+    covers only SOME entries — dist.Shard.route_by_peer — fills its part of them; the row sums are taken over the
+    arrays as they stand, so they are final after the last part)."""
     lib = _lib.load()
     Z, dt = _tab(Z)
     _need_cuda(Z, g.rowptr)
     N, K, d = _check_rows(g, Z)
-    p = _empty(g.n_edges, torch.uint8, Z.device)
-    a = _empty(g.n_edges, torch.float32, Z.device)
+    if (p_out is None) != (a_out is None):
+        raise ValueError("p_out and a_out come together")
+    if p_out is not None and (p_out.dtype != torch.uint8 or a_out.dtype != torch.float32 or p_out.numel() != g.n_edges
+                              or a_out.numel() != g.n_edges or not p_out.is_contiguous() or not a_out.is_contiguous()):
+        raise ValueError("p_out / a_out must be contiguous uint8 / float32 arrays of n_edges entries")
+    p = _empty(g.n_edges, torch.uint8, Z.device) if p_out is None else p_out
+    a = _empty(g.n_edges, torch.float32, Z.device) if a_out is None else a_out
     s = _empty((N, K), torch.float32, Z.device) if s_out is None else s_out
     ws = _workspace(g.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_route_fwd(g.c_struct(), Z.data_ptr(), K, d, dt, float(t), p.data_ptr(), a.data_ptr(),

@@ -24,19 +24,33 @@ def _np(t):
 
 
 class OracleBackend:
-    def route_fwd(self, g, Z, t, s_out):
+    def route_fwd(self, g, Z, t, s_out, p_out=None, a_out=None):
+        """Like dl_route_fwd: the entries of the graph's ROUTING plan are routed (all of them, or — Shard.route_by_peer —
+        those whose column lies in one peer's block), into p_out / a_out when given; the row sums are then taken over the
+        per-entry arrays as they stand."""
         src, dst = _rows(g.plan)
         Zh = _np(Z)
         K = Zh.shape[1]
-        with np.errstate(over="ignore", invalid="ignore"):
-            ex = np.exp(_edge_dots(Zh, src, dst) / f32(t), dtype=f32)
-            alpha = ex / ex.sum(axis=1, dtype=f32, keepdims=True)
-        p = np.argmax(alpha, axis=1) if src.size else np.zeros(0, np.int64)
-        a = alpha[np.arange(p.size), p].astype(f32) if src.size else np.zeros(0, f32)
+        E = src.size
+        p_all = p_out.numpy() if p_out is not None else np.zeros(E, np.uint8)
+        a_all = a_out.numpy() if a_out is not None else np.zeros(E, f32)
+        todo = np.arange(E)
+        if g.route is not None:
+            r = g.route
+            rows, beg, end = r.seg_row.numpy(), r.seg_beg.numpy(), r.seg_end.numpy()
+            todo = np.concatenate([np.arange(b, e) for rw, b, e in zip(rows, beg, end) if rw >= 0 and e > b] or
+                                  [np.zeros(0, np.int64)]).astype(np.int64)
+        if todo.size:
+            with np.errstate(over="ignore", invalid="ignore"):
+                ex = np.exp(_edge_dots(Zh, src[todo], dst[todo]) / f32(t), dtype=f32)
+                alpha = ex / ex.sum(axis=1, dtype=f32, keepdims=True)
+            pk = np.argmax(alpha, axis=1)
+            p_all[todo] = pk.astype(np.uint8)
+            a_all[todo] = alpha[np.arange(pk.size), pk].astype(f32)
         s_loc = np.zeros((g.n_rows, K), dtype=f32)
-        np.add.at(s_loc, (src - g.row_offset, p), a)
+        np.add.at(s_loc, (src - g.row_offset, p_all.astype(np.int64)), a_all)
         s_out[g.row_offset:g.row_offset + g.n_rows] = torch.from_numpy(s_loc)
-        return torch.from_numpy(p.astype(np.uint8)), torch.from_numpy(a)
+        return (torch.from_numpy(p_all) if p_out is None else p_out), (torch.from_numpy(a_all) if a_out is None else a_out)
 
     def aggregate_fwd(self, g, Z, beta, p, a, s, H_out):
         src, dst = _rows(g.plan)

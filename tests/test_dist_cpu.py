@@ -53,7 +53,7 @@ def _reference(pb, sd):
     return emb.detach().numpy(), prob.detach().numpy(), float(loss.detach()), {k: v.grad.numpy() for k, v in sd.items()}
 
 
-def _worker(rank, world, port, pb, sd, out, n_chunks=1):
+def _worker(rank, world, port, pb, sd, out, n_chunks=1, z_by_peer=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -66,7 +66,8 @@ def _worker(rank, world, port, pb, sd, out, n_chunks=1):
         model = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"])
         model.load_state_dict(sd)
         shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4,
-                               n_chunks=n_chunks)
+                               n_chunks=n_chunks, z_by_peer=z_by_peer)
+        assert bool(shard.route_by_peer) == bool(z_by_peer)
         r0, r1 = shard.local_real_rows()
         emb, prob = dd.sharded_forward(model, torch.from_numpy(pb["x"][r0:r1]), shard, backend=OracleBackend())
         lab = torch.from_numpy(pb["label"][shard.pair_lo:shard.pair_hi])
@@ -85,7 +86,7 @@ def _worker(rank, world, port, pb, sd, out, n_chunks=1):
         dist.destroy_process_group()
 
 
-def _loss_worker(rank, world, port, pb, sd, out, table):
+def _loss_worker(rank, world, port, pb, sd, out, table, z_by_peer=False):
     """The training step through sharded_forward_loss: one-pass scorer over the local incidence rows, no (prob, g_prob)
     all-gather; `table` = storage type of the gathered tables."""
     sys.path.insert(0, ROOT)
@@ -100,7 +101,8 @@ def _loss_worker(rank, world, port, pb, sd, out, table):
         model = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"],
                             table_dtype=torch.bfloat16 if table == "bf16" else torch.float32)
         model.load_state_dict(sd)
-        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4, n_chunks=2)
+        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4, n_chunks=2,
+                               z_by_peer=z_by_peer)
         r0, r1 = shard.local_real_rows()
         P = pb["pu"].size
         label = torch.from_numpy(pb["label"])
@@ -119,8 +121,8 @@ def _loss_worker(rank, world, port, pb, sd, out, table):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,table", [(2, "f32"), (4, "f32"), (4, "bf16")])
-def test_sharded_training_step_with_the_one_pass_scorer(world, table):
+@pytest.mark.parametrize("world,table,z_by_peer", [(2, "f32", False), (4, "f32", False), (4, "bf16", False), (4, "f32", True)])
+def test_sharded_training_step_with_the_one_pass_scorer(world, table, z_by_peer):
     """sharded_forward_loss over gloo: every rank runs the scorer's forward + loss gradient + backward in one pass over
     ITS incidence rows (all pairs touching its nodes), so no (prob, g_prob) all-gather exists; the summed replicas'
     gradients equal the unsharded dense oracle's.  bf16: the gathered Z / H tables are bf16 (half the all-gather bytes);
@@ -132,7 +134,7 @@ def test_sharded_training_step_with_the_one_pass_scorer(world, table):
     emb_ref, prob_ref, loss_ref, grads_ref = _reference(pb, sd)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_loss_worker, args=(world, _free_port(), pb, sd, out, table), nprocs=world, join=True)
+    mp.spawn(_loss_worker, args=(world, _free_port(), pb, sd, out, table, z_by_peer), nprocs=world, join=True)
     tol = dict(rtol=1e-5, atol=1e-6) if table == "f32" else dict(rtol=5e-2, atol=2e-2)
     gtol = 2e-4 if table == "f32" else 8e-2
     for r in range(world):
@@ -160,10 +162,12 @@ def _skewed_problem(seed=5, N=90, F=7, K=4, d=8, nhid=5):
     return dict(N=N, F=F, K=K, d=d, nhid=nhid, src=src, dst=dst, x=x, pu=pu, pv=pv, label=label, beta=0.7, t=1.0)
 
 
-@pytest.mark.parametrize("world,n_chunks,skewed", [(2, 1, False), (3, 1, False), (3, 2, False), (4, 3, True), (8, 2, True)])
-def test_sharded_path_matches_unsharded_oracle(world, n_chunks, skewed):
+@pytest.mark.parametrize("world,n_chunks,skewed,z_by_peer", [(2, 1, False, False), (3, 1, False, False), (3, 2, False, True),
+                                                              (4, 3, True, False), (4, 3, True, True), (8, 2, True, False)])
+def test_sharded_path_matches_unsharded_oracle(world, n_chunks, skewed, z_by_peer):
     """2 / 3 / 4 ranks over gloo, work-balanced blocks (padded to the largest, ids relabelled), with the H all-gather
-    blocking (n_chunks = 1) or in asynchronous row chunks with the pairs scored in arrival order."""
+    blocking (n_chunks = 1) or in asynchronous row chunks with the pairs scored in arrival order; z_by_peer: the Z table
+    gathered peer block by peer block with the routing in arrival order (local columns first)."""
     from disenlink_amd.model import Disentangle
     pb = _skewed_problem() if skewed else _problem()
     torch.manual_seed(0)
@@ -171,7 +175,7 @@ def test_sharded_path_matches_unsharded_oracle(world, n_chunks, skewed):
     emb_ref, prob_ref, loss_ref, grads_ref = _reference(pb, sd)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), pb, sd, out, n_chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), pb, sd, out, n_chunks, z_by_peer), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
     if n_chunks > 1:                                        # every local pair sits in exactly one arrival group
         for r in range(world):
@@ -194,6 +198,55 @@ def test_sharded_path_matches_unsharded_oracle(world, n_chunks, skewed):
         covered_rows += r1 - r0
         covered_pairs += q1 - q0
     assert covered_rows == pb["N"] and covered_pairs == pb["pu"].size
+
+
+def test_routing_in_arrival_order_reads_only_blocks_that_have_arrived():
+    """route_in_arrival_order without any process group: a stand-in gather hands over one peer block per wait(q), every
+    block that has not arrived yet is NaN.  The entries routed before a block's arrival must not have read it (no NaN
+    in p / a / s) and the result equals ONE routing pass over the complete table bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from disenlink_amd import dist as dd
+    from oracle_backend import OracleBackend
+    pb = _skewed_problem(seed=11, N=120)
+    world, K, d = 4, pb["K"], pb["d"]
+    rng = np.random.default_rng(0)
+    for rank in range(world):
+        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4,
+                               with_backward=False, z_by_peer=True)
+        assert len(shard.route_by_peer) == world and any(g is not None for g in shard.route_by_peer)
+        # every entry belongs to exactly one peer's routing plan
+        seen = np.zeros(shard.graph.n_edges, np.int64)
+        for g in shard.route_by_peer:
+            if g is not None:
+                r = g.route
+                for rw, b, e in zip(r.seg_row.numpy(), r.seg_beg.numpy(), r.seg_end.numpy()):
+                    if rw >= 0:
+                        seen[b:e] += 1
+        assert np.all(seen == 1)
+        Zfull = torch.from_numpy((rng.standard_normal((shard.n_pad, K, d)) * 0.4).astype(np.float32))
+        B = shard.part.block
+        be = OracleBackend()
+        s_ref = torch.zeros((shard.n_pad, K))
+        p_ref, a_ref = be.route_fwd(shard.graph, Zfull, 1.0, s_ref)
+
+        class Reveal:                                            # the gather: block q appears at wait(q)
+            def __init__(self, Z):
+                self.Z, self.seen = Z, []
+            def wait(self, q):
+                self.Z[q * B:(q + 1) * B] = Zfull[q * B:(q + 1) * B]
+                self.seen.append(q)
+            def wait_all(self):
+                for q in range(world):
+                    if q not in self.seen and q != rank:
+                        self.wait(q)
+        Z = torch.full_like(Zfull, float("nan"))
+        Z[shard.lo:shard.hi] = Zfull[shard.lo:shard.hi]
+        s = torch.full((shard.n_pad, K), float("nan"))
+        rev = Reveal(Z)
+        p, a = dd.route_in_arrival_order(be, shard, Z, 1.0, s, rev)
+        assert rev.seen == [q for q in range(world) if q != rank]
+        assert torch.equal(p, p_ref) and torch.equal(a, a_ref) and not torch.isnan(a).any()
+        assert torch.equal(s[shard.lo:shard.hi], s_ref[shard.lo:shard.hi])
 
 
 def test_work_balanced_partition_on_hub_skewed_graphs():

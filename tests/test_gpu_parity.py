@@ -948,6 +948,49 @@ def test_scaled_backward_is_the_backward_times_a_device_scalar():
     assert torch.allclose(grads[2.5], grads[1.0] * 2.5, rtol=1e-5, atol=1e-7 * float(grads[1.0].abs().max()))
 
 
+def test_routing_by_peer_block_on_the_gpu_equals_one_routing_pass():
+    """dist.Shard.route_by_peer through the kernels: rank 0 .. 3 of a 4-way shard of a squirrel-shaped graph, the Z table
+    revealed peer block by peer block (blocks that have not "arrived" are NaN): p, a and the rank's rows of s equal one
+    routing pass over the complete table bit for bit, and nothing read a block before its arrival."""
+    from disenlink_amd import dist as dd
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.splits import make_link_split
+    sg = synthetic_graph("chameleon", seed=4)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=2, seed=4)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    o = np.argsort(pu, kind="stable")
+    pu, pv = pu[o], pv[o]
+    world, K, d = 4, 8, 64
+    be = dd.HipBackend()
+    for rank in range(world):
+        shard = dd.Shard.build(rank, world, sg.n_nodes, split.train_src, split.train_dst, pu, pv, DEV, row_bytes=K * d * 4,
+                               with_backward=False, z_by_peer=True)
+        assert len(shard.route_by_peer) == world
+        B = shard.part.block
+        torch.manual_seed(rank)
+        Zfull = torch.randn(shard.n_pad, K, d, device=DEV) * 0.3
+        s_ref = torch.zeros((shard.n_pad, K), device=DEV)
+        p_ref, a_ref = be.route_fwd(shard.graph, Zfull, 1.0, s_ref)
+
+        class Reveal:
+            def __init__(self, Z):
+                self.Z, self.seen = Z, []
+            def wait(self, q):
+                self.Z[q * B:(q + 1) * B] = Zfull[q * B:(q + 1) * B]
+                self.seen.append(q)
+            def wait_all(self):
+                for q in range(world):
+                    if q not in self.seen and q != rank:
+                        self.wait(q)
+        Z = torch.full_like(Zfull, float("nan"))
+        Z[shard.lo:shard.hi] = Zfull[shard.lo:shard.hi]
+        s = torch.full((shard.n_pad, K), float("nan"), device=DEV)
+        p, a = dd.route_in_arrival_order(be, shard, Z, 1.0, s, Reveal(Z))
+        assert torch.equal(p, p_ref) and torch.equal(a, a_ref) and not torch.isnan(a).any()
+        assert torch.equal(s[shard.lo:shard.hi], s_ref[shard.lo:shard.hi])
+
+
 def test_launches_follow_the_callers_stream():
     """The library binds to torch's HIP runtime, so a non-default torch stream is honoured."""
     from disenlink_amd import ops
