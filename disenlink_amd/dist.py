@@ -851,6 +851,21 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
         if it >= args.warmup:
             acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3 + ng)]
     acc /= args.steps
+    # the routing cut by peer block (Shard.route_by_peer): its kernels alone, every block already present
+    by_peer = None
+    if shard.route_by_peer:
+        class _Arrived:
+            def wait(self, q): pass
+            def wait_all(self): pass
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(args.warmup + 1):
+            e0.record()
+            for _ in range(args.steps):
+                route_in_arrival_order(backend, shard, Z, t, s, _Arrived())
+            e1.record()
+            torch.cuda.synchronize()
+        peers = [g for g in shard.route_by_peer if g is not None]
+        by_peer = {"route_us": e0.elapsed_time(e1) * 1e3 / args.steps, "passes": len(peers)}
     w = np.bincount(train_src, minlength=sg.n_nodes) + np.bincount(train_dst, minlength=sg.n_nodes) + 1
     cuts = shard.part.cuts
     share = np.array([w[cuts[r]:cuts[r + 1]].sum() for r in range(emu_world)], dtype=np.float64)
@@ -863,6 +878,7 @@ def _bench_emulated(args, emu_world: int, device) -> dict:
             "n_nodes": sg.n_nodes, "block_rows": shard.part.block, "table_MB": shard.n_pad * K * d * wb / 1e6,
             "work_share_max_over_mean": float(share.max() / share.mean()),
             "route_us": acc[0] * 1e3, "aggregate_us": acc[1] * 1e3, "score_us": acc[2] * 1e3,
+            "route_by_peer": by_peer,
             "score_in_gather_order": groups,
             "scored_before_any_chunk_lands": (groups[0]["pairs"] / max(1, shard.pairs.n_pairs)) if groups else 0.0,
             "allgather_bytes_per_rank_per_step": (emu_world - 1) * shard.part.block * (2 * K * d * wb + K * 4)}
