@@ -226,17 +226,13 @@ def route_in_arrival_order(backend, shard: "Shard", Z, t, s, gather):
     p = torch.zeros(shard.graph.n_edges, dtype=torch.uint8, device=dev)
     a = torch.zeros(shard.graph.n_edges, dtype=torch.float32, device=dev)
     s[shard.lo:shard.hi] = 0                                   # (rows without any entry on any peer keep this)
-    order = [shard.rank] + [q for q in range(shard.world) if q != shard.rank]
-    last = max((i for i, q in enumerate(order) if shard.route_by_peer[q] is not None), default=-1)
-    for i, q in enumerate(order):
+    for q in [shard.rank] + [q for q in range(shard.world) if q != shard.rank]:
         if q != shard.rank:
             gather.wait(q)
         g = shard.route_by_peer[q]
-        if g is not None:
+        if g is not None:                                      # (a shard without any entry keeps the zero row sums)
             backend.route_fwd(g, Z, t, s, p_out=p, a_out=a)
     gather.wait_all()
-    if last < 0:                                               # no entries at all: the row sums of empty rows are zero
-        pass
     return p, a
 
 
