@@ -323,8 +323,9 @@ class Shard:
         """edge rows = TRAIN edge rows (directed, duplicates ok); pu/pv = the global pair list, sorted by pu.
         balance: "nnz" (blocks of equal work) or "nodes" (equal node counts); n_chunks: row chunks of the asynchronous
         H all-gather (1 = one blocking all-gather before scoring).  z_by_peer: route the local-column entries first and
-        every peer's entries when ITS block of Z has arrived (None: when a (row, peer) run holds >= 4 entries on average —
-        shorter runs are a wavefront per entry or two; DL_Z_BY_PEER=0/1 forces it)."""
+        every peer's entries when ITS block of Z has arrived (DL_Z_BY_PEER=0/1 forces it; default off: it trades one
+        all-gather for W broadcasts and has not been timed on real links — and it only makes sense where a (row, peer) run
+        still holds several entries, n_edges >= 4 * world * rows, shorter runs being a wavefront per entry or two)."""
         pu = np.asarray(pu, dtype=np.int64)
         pv = np.asarray(pv, dtype=np.int64)
         if pu.size and np.any(np.diff(pu) < 0):
@@ -362,7 +363,7 @@ class Shard:
         if forced is not None and forced != "":
             z_by_peer = forced != "0"
         if z_by_peer is None:
-            z_by_peer = world > 1 and graph.n_edges >= 4 * world * max(1, hi - lo)
+            z_by_peer = False        # opt-in until it has been timed on real links (W broadcasts against one all-gather)
         by_peer = []
         if z_by_peer and world > 1:
             from .graph import CsrPlan, length_order, route_seg_len
