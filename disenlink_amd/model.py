@@ -97,13 +97,24 @@ class Disentangle(nn.Module):
             for attr in ("weight", "bias"):
                 yield (name, attr), [getattr(getattr(f, name), attr) for f in self.factors]
 
+    def _param_slots(self):
+        """(key, [(owning module's _parameters dict, attribute name)]) per group: where the LIVE Parameter objects are
+        registered — the fast path checks identity against these slots, so a replaced Parameter object
+        (load_state_dict(assign=True), setattr, weight tying) is seen."""
+        names = ("mlp",) if self.single_layer else ("mlp1", "mlp2")
+        for name in names:
+            for attr in ("weight", "bias"):
+                yield (name, attr), [(getattr(f, name)._parameters, attr) for f in self.factors]
+
     def _restack(self):
-        self._stacked_check = []          # (parameter, expected data pointer, expected shape) of every view
-        for key, ps in self._param_groups():
+        # (owner's _parameters dict, attribute, parameter, expected data pointer, expected shape) of every view
+        self._stacked_check = []
+        for key, slots in self._param_slots():
+            ps = [reg[attr] for reg, attr in slots]
             buf = torch.stack([p.data for p in ps]).contiguous()
-            for i, p in enumerate(ps):
+            for i, (p, (reg, attr)) in enumerate(zip(ps, slots)):
                 p.data = buf[i]
-                self._stacked_check.append((p, p.data_ptr(), tuple(p.shape)))
+                self._stacked_check.append((reg, attr, p, p.data_ptr(), tuple(p.shape)))
             self._stacked[key] = buf
 
     def _apply(self, fn, *args, **kwargs):                     # .to(device) / .float() replace .data: re-stack
@@ -129,17 +140,37 @@ class Disentangle(nn.Module):
         every forward: compares each parameter's data pointer with the one recorded when the buffers were built (indexing
         the buffers here — 4K tiny view tensors per call — cost the eager loop ~50 us of host time per epoch)."""
         chk = self.__dict__.get("_stacked_check")
-        if chk and all(p.data_ptr() == ptr and tuple(p.shape) == shape for p, ptr, shape in chk):
-            return [c[0] for c in chk]
-        # pointers moved (a deep copy, an unpickled module): look at the buffers themselves and record anew
+        if chk and all(reg.get(attr) is p and p.data_ptr() == ptr and tuple(p.shape) == shape
+                       for reg, attr, p, ptr, shape in chk):
+            return [c[2] for c in chk]
+        # pointers moved (a deep copy, an unpickled module) or a Parameter object was replaced: look at the LIVE
+        # parameters and the buffers themselves, and record anew
         fresh = []
-        for key, ps in self._param_groups():
+        for key, slots in self._param_slots():
             buf = self._stacked.get(key)
-            if buf is None or any(p.data_ptr() != buf[i].data_ptr() or p.shape != buf[i].shape for i, p in enumerate(ps)):
+            ps = [reg.get(attr) for reg, attr in slots]
+            if buf is None or any(p is None or p.data_ptr() != buf[i].data_ptr() or p.shape != buf[i].shape
+                                  for i, p in enumerate(ps)):
                 return None
-            fresh += [(p, p.data_ptr(), tuple(p.shape)) for p in ps]
+            fresh += [(reg, attr, p, p.data_ptr(), tuple(p.shape)) for p, (reg, attr) in zip(ps, slots)]
         self._stacked_check = fresh
-        return [c[0] for c in fresh]
+        return [c[2] for c in fresh]
+
+    def restack(self):
+        """Re-establish the shared [K, ...] buffers from the LIVE parameters (after load_state_dict(assign=True) or any
+        other replacement of Parameter objects, which leaves project() on the slower stacking path until this is
+        called).  Optimisers built over the old Parameter objects must be rebuilt, as torch requires after assign."""
+        self._restack()
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """torch's load_state_dict; with ``assign=True`` — which REPLACES the Parameter objects instead of copying into
+        them — the shared buffers are rebuilt from the new parameters afterwards, so the kernels, snapshot_state() and
+        the live state_dict keep reading the same storage."""
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        if assign:
+            self._restack()
+        return out
 
     def train(self, mode: bool = True):
         """No layer of this model depends on the mode (main_disentangled.py:193,201 call train()/eval() every

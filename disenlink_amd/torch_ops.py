@@ -18,39 +18,48 @@ scorer: model.py:109-113, backward: autograd under main_disentangled.py:198).
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch import Tensor
 
 from . import _lib, ops
 from .graph import Graph, PairList
 
-_graphs: dict[int, Graph] = {}
-_pairs: dict[int, PairList] = {}
+# handle -> object, held WEAKLY: an operator call holds its Graph / PairList through the caller's own reference (the
+# module's forward_pairs has them as arguments), so a caller that builds a new Graph or PairList per epoch (resampled
+# negatives, sweeps) does not accumulate their GPU plans here.  The handle is remembered on the object itself.
+_graphs: "weakref.WeakValueDictionary[int, Graph]" = weakref.WeakValueDictionary()
+_pairs: "weakref.WeakValueDictionary[int, PairList]" = weakref.WeakValueDictionary()
+_pinned: dict[int, object] = {}            # register_*(…, pin=True): kept alive until release(handle)
 _next = [1]
 
 
-def register_graph(g: Graph) -> int:
-    """-> handle of `g` for the operators below (idempotent per object; the registry keeps the graph alive)."""
-    for h, o in _graphs.items():
-        if o is g:
-            return h
-    h = _next[0]
-    _next[0] += 1
-    _graphs[h] = g
+def _register(table, obj, pin: bool) -> int:
+    h = getattr(obj, "_dl_handle", None)
+    if h is None or table.get(h) is not obj:
+        h = _next[0]
+        _next[0] += 1
+        obj._dl_handle = h
+        table[h] = obj
+    if pin:
+        _pinned[h] = obj
     return h
 
 
-def register_pairs(p: PairList) -> int:
-    for h, o in _pairs.items():
-        if o is p:
-            return h
-    h = _next[0]
-    _next[0] += 1
-    _pairs[h] = p
-    return h
+def register_graph(g: Graph, pin: bool = False) -> int:
+    """-> handle of `g` for the operators below (idempotent per object).  The registry does NOT keep the graph alive
+    unless ``pin=True`` (then until ``release(handle)``): keep your own reference for as long as operators use it."""
+    return _register(_graphs, g, pin)
+
+
+def register_pairs(p: PairList, pin: bool = False) -> int:
+    return _register(_pairs, p, pin)
 
 
 def release(handle: int) -> None:
+    """Forget a handle (and drop the pin, if any).  Unpinned handles vanish by themselves with their object."""
+    _pinned.pop(handle, None)
     _graphs.pop(handle, None)
     _pairs.pop(handle, None)
 

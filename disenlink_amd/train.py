@@ -62,16 +62,22 @@ class RunResult:
 
 _FUSED_ADAM = os.environ.get("DL_FUSED_ADAM", "1") != "0"
 _STACKED_ADAM = os.environ.get("DL_STACKED_ADAM", "1") != "0"
+_ADAM_KERNEL = os.environ.get("DL_ADAM_KERNEL", "dl")        # "torch": torch._fused_adam_ over the stacked buffers
 
 
 def _make_adam(model, on_gpu: bool, lr: float, weight_decay: float, capturable: bool = False):
     """The reference's Adam (main_disentangled.py:150).  On the GPU, for the drop-in module: the same fused update over
-    the module's 4 shared parameter buffers instead of its 4K views (optim.StackedAdam: same bits, an eighth of the
-    optimiser's launches' chunks and Python work); otherwise torch's own."""
+    the module's 4 shared parameter buffers instead of its 4K views (optim.StackedAdam), by default through the
+    library's one-launch ``dl_adam_step``: torch.optim.Adam's ARITHMETIC, equal to torch's fused kernel up to rounding
+    (fmaf weight decay, a different FMA contraction of the bias corrections: relative 1e-6 per step, tested) — NOT the
+    same bits.  ``DL_ADAM_KERNEL=torch`` keeps ``torch._fused_adam_`` over the 4 buffers, which IS bit-identical to
+    ``torch.optim.Adam(fused=True)`` over the views (parity runs against torch trajectories); ``DL_STACKED_ADAM=0``
+    returns to torch's own optimiser."""
     if on_gpu and _FUSED_ADAM and _STACKED_ADAM and getattr(model, "_stacked_params", None) is not None \
             and model._stacked_params() is not None:
         from .optim import StackedAdam
-        return StackedAdam(model, lr=lr, weight_decay=weight_decay, capturable=capturable)
+        return StackedAdam(model, lr=lr, weight_decay=weight_decay, capturable=capturable,
+                           use_torch_kernel=_ADAM_KERNEL == "torch")
     if capturable:
         return Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True, fused=_FUSED_ADAM)
     return Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=on_gpu and _FUSED_ADAM)
