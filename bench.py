@@ -10,9 +10,12 @@ non-zeros of the training adjacency, + the pair scorer (model.py:109-113) over t
 training pairs.  value = (E_sym + P) / median step time  (SURVEY.md §8d headline rate).  The
 projection GEMM and the one-time CSR construction are outside the timed region, as §8d says.
 
-Timing: W warm-up steps, then R = --repeats blocks of exactly K steps, each block bracketed by a
-device synchronise; ms_per_step is the MEDIAN block (a 20-step block of the default workload is ~5 ms,
-one sample of that says little).
+Timing: W warm-up steps, then warm-up BY TIME (blocks of K steps until at least 0.3 s have passed and three
+consecutive blocks agree within 2 % — a fresh GPU ramps its clocks for tens of milliseconds, far longer than any
+sensible W at 0.2 ms per step), then R blocks of exactly K steps, each bracketed by a device synchronise, R >= --repeats
+and large enough for the timed region to last >= 1 s; ms_per_step is the MEDIAN block, min / median / max are in the
+line.  The line also carries `parity`: the timed GPU outputs against the CPU oracle's dense pass on the same Z
+(max |dprob| over the scored pairs, AUC on both sides).
 
 Roofline accounting.  Two byte counts per kernel phase:
   * algorithmic_bytes — SURVEY.md §8(d)'s per-unit figures (no cache credit, every directed edge, the u rows of the
@@ -27,7 +30,9 @@ of the XCD L2s / the Infinity Cache, not HBM, so the bound that applies is the L
 sit in any cache, where the 8 TB/s HBM roofline is the bound: that is the number the north star's "fraction of the HBM
 roofline on the K-factor edge-scatter" refers to.
 
-N > 1 is launched by torch.distributed.run, one rank per GPU (see disenlink_amd/dist.py).
+N > 1: one rank per GPU over RCCL (disenlink_amd/dist.py, dist_bench.py).  Started under torch.distributed.run the
+process is a rank; started plainly (`python bench.py --gpus N`) it LAUNCHES its N ranks itself as child processes —
+before it has made any GPU call, relaying rank 0's JSON line and the children's exit code.
 """
 from __future__ import annotations
 
@@ -68,7 +73,11 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(workload_key: str):
+TRAIN_PHASE_KERNELS = {"scorer": ("score_bwd_seg_kernel", "score_bwd_coef_seg_kernel"),
+                       "bwd_phase1": ("bwd_phase1_seg_kernel",), "bwd_phase2": ("bwd_phase2_seg_kernel",)}
+
+
+def pmc_traffic(workload_key: str, phases=None):
     """HBM-side bytes per launch and phase from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2
     gfx950 correction + WRITE_SIZE, separate passes of `bench.py --sections <...>`), or None when no summary exists for
     this workload or it was collected for different kernel sources."""
@@ -83,7 +92,7 @@ def pmc_traffic(workload_key: str):
         return None, (f"PMC passes in profiles/ were collected for kernel sources {entry.get('kernel_source_hash')}, "
                       f"this build is {kernel_source_hash()}: not reported")
     out = {}
-    for phase, kernels in PHASE_KERNELS.items():
+    for phase, kernels in (phases or PHASE_KERNELS).items():
         tot = 0.0
         for kname, v in entry["kernels"].items():
             base = kname.split("<")[0].split("::")[-1]
@@ -157,6 +166,7 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0, elem_bytes=
     pu, pv = pu[order], pv[order]
     pairs = PairList.build(torch.from_numpy(pu).to(device), torch.from_numpy(pv).to(device), sg.n_nodes,
                            row_bytes=K * d * elem_bytes)
+    pairs.bench_label = np.concatenate([split.pos_train.label, split.neg_train.label])[order].astype(np.float32)
     torch.manual_seed(seed)
     model = Disentangle(sg.n_feat, nhid, d, nfactor=K, beta=0.5, t=1).to(device)
     x = torch.from_numpy(sg.features()).to(device)
@@ -165,9 +175,10 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0, elem_bytes=
     return sg, split, graph, pairs, model, x, Z
 
 
-def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=30.0):
+def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=30.0, parity=None):
     """The oracle's dense restatement (same op sequence as model.py:56-76,109-113) timed on the host
-    cores: one warm-up, then the median of up to 3 passes within the budget."""
+    cores: one warm-up, then the median of up to 3 passes within the budget.  `parity` = (pu, pv, label, prob_gpu) of
+    the timed GPU step: the warm-up pass's probabilities at those pairs become the line's parity block."""
     from oracle import dense_ref
     N = Z_cpu.shape[0]
     adj = torch.zeros(N, N)
@@ -182,16 +193,36 @@ def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=30.0):
             H, e, _att, _p, _s = dense_ref.route_aggregate(Zk, adj, beta, t)
             P = dense_ref.score_allpairs(H, e)
             dt = time.perf_counter() - t0
+            if it == 0 and parity is not None:
+                par = parity_block(P[parity[0].long(), parity[1].long()].numpy(), *parity[2:])
             del H, e, _att, P
             if it > 0:
                 times.append(dt)
             if time.perf_counter() - t_all > budget_s and times:
                 break
     med = float(np.median(times))
-    return dict(value=n_units / med, unit="edges/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"whole workload, dense [K,N,N] forward (route+aggregate+all-pairs score) of oracle/dense_ref.py, "
-                       f"median of {len(times)} after 1 warm-up, {med:.2f} s per pass",
-                seconds_per_pass=med)
+    out = dict(value=n_units / med, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"whole workload, dense [K,N,N] forward (route+aggregate+all-pairs score) of oracle/dense_ref.py, "
+                      f"median of {len(times)} after 1 warm-up, {med:.2f} s per pass",
+               seconds_per_pass=med)
+    return (out, par) if parity is not None else out
+
+
+def parity_block(prob_cpu, label, prob_gpu):
+    """The metric's "link-pred AUC parity vs CPU ref" for the outputs of the TIMED GPU step: max |dprob| over the scored
+    pairs against the oracle's dense pass on the same Z, and the tie-averaged AUC of either side (the oracle's numpy AUC
+    for the CPU probabilities, the library's device AUC — dl_auc_pair_counts — for the GPU's)."""
+    from disenlink_amd.metrics import AucPlan
+    from oracle import metrics_ref
+    pg = prob_gpu.detach().float()
+    lab = torch.from_numpy(label).to(pg.device)
+    auc_gpu = float(AucPlan(lab).auc(pg))
+    auc_cpu = float(metrics_ref.auc_tie_avg(label, prob_cpu))
+    dmax = float(np.max(np.abs(pg.cpu().numpy().astype(np.float64) - prob_cpu.astype(np.float64))))
+    return {"max_abs_dprob": dmax, "auc_gpu": auc_gpu, "auc_cpu": auc_cpu, "abs_dauc": abs(auc_gpu - auc_cpu),
+            "pairs": int(label.size), "tolerance": {"max_abs_dprob": 1e-5, "abs_dauc": 1e-4},
+            "ok": bool(dmax <= 1e-5 and abs(auc_gpu - auc_cpu) <= 1e-4),
+            "what": "timed GPU step (route+aggregate+score on the scored train pairs) vs oracle/dense_ref.py on the same Z"}
 
 
 def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=30.0):
@@ -221,25 +252,46 @@ def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=
                 seconds_per_pass=med)
 
 
-def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats):
-    """-> (per-block seconds per step [repeats], per-phase kernel seconds (HIP events on the launch stream, mean))."""
+def steady_warmup(run_block, min_s=0.3, tol=0.02, max_s=4.0):
+    """Blocks of the step (run_block() -> seconds for one block, synchronised) until >= min_s have elapsed AND three
+    consecutive blocks agree within tol (or max_s is up) -> (blocks run, seconds spent, settled?)."""
+    hist, t0 = [], time.perf_counter()
+    while True:
+        hist.append(run_block())
+        el = time.perf_counter() - t0
+        last = hist[-3:]
+        settled = len(last) == 3 and (max(last) - min(last)) <= tol * min(last)
+        if (el >= min_s and settled) or el >= max_s:
+            return len(hist), el, settled
+
+
+def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats, min_region_s=1.0, info=None):
+    """-> (per-block seconds per step, per-phase kernel seconds (HIP events on the launch stream, median)).
+    W warm-up steps, warm-up by time (steady_warmup), then max(repeats, enough for min_region_s) blocks of exactly
+    `steps` steps."""
     def step():
         p, a, s = ops.route_fwd(graph, Z, t)
         H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
         return ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
 
-    for _ in range(warmup):
-        step()
-    blocks = []
-    for _ in range(repeats):
+    def block():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        blocks.append((time.perf_counter() - t0) / steps)
+        return (time.perf_counter() - t0) / steps
+
+    for _ in range(warmup):
+        step()
+    n_warm, warm_s, settled = steady_warmup(block)
+    est = block()
+    n_blocks = int(min(2000, max(repeats, np.ceil(min_region_s / max(est * steps, 1e-9)))))
+    blocks = [block() for _ in range(n_blocks)]
+    if info is not None:
+        info.update(warmup_blocks=n_warm, warmup_s=warm_s, warmup_settled=bool(settled), timed_region_s=float(sum(blocks)) * steps)
     # per-kernel durations with HIP events on the launch stream (torch's current stream), same loop
-    n_ev = min(steps, 50)
+    n_ev = min(max(steps, 20), 50)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
     torch.cuda.synchronize()
     for i in range(n_ev):
@@ -316,6 +368,63 @@ def hbm_bound_section(ops, device, K, d, nhid, steps, warmup, repeats, workload=
     return out
 
 
+def under_launcher() -> bool:
+    """Started by torch.distributed.run (or any launcher that sets the rendezvous variables)?"""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), pass their stderr
+    through, relay rank 0's JSON line on stdout and return the children's exit code (non-zero when any rank failed or no
+    line came back).  This process makes NO GPU / HIP call — it neither asks torch.cuda anything nor loads the library —
+    and replaces no running program (no os.exec*): it only waits for its children."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: what the host driver supports
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    env["DL_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("bench.py: launching %d ranks: %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+def launch_check(rank: int, world: int) -> int:
+    """DL_BENCH_LAUNCH_CHECK=1 (CPU tests of the launch path, no GPU needed): every rank joins a gloo group, one
+    all-reduce proves the rendezvous, rank 0 prints a line marked as a launch check.  =fail makes the last rank exit
+    non-zero before the rendezvous, to prove that a failing child fails the launch."""
+    import torch.distributed as dist
+    mode = os.environ["DL_BENCH_LAUNCH_CHECK"]
+    if mode == "fail" and rank == world - 1:
+        return 3
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    v = torch.tensor([float(rank + 1)])
+    dist.all_reduce(v)
+    if rank == 0:
+        print(json.dumps({"metric": "launch check only (no measurement)", "launch_check": True, "n_gpus": world,
+                          "rank_sum": float(v), "self_launched": bool(os.environ.get("DL_BENCH_SELF_LAUNCHED"))}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,8 +432,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is their median")
     ap.add_argument("--workload", default="auto",
-                    help="auto = squirrel_real (the real geom-gcn edge list shipped as the parity fixture) when the "
-                         "fixture is present, else the seeded squirrel-shaped graph")
+                    help="N=1: auto = squirrel_real (the real geom-gcn edge list shipped as the parity fixture) when the "
+                         "fixture is present, else the seeded squirrel-shaped graph.  N>1: auto = the three blocks of "
+                         "disenlink_amd/dist_bench.py (snap_patents strong, penn94 bf16 strong, squirrel weak); a name = "
+                         "that workload alone with --scaling / --K / --d / --dtype")
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--nhidden", type=int, default=512)
@@ -341,16 +452,22 @@ def main():
     ap.add_argument("--hbm-steps", type=int, default=5)
     args = ap.parse_args()
     want = lambda s: args.sections == "all" or s in args.sections.split(",")
-    if args.workload == "auto":                                # N > 1 grows / shards a generated graph: the seeded shape there
-        one = int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("DL_FORCE_SHARDED")
-        args.workload = "squirrel_real" if one and os.path.exists(os.path.join(ROOT, "tests", "golden", "real_squirrel.npz")) \
-            else "squirrel"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not under_launcher():                 # BEFORE any GPU call: the parent only starts and waits
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
+    if os.environ.get("DL_BENCH_LAUNCH_CHECK"):
+        raise SystemExit(launch_check(rank, world))
+    one = world == 1 and not os.environ.get("DL_FORCE_SHARDED")
+    if args.workload == "auto" and one:
+        args.workload = "squirrel_real" if os.path.exists(os.path.join(ROOT, "tests", "golden", "real_squirrel.npz")) \
+            else "squirrel"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # DL_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the collectives go through gloo — a functional
@@ -378,10 +495,10 @@ def main():
     beta, t = 0.5, 1.0
     if sharded:
         import torch.distributed as dist
-        from disenlink_amd import dist as dl_dist
-        result = dl_dist.bench_sharded(args, rank, world, device)
+        from disenlink_amd import dist_bench
+        result = dist_bench.bench_sharded(args, rank, world, device)
         if rank == 0:
-            print(json.dumps(result))
+            print(json.dumps(result), flush=True)
         dist.destroy_process_group()
         return
 
@@ -393,10 +510,13 @@ def main():
         Z = Z.to(torch.bfloat16)
 
     table_bytes = 2 * N * K * d * wbytes
+    tinfo = {}
     if want("headline"):
-        blocks, ktime = time_forward(ops, graph, pairs, Z, beta, t, args.steps, args.warmup, args.repeats)
+        blocks, ktime = time_forward(ops, graph, pairs, Z, beta, t, args.steps, args.warmup, args.repeats, info=tinfo)
+        prob_timed = ops.score_pairs_fwd(Z, ops.aggregate_fwd(graph, Z, beta, *ops.route_fwd(graph, Z, t)),
+                                         pairs.pu, pairs.pv, t, pairs).clone()       # the timed step's output, for `parity`
     else:
-        blocks, ktime = [float("nan")], {n: float("nan") for n in NAMES}
+        blocks, ktime, prob_timed = [float("nan")], {n: float("nan") for n in NAMES}, None
     step_s = float(np.median(blocks))
     abytes, mbytes = algorithmic_bytes(K, d, N, E, P, w=wbytes), moved_bytes(graph, pairs, K, d, w=wbytes)
     pmc_key = f"{args.workload}x{args.scale:g}_K{K}_d{d}_{args.dtype}"
@@ -407,31 +527,84 @@ def main():
     kernels["score"]["pairs_per_s"] = P / ktime["score"]                  # P / t_score
     dom = max(NAMES, key=lambda n: ktime[n])
 
-    # extra: forward+backward of the same path (what one training epoch adds on top), not the headline
-    fb_ms = None
+    # extra: forward+backward of the same path (what one training epoch adds on top), not the headline — with its own
+    # per-kernel roofline table (the training kernels are 70 % of an epoch's GPU time)
+    fb_ms, fb_kernels = None, None
     if want("fwd_bwd"):
         gp = torch.full((P,), 1.0 / P, device=device)
         yb_ = (torch.rand(P, device=device) < 0.2).float()
         # the training loop's own choice (model.forward_pairs_loss): fp32 tables take the one-pass scorer
         one_pass_fb = args.dtype == "f32" and ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32)
-        def train_step():
+        def train_step(ev=None):
+            rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
+            rec(0)
             p, a, s = ops.route_fwd(graph, Z, t)
+            rec(1)
             H = ops.aggregate_fwd(graph, Z, beta, p, a, s)
+            rec(2)
             if one_pass_fb:
                 _prob, dZs, dH = ops.score_pairs_train(Z, H, pairs, t, yb_, gp)
             else:
                 prob, coef = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
                 dZs, dH = ops.score_pairs_bwd(Z, H, pairs, t, prob, gp, coef=coef)
-            return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
+            rec(3)
+            if ev is None:
+                return ops.route_aggregate_bwd(graph, Z, beta, t, p, a, s, dH, dZ_accum=dZs)
+            ds = torch.empty((N, K), dtype=torch.float32, device=device)
+            rec(4)
+            dw, dwr = ops.route_aggregate_bwd_phase1(graph, Z, beta, p, a, s, dH, ds)
+            rec(5)
+            ops.route_aggregate_bwd_phase2(graph, Z, beta, t, p, a, s, dH, dw, dwr, ds, dZs, True)
+            rec(6)
         for _ in range(3):
             train_step()
+        def fb_block(nb=max(5, args.steps // 4)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nb):
+                train_step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / nb
+        steady_warmup(fb_block, min_s=0.2)
+        fb_blocks = [fb_block() for _ in range(5)]
+        fb_ms = float(np.median(fb_blocks)) * 1e3
+        n_ev = 20
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(n_ev)]
+        for i in range(n_ev):
+            train_step(evs[i])
         torch.cuda.synchronize()
-        nb = max(5, args.steps // 4)
-        t0 = time.perf_counter()
-        for _ in range(nb):
-            train_step()
-        torch.cuda.synchronize()
-        fb_ms = (time.perf_counter() - t0) / nb * 1e3
+        med = lambda i, j: float(np.median([e[i].elapsed_time(e[j]) for e in evs])) * 1e-3
+        row = K * d * wbytes
+        inc = pairs.inc
+        plan = graph.plan
+        fb_model = {
+            # one pass over the incidence rows: every pair slot (2 per pair) gathers the partner's Z and H rows and the
+            # pair's label / weight; per segment the node's own Z, H rows + descriptors; per node dZ, dH rows out; per pair prob
+            # out; partial slots written and read back (2 rows each)
+            "scorer_one_pass" if one_pass_fb else "scorer_fwd_terms_plus_bwd":
+                (med(2, 3), 2 * P * (2 * row + 4 + 8) + inc.n_seg * (2 * row + 16) + N * 2 * K * d * 4 + P * 4
+                 + inc.n_slots * 2 * K * d * 4 * 2 if one_pass_fb else None,
+                 2 * P * (2 * row + 16) + N * 2 * K * d * 4 if one_pass_fb else None),
+            # phase 1 per edge 2*d*4*2+17, own rows; phase 2 per edge K*d*4 + d*4 + 25, per node 3*K*d*4
+            "bwd_phase1": (med(4, 5), E * (2 * d * 4 * 2 + 17) + N * 2 * K * d * 4 + plan.n_seg * 16,
+                           E * (2 * d * 4 * 2 + 17) + N * 2 * K * d * 4),
+            "bwd_phase2": (med(5, 6), E * (row + d * 4 + 25) + N * 3 * K * d * 4 + plan.n_seg * 16 + plan.n_slots * 2 * K * d * 4,
+                           E * (row + d * 4 + 25) + N * 3 * K * d * 4),
+            "route": (med(0, 1), mbytes["route"], abytes["route"]),
+            "aggregate": (med(1, 2), mbytes["aggregate"], abytes["aggregate"]),
+        }
+        fb_traffic, fb_traffic_src = pmc_traffic(pmc_key + "_train", phases=TRAIN_PHASE_KERNELS)
+        fb_kernels = {}
+        for name, (sec, mv, ab) in fb_model.items():
+            e = {"avg_us": sec * 1e6, "moved_bytes": mv, "algorithmic_bytes": ab}
+            if mv is not None:
+                e.update(achieved_GBs=mv / sec / 1e9, frac=mv / sec / 1e9 / peak, bound=bound)
+            key = "scorer" if name.startswith("scorer") else name
+            if fb_traffic is not None and key in fb_traffic:
+                e.update(traffic=fb_traffic[key], hbm_frac=fb_traffic[key] / sec / 1e9 / HBM_PEAK_GBS)
+            fb_kernels[name] = e
+        fb_kernels["_sum_of_kernels_us"] = sum(v[0] for v in fb_model.values()) * 1e6
+        fb_kernels["_traffic_source"] = fb_traffic_src
 
     # extra: the scorer's training step in its two forms: forward storing terms + two backward passes,
     # and dl_score_pairs_train (forward, loss gradient and backward in one pass; the default for tables that live in HBM)
@@ -545,8 +718,15 @@ def main():
         "metric": "edges/sec (aggregate+score) at K=8 d=64",
         "value": units / step_s,
         "unit": "edges/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
-        "ms_per_step": step_s * 1e3, "ms_per_step_blocks": [b * 1e3 for b in blocks],
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": len(blocks),
+        "ms_per_step": step_s * 1e3,
+        "ms_per_step_min_median_max": [float(np.min(blocks)) * 1e3, step_s * 1e3, float(np.max(blocks)) * 1e3],
+        "ms_per_step_blocks": [round(b * 1e3, 5) for b in (blocks if len(blocks) <= 24 else
+                                                            blocks[:8] + blocks[len(blocks) // 2 - 4:len(blocks) // 2 + 4] + blocks[-8:])],
+        "ms_per_step_blocks_note": "all blocks" if len(blocks) <= 24 else "first 8, middle 8, last 8 of %d blocks" % len(blocks),
+        "timing": {"blocks_of_steps": args.steps, **tinfo,
+                   "note": "warm-up = --warmup steps, then blocks until >= 0.3 s AND three consecutive blocks within 2 %; "
+                           "timed region = R blocks of exactly --steps steps, R >= --repeats and >= 1 s in total"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "real edge rows, synthetic features" if args.workload.endswith("_real") else "synthetic",
         "config": {"workload": f"{args.workload + ' (edge list of the parity fixture)' if args.workload.endswith('_real') else args.workload + '-synthetic'}(seed 0): N={N}, edge rows={sg.src.size}, 85/5/10 split, "
@@ -574,7 +754,8 @@ def main():
              else "or the L2s, and no PMC passes exist for this build and workload") +
             "; this is NOT a fraction of the HBM roofline — the hbm_bound block (tables far beyond every cache) is")
     if fb_ms is not None:
-        result["fwd_bwd"] = {"ms_per_step": fb_ms, "edges_per_s": units / (fb_ms * 1e-3),
+        result["fwd_bwd"] = {"ms_per_step": fb_ms, "ms_per_step_blocks": [b * 1e3 for b in fb_blocks],
+                             "edges_per_s": units / (fb_ms * 1e-3), "kernels": fb_kernels,
                              "scorer": "one pass (dl_score_pairs_train)" if one_pass_fb else
                              "dl_score_pairs_fwd storing terms + dl_score_pairs_bwd"}
     result["scorer_training_step"] = scorer_train
@@ -583,6 +764,7 @@ def main():
     gcpu = graph.to("cpu") if want("cpu") and not args.no_cpu_baseline else None
     Zc = Z.float().cpu() if gcpu is not None else None
     pcpu = (pairs.pu.cpu(), pairs.pv.cpu()) if gcpu is not None else None
+    label_cpu = pairs.bench_label
     if want("hbm_bound"):
         del graph, pairs, Z, model, x
         torch.cuda.empty_cache()
@@ -590,10 +772,12 @@ def main():
                                                 scale=args.hbm_scale)
     if gcpu is not None:
         if N <= 12000:                                          # dense [K,N,N] fits: the reference's own form
-            result["cpu_baseline"] = cpu_baseline(Zc, gcpu, units, beta, t)
+            par_in = (pcpu[0], pcpu[1], label_cpu, prob_timed) if prob_timed is not None else None
+            got = cpu_baseline(Zc, gcpu, units, beta, t, parity=par_in)
+            result["cpu_baseline"], result["parity"] = got if par_in is not None else (got, None)
         else:
             result["cpu_baseline"] = cpu_baseline_sparse(Zc, gcpu, pcpu, units, beta, t)
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

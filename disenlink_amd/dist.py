@@ -123,63 +123,109 @@ class Partition:
 
 
 # --------------------------------------------------------------------------- collectives
+# Three ways to move a node table's blocks between the ranks, all of them writing every received row straight into its
+# final place in the full table (no list all-gather, hence none of ProcessGroupNCCL's flatten-to-a-temporary-and-copy-out):
+#   "allgather" — ONE all_gather_into_tensor (rank q's block IS rows [qB, (q+1)B): the output is the table itself, the
+#                 input the rank's own rows in place — RCCL's in-place form, sendbuff = recvbuff + rank * count);
+#   "p2p"       — the DIRECT fully connected exchange of SURVEY.md §8(e): one grouped batch of W-1 sends and W-1
+#                 receives (one RCCL group call = one kernel driving all seven xGMI links at once), each message one
+#                 contiguous block of rows; the only form that also serves ROW CHUNKS of every block (a chunk of rank q's
+#                 block is contiguous where it lies), which is what lets the scorer run under the H gather;
+#   "broadcast" — W broadcasts, one per owner; `wait(q)` per peer (routing in arrival order).
+# Which of them is fastest on real links is decided by measurement in the run itself (bench_sharded: all three are timed
+# on the Z table before the timed region and the fastest is used; DL_GATHER_MODE forces one).
+GATHER_MODES = ("allgather", "p2p", "broadcast")
+MESSAGES = {"collectives": 0, "p2p_ops": 0, "staging_copies": 0}     # counted per process; bench lines quote them per step
+
+
+def _count(kind: str, n: int = 1) -> None:
+    MESSAGES[kind] += n
+
+
+def reset_message_counts() -> dict:
+    out = dict(MESSAGES)
+    for k in MESSAGES:
+        MESSAGES[k] = 0
+    return out
+
+
 def _gloo_on_device(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"          # one-GPU rehearsal: gloo moves host memory
 
 
+def _global_rank(group, q: int) -> int:
+    return dist.get_global_rank(group, q) if group is not None else q
+
+
 def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None, src: torch.Tensor | None = None) -> None:
-    """Every rank contributes rows [lo, hi) of `full` (equal sizes on all ranks) and receives all rows.  The
-    send buffer never aliases the receive buffer: `src` if the caller still holds the local rows elsewhere,
-    else a copy of full[lo:hi] (a few microseconds against a collective of 8x the bytes)."""
-    local = src if src is not None else full[lo:hi].clone()
+    """Every rank contributes rows [lo, hi) of `full` (equal sizes on all ranks, rank-major) and receives all rows: one
+    all_gather_into_tensor whose output is `full` itself.  `src`: the local rows, if the caller holds them elsewhere
+    (then `full[lo:hi]` need not be filled); otherwise they are taken where they lie — in place over RCCL, through one
+    clone where the backend (gloo) does not promise the in-place form."""
+    _count("collectives")
     if _gloo_on_device(full, group):
+        local = src if src is not None else full[lo:hi]
         host = torch.empty(full.shape, dtype=full.dtype)
         dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
         full.copy_(host)
         return
-    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    if src is None:
+        if dist.get_backend(group) == "gloo":
+            src = full[lo:hi].clone()
+            _count("staging_copies")
+        else:
+            src = full[lo:hi]                                     # in place: sendbuff == recvbuff + rank * count
+    dist.all_gather_into_tensor(full, src.contiguous(), group=group)
 
 
 class ChunkedRowGather:
-    """All-gather of a node table in C row chunks, asynchronously: chunk c = rows [c Bc, (c+1) Bc) of EVERY rank's
-    block.  `start` enqueues all C collectives (each into the views of `full` the chunk belongs to; the own block is
-    already in place and is not rewritten — its slot goes to a scratch buffer); `wait(c)` makes the current stream wait
-    for chunk c only, so kernels that need chunk c run under the transfer of chunks c+1 .."""
+    """All-gather of a node table in C row chunks, asynchronously and DIRECT: chunk c = rows [c Bc, (c+1) Bc) of EVERY
+    rank's block.  `start` enqueues C grouped batches of point-to-point messages — per chunk W-1 sends of this rank's
+    chunk and W-1 receives, each landing contiguously at full[q B + c Bc ...], its final place (the own block is already
+    there) — and `wait(c)` makes the current stream wait for chunk c only, so kernels that need chunk c run under the
+    transfer of chunks c+1 ..  Batches follow each other on the backend's stream: chunk c is complete before c+1
+    starts, all W-1 links busy for each."""
 
     def __init__(self, full: torch.Tensor, part: Partition, rank: int, group=None):
         self.full, self.part, self.rank, self.group = full, part, rank, group
-        self.works, self._keep = [], []
+        self.works, self._host, self._done = [], [], set()
 
     def start(self):
         B, Bc, W = self.part.block, self.part.chunk_rows, self.part.world
-        full = self.full
+        full, me = self.full, self.rank
         host_path = _gloo_on_device(full, self.group)
+        peers = [(me + k) % W for k in range(1, W)]                # every rank starts with its right-hand neighbour
         for c in range(self.part.n_chunks):
-            send = full[self.rank * B + c * Bc: self.rank * B + (c + 1) * Bc].clone()
-            if host_path:
-                outs = [torch.empty(send.shape, dtype=send.dtype) for _ in range(W)]
-                work = dist.all_gather(outs, send.cpu(), group=self.group, async_op=True)
-                self._keep.append((send, outs))
-            else:
-                scratch = torch.empty_like(send)
-                outs = [scratch if q == self.rank else full[q * B + c * Bc: q * B + (c + 1) * Bc] for q in range(W)]
-                work = dist.all_gather(outs, send, group=self.group, async_op=True)
-                self._keep.append((send, scratch))
-            self.works.append(work)
+            rows = lambda q: slice(q * B + c * Bc, q * B + (c + 1) * Bc)
+            if W == 1:
+                self.works.append([])
+                continue
+            send = full[rows(me)].cpu() if host_path else full[rows(me)]
+            recv = {q: (torch.empty(send.shape, dtype=send.dtype) if host_path else full[rows(q)]) for q in peers}
+            ops = []
+            for q in peers:
+                ops.append(dist.P2POp(dist.isend, send, _global_rank(self.group, q), self.group, tag=c))
+                ops.append(dist.P2POp(dist.irecv, recv[q], _global_rank(self.group, q), self.group, tag=c))
+            _count("p2p_ops", len(ops))
+            self.works.append(dist.batch_isend_irecv(ops))
+            self._host.append((send, recv) if host_path else None)
         return self
 
     def wait(self, c: int):
-        self.works[c].wait()
-        if _gloo_on_device(self.full, self.group):
+        if c in self._done:
+            return
+        self._done.add(c)
+        for w in self.works[c]:
+            w.wait()
+        if self._host and self._host[c] is not None:
             B, Bc = self.part.block, self.part.chunk_rows
-            for q, o in enumerate(self._keep[c][1]):
-                if q != self.rank:
-                    self.full[q * B + c * Bc: q * B + (c + 1) * Bc].copy_(o)
+            for q, o in self._host[c][1].items():
+                self.full[q * B + c * Bc: q * B + (c + 1) * Bc].copy_(o)
 
     def wait_all(self):
         for c in range(len(self.works)):
             self.wait(c)
-        self._keep.clear()
+        self._host.clear()
 
 
 class PeerRowGather:
@@ -189,14 +235,15 @@ class PeerRowGather:
 
     def __init__(self, full: torch.Tensor, part: Partition, rank: int, group=None):
         self.full, self.part, self.rank, self.group = full, part, rank, group
-        self.works, self._host = [], []
+        self.works, self._host, self._done = [], [], set()
 
     def start(self):
         B, W = self.part.block, self.part.world
         host_path = _gloo_on_device(self.full, self.group)
         for q in range(W):
-            src = dist.get_global_rank(self.group, q) if self.group is not None else q
+            src = _global_rank(self.group, q)
             blk = self.full[q * B:(q + 1) * B]
+            _count("collectives")
             if host_path:
                 h = blk.cpu() if q == self.rank else torch.empty(blk.shape, dtype=blk.dtype)
                 self._host.append(h)
@@ -206,6 +253,9 @@ class PeerRowGather:
         return self
 
     def wait(self, q: int):
+        if q in self._done:                                       # (a block already copied is not copied again)
+            return
+        self._done.add(q)
         self.works[q].wait()
         if self._host and q != self.rank:
             B = self.part.block
@@ -215,6 +265,32 @@ class PeerRowGather:
         for q in range(len(self.works)):
             self.wait(q)
         self._host.clear()
+
+
+def gather_table(full: torch.Tensor, part: Partition, rank: int, mode: str = "allgather", group=None,
+                 src: torch.Tensor | None = None) -> None:
+    """Blocking all-gather of a whole node table in one of GATHER_MODES (the own block must be in `full` for "p2p" and
+    "broadcast"; `src` may stand in for it with "allgather")."""
+    B = part.block
+    if mode == "allgather" or part.world == 1:
+        all_gather_rows(full, rank * B, (rank + 1) * B, group, src=src)
+        return
+    if src is not None:
+        full[rank * B:(rank + 1) * B] = src
+    if mode == "p2p":
+        one = Partition(part.world, part.n_nodes, part.cuts, part.block, 1)       # the whole block as one chunk
+        ChunkedRowGather(full, one, rank, group).start().wait_all()
+    elif mode == "broadcast":
+        PeerRowGather(full, part, rank, group).start().wait_all()
+    else:
+        raise ValueError(f"gather mode must be one of {GATHER_MODES}")
+
+
+def default_gather_mode() -> str:
+    mode = os.environ.get("DL_GATHER_MODE", "allgather")
+    if mode not in GATHER_MODES:
+        raise ValueError(f"DL_GATHER_MODE must be one of {GATHER_MODES}")
+    return mode
 
 
 def route_in_arrival_order(backend, shard: "Shard", Z, t, s, gather):
@@ -246,6 +322,13 @@ class HipBackend:
 
     def route_fwd(self, g, Z, t, s_out, p_out=None, a_out=None):
         return self.ops.route_fwd(g, Z, t, s_out=s_out, p_out=p_out, a_out=a_out)[:2]
+
+    def honours_partial_route_plans(self, K, d, table_dtype) -> bool:
+        """Whether dl_route_fwd walks only the entries of the graph's ROUTING plan (the tuned kernels do; the generic
+        path — dl_set_force_generic or a (K, d) without a tuned instantiation — routes every entry whatever the plan
+        says, so per-peer passes under an asynchronous gather would read blocks that have not arrived)."""
+        dt = self.ops._lib.DL_F32 if table_dtype == torch.float32 else self.ops._lib.DL_BF16
+        return self.ops.score_terms_available(K, d, dt)
 
     def aggregate_fwd(self, g, Z, beta, p, a, s, H_out):
         self.ops.aggregate_fwd(g, Z, beta, p, a, s, H_out=H_out)
@@ -424,11 +507,12 @@ def _gather_and_route(sh: "Shard", backend, Z_loc, t, group, table_dtype):
     dev = Z_loc.device
     Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
     s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
-    if sh.route_by_peer:
+    by_peer = bool(sh.route_by_peer) and backend.honours_partial_route_plans(K, d, table_dtype)
+    if by_peer:
         Z[sh.lo:sh.hi] = Z_loc.detach().to(table_dtype)
         p, a = route_in_arrival_order(backend, sh, Z, t, s, PeerRowGather(Z, sh.part, sh.rank, group).start())
-    else:
-        all_gather_rows(Z, sh.lo, sh.hi, group, src=Z_loc.detach().to(table_dtype))
+    else:                                                      # one blocking gather, one routing pass over every entry
+        gather_table(Z, sh.part, sh.rank, default_gather_mode(), group, src=Z_loc.detach().to(table_dtype))
         p, a = backend.route_fwd(sh.graph, Z, t, s)
     return Z, s, p, a
 
@@ -576,306 +660,3 @@ def allreduce_gradients(model, group=None) -> None:
         if prm.grad is None:
             prm.grad = torch.zeros_like(prm)
         dist.all_reduce(prm.grad, op=dist.ReduceOp.SUM, group=group)
-
-
-# --------------------------------------------------------------------------- bench (bench.py --gpus N)
-@dataclass
-class BenchProblem:
-    """What every rank needs of the benchmark graph: the train edge rows, the scored pairs sorted by (u, v) and the
-    generator of the feature rows (any rank can produce exactly its own rows, data.SyntheticGraph.features)."""
-    sg: object                 # SyntheticGraph (its src / dst are empty on the ranks that received the problem)
-    edge_rows: int
-    train_src: np.ndarray
-    train_dst: np.ndarray
-    pu: np.ndarray
-    pv: np.ndarray
-    scale: float
-    prep_s: float = 0.0
-
-
-def _build_problem(args, scale: float, device) -> BenchProblem:
-    from .data import synthetic_graph
-    from .splits import make_link_split
-    sg = synthetic_graph(args.workload, seed=0, scale=scale)
-    # the sorts and searches of the split run on the GPU when there is one (same split bit for bit, splits.py):
-    # snap-patents full size 104 s -> seconds
-    dev = device if (device is not None and torch.device(device).type == "cuda") else None
-    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0, device=dev)
-    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
-    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
-    if dev is not None:
-        order = torch.argsort(torch.as_tensor(pu * sg.n_nodes + pv, device=dev), stable=True).cpu().numpy()
-    else:
-        order = np.lexsort((pv, pu))
-    return BenchProblem(sg, int(sg.src.size), split.train_src, split.train_dst, pu[order], pv[order], scale)
-
-
-def _bench_problem(args, world_for_scale: int, rank: int = 0, world: int = 1, device=None) -> BenchProblem:
-    """The benchmark problem, built ONCE: rank 0 generates the graph, the split and the sorted pair list and writes the
-    four index arrays to /dev/shm; the other ranks read them (round 2: every rank repeated the whole host preparation —
-    104 s for snap-patents, times N ranks on one host).  Feature rows are generated per rank, for its own rows only."""
-    from .data import SyntheticGraph
-    scale = args.scale * (world_for_scale if args.scaling == "weak" else 1)
-    t0 = time.perf_counter()
-    shm = os.environ.get("DL_SHARE_DIR", "/dev/shm")
-    if world == 1 or not dist.is_initialized() or not os.path.isdir(shm):
-        prob = _build_problem(args, scale, device)
-        prob.prep_s = time.perf_counter() - t0
-        return prob
-    token = [f"dl_bench_{os.getpid()}_{time.time_ns()}" if rank == 0 else None]
-    dist.broadcast_object_list(token, src=0)
-    base = os.path.join(shm, token[0])
-    names = ("train_src", "train_dst", "pu", "pv")
-    meta = [None]
-    if rank == 0:
-        prob = _build_problem(args, scale, device)
-        for n in names:
-            np.save(f"{base}_{n}.npy", getattr(prob, n))
-        meta = [dict(name=prob.sg.name, n_nodes=prob.sg.n_nodes, n_feat=prob.sg.n_feat, seed=prob.sg.seed,
-                     edge_rows=prob.edge_rows)]
-    dist.broadcast_object_list(meta, src=0)                       # also the "files are complete" signal
-    if rank != 0:
-        m = meta[0]
-        empty = np.zeros(0, dtype=np.int64)
-        sg = SyntheticGraph(m["name"], m["n_nodes"], empty, empty, m["n_feat"], m["seed"])
-        arrs = {n: np.load(f"{base}_{n}.npy") for n in names}
-        prob = BenchProblem(sg, m["edge_rows"], arrs["train_src"], arrs["train_dst"], arrs["pu"], arrs["pv"], scale)
-    try:
-        dist.barrier()                                            # everyone has read: rank 0 removes the files
-    finally:
-        if rank == 0:
-            for n in names:
-                try:
-                    os.remove(f"{base}_{n}.npy")
-                except OSError:
-                    pass
-    prob.prep_s = time.perf_counter() - t0
-    return prob
-
-
-def bench_sharded(args, rank: int, world: int, device) -> dict:
-    """One step = all-gather Z, route, all-gather s, aggregate, all-gather H (chunked, asynchronous), score the local pairs
-    under it; value = (E_sym + P over all ranks) / max-over-ranks time.  --scaling weak: the graph grows with the GPU
-    count (scale x world, same degree law); strong: the same graph on every GPU count.  --dtype bf16: the gathered Z / H
-    tables — and the bytes of their all-gathers — are bf16, arithmetic fp32."""
-    from . import _lib
-    from .model import Disentangle
-    lib = _lib.load()
-    K, d, beta, t = args.K, args.d, 0.5, 1.0
-    # DL_EMULATE_WORLD=8 on one GPU: build rank 0's shard of the 8-GPU problem and time its compute alone
-    # (the collectives degenerate to no-ops) — a rehearsal of the per-rank work, not a scaling number.
-    emu = int(os.environ.get("DL_EMULATE_WORLD", "0"))
-    if emu > 1 and world == 1:
-        return _bench_emulated(args, emu, device)
-    tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    wb = 2 if args.dtype == "bf16" else 4
-    t_prep = time.perf_counter()
-    prob = _bench_problem(args, world, rank, world, device)
-    sg, pu, pv, scale = prob.sg, prob.pu, prob.pv, prob.scale
-    shard = Shard.build(rank, world, sg.n_nodes, prob.train_src, prob.train_dst, pu, pv, device, row_bytes=K * d * wb,
-                        n_chunks=DEFAULT_CHUNKS, with_backward=False)
-    torch.manual_seed(0)
-    model = Disentangle(sg.n_feat, args.nhidden, d, nfactor=K, beta=beta, t=1).to(device)
-    r0, r1 = shard.local_real_rows()
-    x_loc = torch.from_numpy(sg.features(rows=(r0, r1))).to(device)      # this rank's rows only
-    torch.cuda.synchronize()
-    dist.barrier()
-    prep_s = time.perf_counter() - t_prep                                 # launch -> every rank ready for its first collective
-    backend = HipBackend()
-    with torch.no_grad():
-        Z_loc = model.project(shard.pad_rows(x_loc)).contiguous().to(tab)
-
-    Z = torch.empty((shard.n_pad, K, d), dtype=tab, device=device)
-    s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
-    H = torch.empty_like(Z)
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-
-    def step(timers=None):
-        e = [ev() for _ in range(8)] if timers is not None else None
-        rec = (lambda i: e[i].record()) if e else (lambda i: None)
-        rec(0)
-        if shard.route_by_peer:                                 # Z peer block by peer block, routing in arrival order
-            Z[shard.lo:shard.hi] = Z_loc
-            gz = PeerRowGather(Z, shard.part, shard.rank).start()
-            rec(1)
-            p, a = route_in_arrival_order(backend, shard, Z, t, s, gz)
-        else:
-            all_gather_rows(Z, shard.lo, shard.hi, src=Z_loc)
-            rec(1)
-            p, a = backend.route_fwd(shard.graph, Z, t, s)
-        rec(2)
-        all_gather_rows(s, shard.lo, shard.hi)
-        rec(3)
-        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
-        rec(4)
-        gather = ChunkedRowGather(H, shard.part, shard.rank).start() if shard.pair_groups else None
-        if gather is None:
-            all_gather_rows(H, shard.lo, shard.hi)
-        rec(5)
-        prob = score_local_pairs(backend, shard, Z, H, t, gather) if gather is not None else \
-            backend.score_pairs_fwd(Z, H, shard.pairs, t)
-        rec(6)
-        if timers is not None:
-            timers.append(e)
-        return prob
-
-    for _ in range(args.warmup):
-        step()
-    blocks = []
-    for _ in range(max(1, args.repeats)):
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        dist.barrier()
-        blocks.append(time.perf_counter() - t0)
-    red_dev = "cpu" if dist.get_backend() == "gloo" else device
-    wall = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)                          # per block: the slowest rank
-    wall_s = float(wall.median())
-    counts = torch.tensor([shard.graph.n_edges, shard.pairs.n_pairs], dtype=torch.int64, device=red_dev)
-    per_rank = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(per_rank, counts)
-    E, P = int(sum(int(c[0]) for c in per_rank)), int(sum(int(c[1]) for c in per_rank))
-    # where a step goes on THIS rank: HIP events on the launch stream around every collective and every kernel phase
-    # (the scoring phase runs under the chunked H gather: "score" is the span from the first scoring launch to the last
-    # chunk's arrival, "h_gather_exposed" what the gather adds before it)
-    timers = []
-    for _ in range(min(args.steps, 10)):
-        step(timers)
-    torch.cuda.synchronize()
-    span = lambda i, j: float(np.median([e[i].elapsed_time(e[j]) for e in timers]))
-    phases = dict(z_gather_ms=span(0, 1), route_ms=span(1, 2), s_gather_ms=span(2, 3), aggregate_ms=span(3, 4),
-                  h_gather_start_ms=span(4, 5), score_and_h_gather_ms=span(5, 6))
-    comm_ms = phases["z_gather_ms"] + phases["s_gather_ms"] + phases["h_gather_start_ms"]
-    # kernels alone (no collectives), for the roofline entry and the compute / exposed-communication split
-    reps = max(5, min(args.steps, 20))
-    kev = [[ev() for _ in range(4)] for _ in range(reps)]
-    for i in range(reps):
-        kev[i][0].record()
-        p, a = backend.route_fwd(shard.graph, Z, t, s)
-        kev[i][1].record()
-        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
-        kev[i][2].record()
-        backend.score_pairs_fwd(Z, H, shard.pairs, t)
-        kev[i][3].record()
-    torch.cuda.synchronize()
-    kt = [float(np.median([kev[i][j].elapsed_time(kev[i][j + 1]) for i in range(reps)])) * 1e-3 for j in range(3)]
-    compute_ms = sum(kt) * 1e3
-    step_ms = wall_s / args.steps * 1e3
-    mine = torch.tensor([compute_ms, step_ms - compute_ms, comm_ms, phases["score_and_h_gather_ms"], kt[2] * 1e3],
-                        dtype=torch.float64, device=red_dev)
-    allr = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allr, mine)
-    import bench as _bench
-    mb = _bench.moved_bytes(shard.graph, shard.pairs, K, d, w=wb)
-    j = int(np.argmax(kt))
-    name = ("route", "aggregate", "score")[j]
-    table_bytes = 2 * shard.n_pad * K * d * wb
-    bound, peak, bound_how = _bench.memory_bound(table_bytes, mb, None)     # no PMC passes exist for sharded runs
-    roofline = {"bound": bound, "bound_decided_by": bound_how, "kernel": name, "achieved": mb[name] / kt[j] / 1e9,
-                "peak": peak, "unit": "GB/s", "frac": mb[name] / kt[j] / 1e9 / peak, "traffic": None,
-                "moved_bytes": mb[name], "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
-    if bound == "hbm" and roofline["frac"] > _bench.HBM_ACHIEVABLE_FRAC:
-        roofline["frac_unverified"] = "above what HBM can deliver and not backed by counters: part of the bytes are cache hits"
-    nnz = np.array([int(c[0]) for c in per_rank], dtype=np.float64)
-    gather_bytes = (world - 1) * shard.part.block * (2 * K * d * wb + K * 4)       # received per rank and step
-    dist.barrier()
-    return {
-        "metric": "edges/sec (aggregate+score) at K=8 d=64",
-        "value": (E + P) * args.steps / wall_s, "unit": "edges/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": len(blocks),
-        "ms_per_step": step_ms, "ms_per_step_blocks": [float(b) / args.steps * 1e3 for b in wall.tolist()],
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "roofline": roofline,
-        "per_rank": [dict(rank=r, nnz=int(per_rank[r][0]), pairs=int(per_rank[r][1]), compute_ms=float(allr[r][0]),
-                          exposed_comm_ms=float(allr[r][1]), blocking_gathers_ms=float(allr[r][2]),
-                          score_under_h_gather_ms=float(allr[r][3]), score_alone_ms=float(allr[r][4]))
-                     for r in range(world)],
-        "phases_rank0_ms": phases,
-        "z_gather": ("by peer block, routing in arrival order (route_ms spans the gather)" if shard.route_by_peer
-                     else "one blocking all-gather before the routing"),
-        "partition": {"balance": "nnz", "block_rows": shard.part.block, "padded_nodes": shard.n_pad,
-                      "nnz_max_over_mean": float(nnz.max() / max(nnz.mean(), 1.0)), "h_gather_chunks": shard.part.n_chunks,
-                      "allgather_bytes_received_per_rank_per_step": int(gather_bytes)},
-        "prep_s": {"problem_built_once_and_shared": prob.prep_s, "until_first_collective": prep_s},
-        "config": {"workload": f"{args.workload}-synthetic x{scale:g} (seed 0): N={sg.n_nodes}, edge rows={prob.edge_rows}, "
-                               f"85/5/10 split, E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, {args.dtype} tables; "
-                               f"row-sharded over {world} GPUs by work (nnz), all-gather of Z, s and H over RCCL each step, "
-                               f"the H gather in {shard.part.n_chunks} chunks under the scorer; forward route+aggregate+score",
-                   "K": K, "d": d, "n_nodes": sg.n_nodes, "E_sym": E, "P": P,
-                   "parallelism": f"row-shard x{world}", "fast_path": bool(lib.dl_has_fast_path_dtype(K, d, 1 if wb == 2 else 0))},
-    }
-
-
-def _bench_emulated(args, emu_world: int, device) -> dict:
-    """Rank 0's shard of the `emu_world`-GPU problem on ONE GPU, compute only: per-phase kernel times, the partition's
-    balance, and how much of the scoring can start before the H all-gather has delivered anything (pairs whose second
-    endpoint is local) or has delivered chunk c."""
-    K, d, beta, t = args.K, args.d, 0.5, 1.0
-    tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    wb = 2 if args.dtype == "bf16" else 4
-    t_prep = time.perf_counter()
-    prob = _bench_problem(args, emu_world, 0, 1, device)
-    sg, pu, pv, scale = prob.sg, prob.pu, prob.pv, prob.scale
-    train_src, train_dst = prob.train_src, prob.train_dst
-    shard = Shard.build(0, emu_world, sg.n_nodes, train_src, train_dst, pu, pv, device,
-                        row_bytes=K * d * wb, n_chunks=DEFAULT_CHUNKS, with_backward=False)
-    torch.cuda.synchronize()
-    prep_s = time.perf_counter() - t_prep
-    backend = HipBackend()
-    Z = (torch.randn((shard.n_pad, K, d), device=device) * 0.24).to(tab)
-    s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
-    H = torch.empty_like(Z)
-    ng = len(shard.pair_groups)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 + ng)]
-    acc = np.zeros(3 + ng)
-    for it in range(args.warmup + args.steps):
-        ev[0].record()
-        p, a = backend.route_fwd(shard.graph, Z, t, s)
-        ev[1].record()
-        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
-        ev[2].record()
-        backend.score_pairs_fwd(Z, H, shard.pairs, t)
-        ev[3].record()
-        for gi, (_idx, sub) in enumerate(shard.pair_groups):
-            if sub is not None:
-                backend.score_pairs_fwd(Z, H, sub, t)
-            ev[4 + gi].record()
-        torch.cuda.synchronize()
-        if it >= args.warmup:
-            acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3 + ng)]
-    acc /= args.steps
-    # the routing cut by peer block (Shard.route_by_peer): its kernels alone, every block already present
-    by_peer = None
-    if shard.route_by_peer:
-        class _Arrived:
-            def wait(self, q): pass
-            def wait_all(self): pass
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for it in range(args.warmup + 1):
-            e0.record()
-            for _ in range(args.steps):
-                route_in_arrival_order(backend, shard, Z, t, s, _Arrived())
-            e1.record()
-            torch.cuda.synchronize()
-        peers = [g for g in shard.route_by_peer if g is not None]
-        by_peer = {"route_us": e0.elapsed_time(e1) * 1e3 / args.steps, "passes": len(peers)}
-    w = np.bincount(train_src, minlength=sg.n_nodes) + np.bincount(train_dst, minlength=sg.n_nodes) + 1
-    cuts = shard.part.cuts
-    share = np.array([w[cuts[r]:cuts[r + 1]].sum() for r in range(emu_world)], dtype=np.float64)
-    groups = [dict(group="second endpoint local" if gi == 0 else f"chunk {gi - 1} of the H gather",
-                   pairs=int(idx.numel()), score_us=float(acc[3 + gi] * 1e3)) for gi, (idx, _s) in enumerate(shard.pair_groups)]
-    return {"emulated_world": emu_world, "scaling": args.scaling, "dtype": args.dtype, "workload": args.workload,
-            "prep_s": {"problem": prob.prep_s, "problem_and_rank0_shard": prep_s,
-                       "note": "graph + split + sorted pair list (sorts / searches on the GPU), then rank 0's shard plans"},
-            "rank0_edges": shard.graph.n_edges, "rank0_pairs": shard.pairs.n_pairs,
-            "n_nodes": sg.n_nodes, "block_rows": shard.part.block, "table_MB": shard.n_pad * K * d * wb / 1e6,
-            "work_share_max_over_mean": float(share.max() / share.mean()),
-            "route_us": acc[0] * 1e3, "aggregate_us": acc[1] * 1e3, "score_us": acc[2] * 1e3,
-            "route_by_peer": by_peer,
-            "score_in_gather_order": groups,
-            "scored_before_any_chunk_lands": (groups[0]["pairs"] / max(1, shard.pairs.n_pairs)) if groups else 0.0,
-            "allgather_bytes_per_rank_per_step": (emu_world - 1) * shard.part.block * (2 * K * d * wb + K * 4)}

@@ -1,0 +1,514 @@
+"""``bench.py --gpus N`` for N > 1: the row-sharded forward step (disenlink_amd/dist.py) timed over RCCL, one rank per GPU.
+
+The reference is single-device (main_disentangled.py:52); BASELINE.json asks for "edges/sec reported at 1, 2, 4 and 8
+GPUs" on its two multi-GPU configurations.  One launch runs up to three BLOCKS and prints one JSON line:
+
+  * ``snap_patents``  K=8  d=64  fp32, STRONG scaling — configs[3]; the line's top-level ``value`` / ``ms_per_step``;
+  * ``penn94``        K=16 d=128 bf16, STRONG scaling — configs[4];
+  * ``squirrel``      K=8  d=64  fp32, WEAK scaling (the graph grows with the GPU count) — the headline shape.
+
+Every block carries ``n1_same_problem_ms``: the SAME problem (the same relabelled graph, the same gathered ``Z``) run
+unsharded on rank 0's GPU in the same process, seconds before the sharded timing — so the scaling efficiency of a line
+follows from that line alone — and ``parity``: the sharded probabilities of rank 0's pair slice against that unsharded
+run (the plans are shard-independent by construction: the difference is expected to be exactly 0).
+
+How the tables travel is decided by MEASUREMENT inside the run (ring or direct?): before the timed
+region the ``Z`` gather is timed as one all_gather_into_tensor, as one grouped batch of direct point-to-point messages and
+as W broadcasts, and the ``H`` phase as "blocking gather + one scoring launch" against "row chunks pushed directly, the
+scorer running under the chunks behind it"; the fastest of each is used for the timed steps and all timings are in the
+line (``gather_ab``), with the number of collectives / point-to-point operations / staging copies per step.
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import dist as dd
+from .graph import Graph, PairList
+
+DEFAULT_BLOCKS = (
+    dict(name="snap_patents_strong", workload="snap_patents", scaling="strong", K=8, d=64, dtype="f32",
+         config="configs[3]: snap_patents, K=8, d=64, edge-sharded with RCCL all-gather"),
+    dict(name="penn94_bf16_strong", workload="penn94", scaling="strong", K=16, d=128, dtype="bf16",
+         config="configs[4]: facebook100 (Penn94), K=16, d=128, bf16, scaling curve 1/2/4/8"),
+    dict(name="squirrel_weak", workload="squirrel", scaling="weak", K=8, d=64, dtype="f32",
+         config="configs[2]'s shape grown with the GPU count (weak scaling)"),
+)
+
+
+# --------------------------------------------------------------------------- the problem, built once
+@dataclass
+class BenchProblem:
+    """What every rank needs of the benchmark graph: the train edge rows, the scored pairs sorted by (u, v) and the
+    generator of the feature rows (any rank can produce exactly its own rows, data.SyntheticGraph.features)."""
+    sg: object                 # SyntheticGraph (its src / dst are empty on the ranks that received the problem)
+    edge_rows: int
+    train_src: np.ndarray
+    train_dst: np.ndarray
+    pu: np.ndarray
+    pv: np.ndarray
+    scale: float
+    prep_s: float = 0.0
+
+
+def build_problem(workload: str, scale: float, device) -> BenchProblem:
+    from .data import synthetic_graph
+    from .splits import make_link_split
+    sg = synthetic_graph(workload, seed=0, scale=scale)
+    # the sorts and searches of the split run on the GPU when there is one (same split bit for bit, splits.py):
+    # snap-patents full size 104 s -> seconds
+    dev = device if (device is not None and torch.device(device).type == "cuda") else None
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0, device=dev)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    if dev is not None:
+        order = torch.argsort(torch.as_tensor(pu * sg.n_nodes + pv, device=dev), stable=True).cpu().numpy()
+    else:
+        order = np.lexsort((pv, pu))
+    return BenchProblem(sg, int(sg.src.size), split.train_src, split.train_dst, pu[order], pv[order], scale)
+
+
+def shared_problem(workload: str, scale: float, rank: int, world: int, device, ctrl=None) -> BenchProblem:
+    """The benchmark problem, built ONCE per node: rank 0 generates the graph, the split and the sorted pair list and
+    writes the four index arrays to /dev/shm; the other ranks read them (every rank repeating the host preparation was
+    104 s for snap-patents, times N ranks on one host).  A failure on rank 0 is broadcast and raised everywhere instead of
+    leaving the others in a collective; a rank that cannot see rank 0's files (another host: /dev/shm is per node)
+    builds the problem itself — it is a pure function of (workload, scale, seed)."""
+    from .data import SyntheticGraph
+    t0 = time.perf_counter()
+    shm = os.environ.get("DL_SHARE_DIR", "/dev/shm")
+    if world == 1 or not dist.is_initialized() or not os.path.isdir(shm):
+        prob = build_problem(workload, scale, device)
+        prob.prep_s = time.perf_counter() - t0
+        return prob
+    names = ("train_src", "train_dst", "pu", "pv")
+    msg = [None]
+    prob = None
+    if rank == 0:
+        base = os.path.join(shm, f"dl_bench_{os.getpid()}_{time.time_ns()}")
+        try:
+            prob = build_problem(workload, scale, device)
+            for n in names:
+                np.save(f"{base}_{n}.npy", getattr(prob, n))
+            msg = [dict(ok=True, base=base, name=prob.sg.name, n_nodes=prob.sg.n_nodes, n_feat=prob.sg.n_feat,
+                        seed=prob.sg.seed, edge_rows=prob.edge_rows)]
+        except Exception as e:                                      # noqa: BLE001 — told to everyone, then raised
+            msg = [dict(ok=False, error=f"{type(e).__name__}: {e}")]
+    dist.broadcast_object_list(msg, src=0, group=ctrl)            # also the "files are complete" signal
+    m = msg[0]
+    if not m["ok"]:
+        raise RuntimeError(f"rank 0 could not build the benchmark problem: {m['error']}")
+    try:
+        if rank != 0:
+            files = [f"{m['base']}_{n}.npy" for n in names]
+            if all(os.path.exists(f) for f in files):
+                empty = np.zeros(0, dtype=np.int64)
+                sg = SyntheticGraph(m["name"], m["n_nodes"], empty, empty, m["n_feat"], m["seed"])
+                arrs = [np.load(f) for f in files]
+                prob = BenchProblem(sg, m["edge_rows"], *arrs, scale)
+            else:                                                   # not on rank 0's host
+                prob = build_problem(workload, scale, device)
+    finally:
+        dist.barrier(group=ctrl)                                    # everyone has read: rank 0 removes the files
+        if rank == 0:
+            for n in names:
+                try:
+                    os.remove(f"{m['base']}_{n}.npy")
+                except OSError:
+                    pass
+    prob.prep_s = time.perf_counter() - t0
+    return prob
+
+
+# --------------------------------------------------------------------------- one block
+def _median_max_over_ranks(times, red_dev, group=None) -> float:
+    v = torch.tensor([float(np.median(times))], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    return float(v)
+
+
+def _timed(fn, reps, red_dev):
+    """median over `reps` of one call of fn bracketed by synchronise + barrier on both sides -> seconds, max over ranks"""
+    fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return _median_max_over_ranks(ts, red_dev)
+
+
+def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
+    """One (workload, scaling, K, d, dtype) block.  One step = all-gather Z, route, all-gather s, aggregate, all-gather H,
+    score the local pairs; value = (E_sym + P over all ranks) / max-over-ranks time."""
+    import bench as _bench
+    from . import _lib
+    from .model import Disentangle
+    lib = _lib.load()
+    K, d, beta, t = spec["K"], spec["d"], 0.5, 1.0
+    tab = torch.bfloat16 if spec["dtype"] == "bf16" else torch.float32
+    wb = 2 if spec["dtype"] == "bf16" else 4
+    base_scale = args.scale
+    scale = base_scale * (world if spec["scaling"] == "weak" else 1)
+    red_dev = "cpu" if dist.get_backend() == "gloo" else device
+    t_prep = time.perf_counter()
+    prob = shared_problem(spec["workload"], scale, rank, world, device, ctrl)
+    sg, pu, pv = prob.sg, prob.pu, prob.pv
+    shard = dd.Shard.build(rank, world, sg.n_nodes, prob.train_src, prob.train_dst, pu, pv, device, row_bytes=K * d * wb,
+                           n_chunks=dd.DEFAULT_CHUNKS, with_backward=False)
+    torch.manual_seed(0)
+    model = Disentangle(sg.n_feat, args.nhidden, d, nfactor=K, beta=beta, t=1).to(device)
+    r0, r1 = shard.local_real_rows()
+    x_loc = torch.from_numpy(sg.features(rows=(r0, r1))).to(device)      # this rank's rows only
+    torch.cuda.synchronize()
+    dist.barrier(group=ctrl)
+    prep_s = time.perf_counter() - t_prep                                 # launch -> every rank ready for its first collective
+    backend = dd.HipBackend()
+    with torch.no_grad():
+        Z_loc = model.project(shard.pad_rows(x_loc)).contiguous().to(tab)
+    del x_loc, model
+
+    Z = torch.empty((shard.n_pad, K, d), dtype=tab, device=device)
+    s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
+    H = torch.empty_like(Z)
+    part, B = shard.part, shard.part.block
+
+    # ---- the N = 1 reference: the SAME problem (padded ids, the gathered Z) unsharded on rank 0's GPU --------------
+    dd.gather_table(Z, part, rank, "allgather", src=Z_loc)
+    torch.cuda.synchronize()
+    n1 = None
+    if spec["scaling"] == "strong":
+        if rank == 0:
+            g1 = Graph.from_edge_rows(torch.as_tensor(part.to_padded(prob.train_src), device=device),
+                                      torch.as_tensor(part.to_padded(prob.train_dst), device=device), shard.n_pad,
+                                      row_bytes=K * d * wb)
+            p1 = PairList.build(torch.as_tensor(part.to_padded(pu), device=device),
+                                torch.as_tensor(part.to_padded(pv), device=device), shard.n_pad, row_range=(0, 0),
+                                row_bytes=K * d * wb)
+            blocks1, kt1 = _bench.time_forward(backend.ops, g1, p1, Z, beta, t, args.steps, args.warmup, 3, min_region_s=0.5)
+            prob1 = backend.ops.score_pairs_fwd(
+                Z, backend.ops.aggregate_fwd(g1, Z, beta, *backend.ops.route_fwd(g1, Z, t)), p1.pu, p1.pv, t, p1)
+            n1 = dict(ms=float(np.median(blocks1)) * 1e3, kernels_us={k: v * 1e6 for k, v in kt1.items()},
+                      E=g1.n_edges, P=p1.n_pairs, prob=prob1[shard.pair_lo:shard.pair_hi].clone())
+            del g1, p1, prob1
+            torch.cuda.empty_cache()
+    else:                                           # weak: the per-GPU problem is the graph at the base scale
+        if rank == 0:
+            _sg, _split, g1, p1, _model, _x, Z1 = _bench.build_workload(spec["workload"], device, K, d, args.nhidden,
+                                                                       scale=base_scale, elem_bytes=wb)
+            Z1 = Z1.to(tab)
+            blocks1, kt1 = _bench.time_forward(backend.ops, g1, p1, Z1, beta, t, args.steps, args.warmup, 3, min_region_s=0.5)
+            n1 = dict(ms=float(np.median(blocks1)) * 1e3, kernels_us={k: v * 1e6 for k, v in kt1.items()},
+                      E=g1.n_edges, P=p1.n_pairs, prob=None)
+            del g1, p1, Z1, _model, _x
+            torch.cuda.empty_cache()
+    dist.barrier(group=ctrl)                        # the others wait on the host (gloo), not in a spinning RCCL kernel
+
+    # ---- how the tables travel: measured here, on this node's links ------------------------------------------------
+    forced = os.environ.get("DL_GATHER_MODE")
+    reps = 3 if world > 1 else 1
+    z_ab = {}
+    for mode in dd.GATHER_MODES:
+        if forced and mode != forced:
+            continue
+        def z_gather(mode=mode):
+            dd.gather_table(Z, part, rank, mode, src=Z_loc)
+        z_ab[mode] = _timed(z_gather, reps, red_dev) * 1e3
+    z_mode = min(z_ab, key=z_ab.get)
+    p, a = backend.route_fwd(shard.graph, Z, t, s)
+    dd.all_gather_rows(s, shard.lo, shard.hi)
+    backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+
+    def h_blocking():
+        dd.gather_table(H, part, rank, z_mode)
+        return backend.score_pairs_fwd(Z, H, shard.pairs, t)
+
+    def h_chunked():
+        return dd.score_local_pairs(backend, shard, Z, H, t, dd.ChunkedRowGather(H, part, rank).start())
+
+    h_forms = {"blocking": h_blocking}
+    if shard.pair_groups:
+        h_forms["chunked"] = h_chunked
+    want_form = os.environ.get("DL_H_GATHER")
+    h_ab = {name: _timed(fn, reps, red_dev) * 1e3 for name, fn in h_forms.items() if not want_form or name == want_form}
+    h_form = min(h_ab, key=h_ab.get)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(timers=None):
+        e = [ev() for _ in range(7)] if timers is not None else None
+        rec = (lambda i: e[i].record()) if e else (lambda i: None)
+        rec(0)
+        dd.gather_table(Z, part, rank, z_mode, src=Z_loc)
+        rec(1)
+        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        rec(2)
+        dd.all_gather_rows(s, shard.lo, shard.hi)
+        rec(3)
+        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+        rec(4)
+        if h_form == "chunked":
+            gather = dd.ChunkedRowGather(H, part, rank).start()
+            rec(5)
+            prob_ = dd.score_local_pairs(backend, shard, Z, H, t, gather)
+        else:
+            dd.gather_table(H, part, rank, z_mode)
+            rec(5)
+            prob_ = backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        rec(6)
+        if timers is not None:
+            timers.append(e)
+        return prob_
+
+    dd.reset_message_counts()
+    prob_sharded = step()
+    torch.cuda.synchronize()
+    messages = dd.reset_message_counts()
+    parity = None
+    if n1 is not None and n1["prob"] is not None:
+        diff = (prob_sharded - n1["prob"]).abs()
+        parity = {"max_abs_dprob_sharded_vs_unsharded_rank0_slice": float(diff.max()) if diff.numel() else 0.0,
+                  "pairs_compared": int(diff.numel()),
+                  "note": "same Z, same relabelled graph: the plans are shard-independent, 0.0 expected"}
+    # ---- warm-up: the requested steps, then by TIME (>= 0.3 s), the count agreed through rank 0 ---------------------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    est = torch.tensor([(time.perf_counter() - t0) / args.steps], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    est_s = max(float(est), 1e-6)
+    for _ in range(min(2000, int(0.3 / est_s))):
+        step()
+    n_blocks = int(min(50, max(args.repeats, math.ceil(1.0 / (est_s * args.steps)))))
+    blocks = []
+    for _ in range(n_blocks):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        blocks.append(time.perf_counter() - t0)
+    wall = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)                          # per block: the slowest rank
+    wall_s = float(wall.median())
+    counts = torch.tensor([shard.graph.n_edges, shard.pairs.n_pairs], dtype=torch.int64, device=red_dev)
+    per_rank = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(per_rank, counts)
+    E, P = int(sum(int(c[0]) for c in per_rank)), int(sum(int(c[1]) for c in per_rank))
+    # where a step goes on THIS rank: HIP events on the launch stream around every collective and every kernel phase
+    timers = []
+    for _ in range(min(args.steps, 10)):
+        step(timers)
+    torch.cuda.synchronize()
+    span = lambda i, j: float(np.median([e[i].elapsed_time(e[j]) for e in timers]))
+    phases = dict(z_gather_ms=span(0, 1), route_ms=span(1, 2), s_gather_ms=span(2, 3), aggregate_ms=span(3, 4),
+                  h_gather_start_ms=span(4, 5), score_and_h_gather_ms=span(5, 6))
+    comm_ms = phases["z_gather_ms"] + phases["s_gather_ms"] + phases["h_gather_start_ms"]
+    # kernels alone (no collectives), for the roofline entry and the compute / exposed-communication split
+    reps_k = max(5, min(args.steps, 20))
+    kev = [[ev() for _ in range(4)] for _ in range(reps_k)]
+    for i in range(reps_k):
+        kev[i][0].record()
+        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        kev[i][1].record()
+        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+        kev[i][2].record()
+        backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        kev[i][3].record()
+    torch.cuda.synchronize()
+    kt = [float(np.median([kev[i][j].elapsed_time(kev[i][j + 1]) for i in range(reps_k)])) * 1e-3 for j in range(3)]
+    compute_ms = sum(kt) * 1e3
+    step_ms = wall_s / args.steps * 1e3
+    mine = torch.tensor([compute_ms, step_ms - compute_ms, comm_ms, phases["score_and_h_gather_ms"], kt[2] * 1e3],
+                        dtype=torch.float64, device=red_dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    mb = _bench.moved_bytes(shard.graph, shard.pairs, K, d, w=wb)
+    j = int(np.argmax(kt))
+    name = ("route", "aggregate", "score")[j]
+    table_bytes = 2 * shard.n_pad * K * d * wb
+    bound, peak, bound_how = _bench.memory_bound(table_bytes, mb, None)     # no PMC passes exist for sharded runs
+    roofline = {"bound": bound, "bound_decided_by": bound_how, "kernel": name, "achieved": mb[name] / kt[j] / 1e9,
+                "peak": peak, "unit": "GB/s", "frac": mb[name] / kt[j] / 1e9 / peak, "traffic": None,
+                "moved_bytes": mb[name], "avg_us": kt[j] * 1e6, "scope": "rank 0's shard, kernels only"}
+    if bound == "hbm" and roofline["frac"] > _bench.HBM_ACHIEVABLE_FRAC:
+        roofline["frac_unverified"] = "above what HBM can deliver and not backed by counters: part of the bytes are cache hits"
+    nnz = np.array([int(c[0]) for c in per_rank], dtype=np.float64)
+    gather_bytes = (world - 1) * B * (2 * K * d * wb + K * 4)       # received per rank and step
+    link_GBs = gather_bytes / max(comm_ms + phases["score_and_h_gather_ms"] - kt[2] * 1e3, 1e-6) / 1e6
+    dist.barrier()
+    value = (E + P) * args.steps / wall_s
+    out = {
+        "name": spec["name"], "baseline_config": spec["config"],
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "repeats": len(blocks), "timed_region_s": float(wall.sum()),
+        "ms_per_step": step_ms, "ms_per_step_min_median_max": [float(wall.min()) / args.steps * 1e3, step_ms,
+                                                               float(wall.max()) / args.steps * 1e3],
+        "ms_per_step_blocks": [float(b) / args.steps * 1e3 for b in wall.tolist()],
+        "scaling": spec["scaling"], "dtype": spec["dtype"], "data": "synthetic",
+        "n1_same_problem_ms": None if n1 is None else n1["ms"],
+        "n1_same_problem": None if n1 is None else
+        {"ms_per_step": n1["ms"], "kernels_us": n1["kernels_us"], "E_sym": n1["E"], "P": n1["P"],
+         "edges_per_s": (n1["E"] + n1["P"]) / (n1["ms"] * 1e-3),
+         "what": ("the same relabelled graph and the same gathered Z, unsharded on rank 0's GPU in this run" if
+                  spec["scaling"] == "strong" else
+                  f"the per-GPU problem of the weak-scaling series ({spec['workload']} x{base_scale:g}) on rank 0's GPU in this run")},
+        "speedup_vs_n1": None if n1 is None else (n1["ms"] / step_ms if spec["scaling"] == "strong" else
+                                                  value / ((n1["E"] + n1["P"]) / (n1["ms"] * 1e-3))),
+        "parity": parity,
+        "gather_ab": {"z_gather_ms": z_ab, "z_gather_used": z_mode, "h_phase_ms": h_ab, "h_phase_used": h_form,
+                      "forced": {"DL_GATHER_MODE": forced, "DL_H_GATHER": want_form},
+                      "note": "allgather = one all_gather_into_tensor into the table itself (in place); p2p = one grouped "
+                              "batch of W-1 direct sends + W-1 receives landing in place; broadcast = W broadcasts; "
+                              "H phase: blocking gather + one scoring launch vs row chunks pushed directly with the "
+                              "scorer under them; max over ranks of the median of %d" % reps},
+        "messages_per_step": {**messages, "note": "this rank: collectives (Z, s[, H]) + point-to-point operations of the "
+                                                  "chunked H exchange; staging_copies = device copies made only to feed or "
+                                                  "unpack a collective (0: every received row lands in its final place)"},
+        "roofline": roofline,
+        "per_rank": [dict(rank=r, nnz=int(per_rank[r][0]), pairs=int(per_rank[r][1]), compute_ms=float(allr[r][0]),
+                          exposed_comm_ms=float(allr[r][1]), blocking_gathers_ms=float(allr[r][2]),
+                          score_under_h_gather_ms=float(allr[r][3]), score_alone_ms=float(allr[r][4]))
+                     for r in range(world)],
+        "phases_rank0_ms": phases,
+        "effective_gather_GBs_rank0": link_GBs,
+        "partition": {"balance": "nnz", "block_rows": B, "padded_nodes": shard.n_pad,
+                      "nnz_max_over_mean": float(nnz.max() / max(nnz.mean(), 1.0)), "h_gather_chunks": part.n_chunks,
+                      "allgather_bytes_received_per_rank_per_step": int(gather_bytes)},
+        "prep_s": {"problem_built_once_and_shared": prob.prep_s, "until_first_collective": prep_s},
+        "config": {"workload": f"{spec['workload']}-synthetic x{scale:g} (seed 0): N={sg.n_nodes}, edge rows={prob.edge_rows}, "
+                               f"85/5/10 split, E_sym={E}, scored train pairs P={P} (m=5), K={K}, d={d}, {spec['dtype']} tables; "
+                               f"row-sharded over {world} GPUs by work (nnz), all-gather of Z, s and H over RCCL each step; "
+                               "forward route+aggregate+score",
+                   "K": K, "d": d, "n_nodes": sg.n_nodes, "E_sym": E, "P": P,
+                   "parallelism": f"row-shard x{world}",
+                   "fast_path": bool(lib.dl_has_fast_path_dtype(K, d, 1 if wb == 2 else 0))},
+    }
+    del Z, H, s, shard, Z_loc
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_sharded(args, rank: int, world: int, device) -> dict:
+    """All blocks of one launch -> the JSON line (rank 0's return value is printed)."""
+    emu = int(os.environ.get("DL_EMULATE_WORLD", "0"))
+    if emu > 1 and world == 1:
+        return bench_emulated(args, emu, device)
+    ctrl = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    if args.workload in ("auto", "multi"):
+        specs = [dict(b) for b in DEFAULT_BLOCKS]
+        only = os.environ.get("DL_BENCH_BLOCKS")
+        if only:
+            specs = [b for b in specs if b["name"] in only.split(",")]
+    else:
+        specs = [dict(name=f"{args.workload}_{args.scaling}", workload=args.workload, scaling=args.scaling, K=args.K,
+                      d=args.d, dtype=args.dtype, config="as given on the command line")]
+    results = [run_block(sp, args, rank, world, device, ctrl) for sp in specs]
+    head = results[0]
+    line = {"metric": "edges/sec (aggregate+score) at K=8 d=64",
+            "value": head["value"], "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
+            "dtype": head["dtype"], "data": "synthetic", "config": head["config"],
+            "n1_same_problem_ms": head["n1_same_problem_ms"], "speedup_vs_n1": head["speedup_vs_n1"],
+            "parity": head["parity"], "roofline": head["roofline"],
+            "cpu_baseline": None,
+            "cpu_baseline_note": "timed on rank 0 at N=1 only (bench.py --gpus 1), as the contract says",
+            "blocks": {r["name"]: r for r in results},
+            "launch": {"self_launched": bool(os.environ.get("DL_BENCH_SELF_LAUNCHED")),
+                       "backend": dist.get_backend(), "rehearsal_on_one_gpu": bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU"))}}
+    return line
+
+
+# --------------------------------------------------------------------------- one GPU standing in for rank 0 of W
+def bench_emulated(args, emu_world: int, device) -> dict:
+    """Rank 0's shard of the `emu_world`-GPU problem on ONE GPU, compute only (DL_EMULATE_WORLD=W): per-phase kernel
+    times, the partition's balance, and how much of the scoring can start before the H exchange has delivered anything
+    (pairs whose second endpoint is local) or has delivered chunk c — a rehearsal of the per-rank work, not a scaling
+    number."""
+    K, d, beta, t = args.K, args.d, 0.5, 1.0
+    tab = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    wb = 2 if args.dtype == "bf16" else 4
+    t_prep = time.perf_counter()
+    workload = "squirrel" if args.workload in ("auto", "multi") else args.workload
+    scale = args.scale * (emu_world if args.scaling == "weak" else 1)
+    prob = shared_problem(workload, scale, 0, 1, device)
+    sg, pu, pv = prob.sg, prob.pu, prob.pv
+    train_src, train_dst = prob.train_src, prob.train_dst
+    shard = dd.Shard.build(0, emu_world, sg.n_nodes, train_src, train_dst, pu, pv, device,
+                           row_bytes=K * d * wb, n_chunks=dd.DEFAULT_CHUNKS, with_backward=False)
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t_prep
+    backend = dd.HipBackend()
+    Z = (torch.randn((shard.n_pad, K, d), device=device) * 0.24).to(tab)
+    s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
+    H = torch.empty_like(Z)
+    ng = len(shard.pair_groups)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 + ng)]
+    acc = np.zeros(3 + ng)
+    for it in range(args.warmup + args.steps):
+        ev[0].record()
+        p, a = backend.route_fwd(shard.graph, Z, t, s)
+        ev[1].record()
+        backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
+        ev[2].record()
+        backend.score_pairs_fwd(Z, H, shard.pairs, t)
+        ev[3].record()
+        for gi, (_idx, sub) in enumerate(shard.pair_groups):
+            if sub is not None:
+                backend.score_pairs_fwd(Z, H, sub, t)
+            ev[4 + gi].record()
+        torch.cuda.synchronize()
+        if it >= args.warmup:
+            acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3 + ng)]
+    acc /= args.steps
+    # the routing cut by peer block (Shard.route_by_peer): its kernels alone, every block already present
+    by_peer = None
+    if shard.route_by_peer:
+        class _Arrived:
+            def wait(self, q): pass
+            def wait_all(self): pass
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(args.warmup + 1):
+            e0.record()
+            for _ in range(args.steps):
+                dd.route_in_arrival_order(backend, shard, Z, t, s, _Arrived())
+            e1.record()
+            torch.cuda.synchronize()
+        peers = [g for g in shard.route_by_peer if g is not None]
+        by_peer = {"route_us": e0.elapsed_time(e1) * 1e3 / args.steps, "passes": len(peers)}
+    w = np.bincount(train_src, minlength=sg.n_nodes) + np.bincount(train_dst, minlength=sg.n_nodes) + 1
+    cuts = shard.part.cuts
+    share = np.array([w[cuts[r]:cuts[r + 1]].sum() for r in range(emu_world)], dtype=np.float64)
+    groups = [dict(group="second endpoint local" if gi == 0 else f"chunk {gi - 1} of the H exchange",
+                   pairs=int(idx.numel()), score_us=float(acc[3 + gi] * 1e3)) for gi, (idx, _s) in enumerate(shard.pair_groups)]
+    W, C = emu_world, shard.part.n_chunks
+    return {"emulated_world": emu_world, "scaling": args.scaling, "dtype": args.dtype, "workload": workload,
+            "prep_s": {"problem": prob.prep_s, "problem_and_rank0_shard": prep_s,
+                       "note": "graph + split + sorted pair list (sorts / searches on the GPU), then rank 0's shard plans"},
+            "rank0_edges": shard.graph.n_edges, "rank0_pairs": shard.pairs.n_pairs,
+            "n_nodes": sg.n_nodes, "block_rows": shard.part.block, "table_MB": shard.n_pad * K * d * wb / 1e6,
+            "work_share_max_over_mean": float(share.max() / share.mean()),
+            "route_us": acc[0] * 1e3, "aggregate_us": acc[1] * 1e3, "score_us": acc[2] * 1e3,
+            "route_by_peer": by_peer,
+            "score_in_gather_order": groups,
+            "scored_before_any_chunk_lands": (groups[0]["pairs"] / max(1, shard.pairs.n_pairs)) if groups else 0.0,
+            "messages_per_step": {"collectives": 2, "p2p_ops": 2 * (W - 1) * C, "staging_copies": 0,
+                                  "note": "Z and s: one all_gather_into_tensor each, in place; H: C grouped batches of "
+                                          "W-1 sends + W-1 receives, every message contiguous in its final place"},
+            "allgather_bytes_per_rank_per_step": (emu_world - 1) * shard.part.block * (2 * K * d * wb + K * 4)}

@@ -24,6 +24,11 @@ def _np(t):
 
 
 class OracleBackend:
+    partial_route_plans = True            # tests flip this to stand in for the generic kernels (which ignore the plan)
+
+    def honours_partial_route_plans(self, K, d, table_dtype) -> bool:
+        return self.partial_route_plans
+
     def route_fwd(self, g, Z, t, s_out, p_out=None, a_out=None):
         """Like dl_route_fwd: the entries of the graph's ROUTING plan are routed (all of them, or — Shard.route_by_peer —
         those whose column lies in one peer's block), into p_out / a_out when given; the row sums are then taken over the

@@ -1702,3 +1702,35 @@ def test_adam_step_kernel_matches_torch_adam_on_odd_sizes():
             assert torch.allclose(mm, st["exp_avg"], rtol=1e-5, atol=1e-7) and torch.allclose(vv, st["exp_avg_sq"], rtol=1e-5, atol=1e-9)
     rc = lib.dl_adam_step(9, None, None, None, None, None, state.data_ptr(), 1e-2, 0.9, 0.999, 1e-8, 0.0, None)
     assert rc == -1 and b"n_bufs" in lib.dl_last_error()
+
+
+def test_bench_gpus_2_launches_itself_and_reports_a_self_contained_scaling_record():
+    """`python bench.py --gpus 2` started plainly (as the driver starts it): the parent launches the two ranks, which on
+    this one-GPU box share cuda:0 with gloo carrying the collectives (DL_REHEARSE_ON_ONE_GPU: functional only).  The line
+    must carry, per block, the same-problem N=1 time measured in the same run, the sharded-vs-unsharded probability
+    difference on rank 0's pair slice (expected exactly 0: the plans are shard-independent), the in-run gather A/B and
+    the per-step message counts with zero staging copies."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DL_REHEARSE_ON_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--scale", "0.02"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["launch"]["self_launched"]
+    assert set(line["blocks"]) == {"snap_patents_strong", "penn94_bf16_strong", "squirrel_weak"}
+    for name, b in line["blocks"].items():
+        assert b["n1_same_problem_ms"] > 0 and b["ms_per_step"] > 0 and b["value"] > 0, name
+        assert b["messages_per_step"]["staging_copies"] == 0, name
+        assert set(b["gather_ab"]["z_gather_ms"]) == {"allgather", "p2p", "broadcast"}, name
+        assert len(b["per_rank"]) == 2
+        if b["scaling"] == "strong":
+            assert b["parity"]["max_abs_dprob_sharded_vs_unsharded_rank0_slice"] == 0.0, (name, b["parity"])
+            assert b["parity"]["pairs_compared"] > 0
+    assert line["n1_same_problem_ms"] == line["blocks"]["snap_patents_strong"]["n1_same_problem_ms"]

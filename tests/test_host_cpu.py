@@ -493,3 +493,31 @@ def test_split_on_a_torch_device_is_the_numpy_split():
     for name in ("pos_train", "neg_train", "val", "test"):
         x, y = getattr(a, name), getattr(b, name)
         assert np.array_equal(x.u, y.u) and np.array_equal(x.v, y.v) and np.array_equal(x.label, y.label), name
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus N` (N > 1) without a launcher — the way the driver starts it — must start its N ranks
+    itself as child processes BEFORE any GPU call, relay rank 0's JSON line and exit 0; a failing rank must fail the
+    whole launch.  DL_BENCH_LAUNCH_CHECK replaces the measurement by one gloo all-reduce, so this runs without a GPU (the
+    parent never touches one: this container has none, and it gets as far as a successful rendezvous)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DL_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line on stdout, everything else on stderr
+    line = json.loads(lines[0])
+    assert line["launch_check"] and line["n_gpus"] == 2 and line["rank_sum"] == 3.0 and line["self_launched"]
+    env["DL_BENCH_LAUNCH_CHECK"] = "fail"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    # under a launcher the rank count must agree with --gpus
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", DL_BENCH_LAUNCH_CHECK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "disagree" in r.stderr
