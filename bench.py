@@ -369,42 +369,19 @@ def hbm_bound_section(ops, device, K, d, nhid, steps, warmup, repeats, workload=
 
 
 def under_launcher() -> bool:
-    """Started by torch.distributed.run (or any launcher that sets the rendezvous variables)?"""
-    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    from disenlink_amd.launch import under_launcher as f
+    return f()
 
 
 def self_launch(n_gpus: int, argv) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes
-    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), pass their stderr
-    through, relay rank 0's JSON line on stdout and return the children's exit code (non-zero when any rank failed or no
-    line came back).  This process makes NO GPU / HIP call — it neither asks torch.cuda anything nor loads the library —
-    and replaces no running program (no os.exec*): it only waits for its children."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: what the host driver supports
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
-    env["DL_BENCH_SELF_LAUNCHED"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
-    print("bench.py: launching %d ranks: %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
-    line = None
-    for out in proc.stdout:
-        if out.lstrip().startswith("{") and '"metric"' in out:
-            line = out.strip()
-        else:
-            sys.stderr.write(out)
-    rc = proc.wait()
-    if rc == 0 and line is None:
-        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
-        rc = 1
-    if rc == 0:
-        print(line, flush=True)
-    return rc
+    (disenlink_amd/launch.py: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>`), pass their stderr through, relay rank 0's JSON line on stdout and return the children's exit code
+    (non-zero when any rank failed or no line came back).  This process makes NO GPU / HIP call — it neither asks
+    torch.cuda anything nor loads the library — and replaces no running program (no os.exec*)."""
+    from disenlink_amd.launch import launch_ranks
+    return launch_ranks(n_gpus, [os.path.abspath(__file__)], list(argv), cwd=ROOT, result_marker='"metric"',
+                        env_extra={"DL_BENCH_SELF_LAUNCHED": "1"})
 
 
 def launch_check(rank: int, world: int) -> int:

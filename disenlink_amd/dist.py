@@ -398,6 +398,7 @@ class Shard:
     # entries whose column lies in block q — one contiguous run per row, columns being sorted), None where a peer has
     # none; empty list = one routing pass after a blocking all-gather
     route_by_peer: list = field(default_factory=list)
+    row_bytes: int = 2048
 
     @staticmethod
     def build(rank: int, world: int, n_nodes: int, edge_src, edge_dst, pu, pv, device,
@@ -463,7 +464,27 @@ class Shard:
                 route.rowptr, route.col = graph.plan.rowptr, graph.plan.col       # the SAME arrays: only the segments differ
                 by_peer.append(Graph(graph.plan, None, route, False))
         return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts,
-                     part, groups, by_peer)
+                     part, groups, by_peer, row_bytes)
+
+    def with_pairs(self, pu, pv, with_backward: bool = False) -> "Shard":
+        """The same partition and local graph with ANOTHER global pair list (sorted by pu; e.g. the test pairs, scored
+        once with the best weights): only the pair plans are built."""
+        pu = np.asarray(pu, dtype=np.int64)
+        pv = np.asarray(pv, dtype=np.int64)
+        if pu.size and np.any(np.diff(pu) < 0):
+            raise ValueError("the pair list must be sorted by pu (pairs are scored by the owner of u)")
+        part, B, dev = self.part, self.part.block, self.graph.device
+        ppu, ppv = part.to_padded(pu), part.to_padded(pv)
+        cuts = np.searchsorted(ppu, np.arange(self.world + 1) * B, side="left")
+        cuts[-1] = ppu.size
+        q0, q1 = int(cuts[self.rank]), int(cuts[self.rank + 1])
+        tpu, tpv = torch.as_tensor(ppu, device=dev), torch.as_tensor(ppv, device=dev)
+        pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], self.n_pad, row_range=(self.lo, self.lo),
+                               by_u_range=(self.lo, self.hi), row_bytes=self.row_bytes)
+        inc = _incidence_only(tpu, tpv, self.n_pad, self.lo, self.hi, self.row_bytes) if with_backward else None
+        block = int(np.max(np.diff(cuts))) if pu.size else 0
+        return Shard(self.rank, self.world, self.n_nodes, self.n_pad, self.lo, self.hi, self.graph, pairs, inc, q0, q1,
+                     int(pu.size), block, cuts, part, [], self.route_by_peer, self.row_bytes)
 
     def pad_rows(self, x_local_real: torch.Tensor) -> torch.Tensor:
         """Feature rows of this rank's block, zero rows for padding nodes."""
@@ -568,10 +589,29 @@ class ShardedHotPath(torch.autograd.Function):
         return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None
 
 
+def gather_grad_rows(dH: torch.Tensor, sh: "Shard", group, wire_dtype) -> None:
+    """All-gather the ranks' rows of the fp32 gradient table dH.  wire_dtype = torch.bfloat16 sends the rows as bf16 —
+    HALF the bytes of the largest message of the backward (snap-patents: 6 GB -> 3 GB received per rank and step) — and
+    widens the REMOTE rows on arrival; a rank's OWN rows stay the exact fp32 values it computed.  The rounding of the
+    remote rows (relative 2^-9 per element of dH) reaches the weight gradients at a few 1e-3 relative (tested over
+    gloo); it rides on the same switch as the bf16 forward tables (Disentangle(table_dtype=torch.bfloat16)), whose own
+    rounding is of the same size.  DL_DH_GATHER=f32 keeps the fp32 wire."""
+    if wire_dtype == torch.float32 or sh.world == 1 or os.environ.get("DL_DH_GATHER", "") == "f32":
+        all_gather_rows(dH, sh.lo, sh.hi, group)
+        return
+    wire = torch.empty(dH.shape, dtype=wire_dtype, device=dH.device)
+    all_gather_rows(wire, sh.lo, sh.hi, group, src=dH[sh.lo:sh.hi].to(wire_dtype))
+    if sh.lo > 0:
+        dH[:sh.lo] = wire[:sh.lo]
+    if sh.hi < dH.shape[0]:
+        dH[sh.hi:] = wire[sh.hi:]
+
+
 def _route_aggregate_bwd_sharded(be, sh: Shard, Z, beta, t, p, a, s, dH, dZ, group) -> None:
-    """dH holds this rank's rows of d loss / d H; dZ its rows of the scorer's d loss / d Z.  All-gather dH, phase 1 on the
-    local rows, all-gather ds, phase 2 accumulating into dZ's local rows."""
-    all_gather_rows(dH, sh.lo, sh.hi, group)
+    """dH holds this rank's rows of d loss / d H; dZ its rows of the scorer's d loss / d Z.  All-gather dH (on a bf16
+    wire when the forward tables are bf16: gather_grad_rows), phase 1 on the local rows, all-gather ds, phase 2
+    accumulating into dZ's local rows."""
+    gather_grad_rows(dH, sh, group, Z.dtype)
     ds = torch.zeros_like(s)
     dw, dwr = be.bwd_phase1(sh.graph, Z, beta, p, a, s, dH, ds)
     all_gather_rows(ds, sh.lo, sh.hi, group)
@@ -654,9 +694,48 @@ def sharded_forward_loss(model, x_local: torch.Tensor, shard: Shard, label: torc
     return H_loc.reshape(H_loc.shape[0], -1), prob, bce
 
 
-def allreduce_gradients(model, group=None) -> None:
-    """Sum the replicas' weight gradients (each rank's loss must already carry the GLOBAL normaliser)."""
-    for prm in model.parameters():
+def allreduce_gradients(model, group=None) -> dict:
+    """Sum the replicas' weight gradients (each rank's loss must already carry the GLOBAL normaliser) with as few
+    messages and copies as the gradients' layout allows -> {"collectives": n, "copies": n, "how": ...}:
+
+    * the drop-in module's gradients arrive as the slices of 4 stacked [K, ...] tensors that ops.project_bwd carves out
+      of ONE allocation: ONE all-reduce over a flat view of it, no copy (round 3: 4 K all-reduces of 4 K small views —
+      32 collectives per step on a model whose whole gradient is 3 MB);
+    * stacked but not adjacent (padded feature widths): one all-reduce per stacked tensor (4);
+    * anything else: the gradients are packed into one flat bucket, reduced once and copied back."""
+    params = [p for p in model.parameters()]
+    for prm in params:
         if prm.grad is None:
             prm.grad = torch.zeros_like(prm)
-        dist.all_reduce(prm.grad, op=dist.ReduceOp.SUM, group=group)
+    stacked = None
+    if getattr(model, "_stacked_params", None) is not None and model._stacked_params() is not None:
+        from .optim import flat_view, stacked_grad
+        groups = dict(model._param_groups())
+        stacked = []
+        for key, ps in groups.items():
+            g0 = ps[0].grad
+            st = stacked_grad(ps, model._stacked[key])
+            if st.data_ptr() != g0.data_ptr():               # a stacking copy, not a view: not worth it, use the bucket
+                stacked = None
+                break
+            stacked.append(st)
+    if stacked:
+        flat = flat_view(stacked)
+        if flat is not None:
+            _count("collectives")
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            return {"collectives": 1, "copies": 0, "how": "one flat view over the stacked gradients"}
+        for st in stacked:
+            _count("collectives")
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=group)
+        return {"collectives": len(stacked), "copies": 0, "how": "one all-reduce per stacked gradient"}
+    grads = [p.grad for p in params]
+    bucket = torch.cat([g.reshape(-1) for g in grads])
+    _count("collectives")
+    _count("staging_copies", 2)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(bucket[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    return {"collectives": 1, "copies": 2 * len(grads), "how": "one packed bucket (gradients are not stacked views)"}

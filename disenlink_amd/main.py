@@ -51,6 +51,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-graph", action="store_true",
                    help="launch every epoch from Python instead of replaying it from a captured HIP graph")
     p.add_argument("--quiet", action="store_true")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="row-shard every run over this many GPUs of the node (one process per GPU, RCCL): started "
+                        "plainly, the command launches its ranks itself (disenlink_amd/launch.py)")
     return p
 
 
@@ -81,10 +84,64 @@ def load_dataset(args):
     return datasets.LinkDataset(f"{key}-synthetic", sg.features(), sg.src, sg.dst)
 
 
+def main_sharded(args):
+    """--gpus N: the same runs with the graph's rows, the feature rows and the pair lists sharded over N ranks
+    (train.run_link_prediction_sharded).  Every rank loads the dataset and draws the SAME seeded split (host arrays);
+    it keeps its own feature rows only.  Rank 0 prints."""
+    import torch.distributed as dist
+    from .model import Disentangle
+    from .splits import make_link_split
+    from .train import prepare_run_sharded, run_link_prediction_sharded
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearse = bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU"))      # all ranks on cuda:0, gloo collectives: functional only
+    device = torch.device("cuda", 0 if rehearse else local)
+    torch.cuda.set_device(device)
+    if rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    say = (lambda *a: print(*a, flush=True)) if rank == 0 and not args.quiet else (lambda *a: None)
+    try:
+        ds = load_dataset(args)
+        say(args)
+        say(f"dataset {ds.name}: N={ds.n_nodes} F={ds.x.shape[1]} edge rows={ds.src.size}; row-sharded over {world} GPUs")
+        tdt = torch.bfloat16 if args.table_dtype == "bf16" else torch.float32
+        row_bytes = args.nfactor * args.nembed * (2 if args.table_dtype == "bf16" else 4)
+        result = []
+        for run in range(args.run):
+            say("run:", run)
+            split = make_link_split(ds.src, ds.dst, ds.n_nodes, m=args.m, seed=args.seed + run)
+            prepared = prepare_run_sharded(split, rank, world, device, row_bytes=row_bytes)
+            r0, r1 = prepared.shard.local_real_rows()
+            x_loc = torch.from_numpy(np.ascontiguousarray(ds.x[r0:r1])).to(device)
+            torch.manual_seed(args.seed + run)                       # identical replicas
+            model = Disentangle(ds.x.shape[1], args.nhidden, args.nembed, nfactor=args.nfactor, beta=args.beta,
+                                t=args.temperature, table_dtype=tdt).to(device)
+            res = run_link_prediction_sharded(model, x_loc, prepared, epochs=args.epochs, lr=args.lr,
+                                              log=say if not args.quiet else None)
+            say("test auc:", res.test_auc)
+            result.append(res.test_auc)
+        result = np.array(result)
+        if rank == 0:
+            print("final", result.mean(), result.std(), flush=True)
+        return result
+    finally:
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     args = build_parser().parse_known_args(argv)[0]                 # unknown tokens ignored, like :50
     if args.layer != 1:
         raise SystemExit("only --layer 1 exists in the reference (main_disentangled.py:147-148)")
+    if args.gpus > 1:
+        from .launch import launch_ranks, under_launcher
+        if not under_launcher():                                    # BEFORE any GPU call: the parent starts and waits
+            raise SystemExit(launch_ranks(args.gpus, ["-m", "disenlink_amd.main"], list(sys.argv[1:] if argv is None else argv)))
+        if args.no_cuda or not torch.cuda.is_available():
+            raise SystemExit("disenlink_amd runs on the GPU only (libdisenlink_hip.so has no CPU fallback)")
+        return main_sharded(args)
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("disenlink_amd runs on the GPU only (libdisenlink_hip.so has no CPU fallback)")
     from .model import Disentangle

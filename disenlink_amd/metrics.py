@@ -100,3 +100,81 @@ class AucPlan:
         u2 = (below + upto).sum()                                   # 2 * (below + (upto - below) / 2), in int64: exact
         return u2.to(torch.float64) / self._denom2.to(score.device) if denom > 0 else torch.full((), float("nan"), dtype=torch.float64,
                                                                                 device=score.device)
+
+
+class ShardedAucPlan:
+    """Tie-aware AUC of an evaluation set whose scores are spread over the ranks of a process group (row-sharded runs:
+    every rank holds the scores of the pairs whose first endpoint it owns).  The Mann-Whitney counts are ADDITIVE over
+    slices of either class:
+
+        2 U = sum over ranks r of  sum_{p in pos(r)} ( 2 #{n: s_n < s_p} + #{n: s_n == s_p} ),   n over ALL negatives
+
+    so per evaluation: one all-gather of the negatives' scores (padded to the largest rank's count; the sizes are fixed
+    for a run), each rank counts ITS positives against all negatives (the same kernel as AucPlan — dl_auc_pair_counts — on
+    the GPU, a sort + two binary searches elsewhere), and the integer counts are summed by the caller's all-reduce
+    (`partial(score)` returns this rank's 2U as an exact float64; `auc(score)` does the all-reduce itself).  Equal to
+    sklearn.roc_auc_score on the concatenated vectors (main_disentangled.py:202-204, :217-219), whatever the sharding."""
+
+    def __init__(self, label_local: torch.Tensor, group=None):
+        import torch.distributed as dist
+        self.group, self.dist = group, dist
+        label_local = label_local.reshape(-1)
+        dev = label_local.device
+        pos = label_local > 0.5
+        self.pos_idx = torch.nonzero(pos).reshape(-1)
+        self.neg_idx = torch.nonzero(~pos).reshape(-1)
+        world = dist.get_world_size(group)
+        self._cpu_wire = label_local.is_cuda and dist.get_backend(group) == "gloo"
+        red = "cpu" if self._cpu_wire else dev
+        mine = torch.tensor([self.pos_idx.numel(), self.neg_idx.numel()], dtype=torch.int64, device=red)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine, group=group)
+        counts = torch.stack(allc).cpu()
+        self.n_pos, self.n_neg = int(counts[:, 0].sum()), int(counts[:, 1].sum())
+        self.max_neg = max(1, int(counts[:, 1].max()))
+        self.world = world
+        # positions of the VALID entries of the gathered [world, max_neg] buffer; this rank's scores follow it
+        valid = torch.cat([r * self.max_neg + torch.arange(int(counts[r, 1])) for r in range(world)]) if self.n_neg else \
+            torch.zeros(0, dtype=torch.int64)
+        self.all_neg_idx = valid.to(dev)
+        self.local_pos_idx = (self.pos_idx + world * self.max_neg).contiguous()
+        self.n_local_pos = int(self.pos_idx.numel())
+        self._denom2 = 2.0 * float(self.n_pos) * float(self.n_neg)
+
+    def partial(self, score_local: torch.Tensor) -> torch.Tensor:
+        """This rank's share of 2U (0-dim float64 on score_local.device; exact: an integer below 2^53)."""
+        dist = self.dist
+        score_local = score_local.reshape(-1).detach().float()
+        dev = score_local.device
+        send = torch.zeros(self.max_neg, dtype=torch.float32, device=dev)
+        send[: self.neg_idx.numel()] = score_local.index_select(0, self.neg_idx)
+        buf = torch.empty(self.world * self.max_neg + score_local.numel(), dtype=torch.float32, device=dev)
+        gathered = buf[: self.world * self.max_neg]
+        if self._cpu_wire:
+            host = torch.empty(gathered.shape, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+            gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered, send, group=self.group)
+        buf[self.world * self.max_neg:] = score_local
+        if self.n_local_pos == 0 or self.n_neg == 0:
+            return torch.zeros((), dtype=torch.float64, device=dev)
+        if buf.is_cuda and float(self.n_local_pos) * float(self.n_neg) <= AucPlan.PAIR_LIMIT:
+            from . import _lib
+            u2 = torch.empty(1, dtype=torch.int64, device=dev)
+            _lib.check(_lib.load().dl_auc_pair_counts(buf.data_ptr(), self.local_pos_idx.data_ptr(), self.n_local_pos,
+                                                      self.all_neg_idx.data_ptr(), self.n_neg, u2.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), "dl_auc_pair_counts")
+            return u2[0].to(torch.float64)
+        sp = buf.index_select(0, self.local_pos_idx)
+        sn = torch.sort(buf.index_select(0, self.all_neg_idx), stable=True).values
+        return (torch.searchsorted(sn, sp, right=False) + torch.searchsorted(sn, sp, right=True)).sum().to(torch.float64)
+
+    def auc_from_sum(self, u2_sum) -> float:
+        return float(u2_sum) / self._denom2 if self._denom2 > 0 else float("nan")
+
+    def auc(self, score_local: torch.Tensor) -> float:
+        u2 = self.partial(score_local)
+        red = u2.cpu() if self._cpu_wire else u2
+        self.dist.all_reduce(red, group=self.group)
+        return self.auc_from_sum(red)

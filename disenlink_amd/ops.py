@@ -486,9 +486,20 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
         d, nhid = W1.shape[1], 1
     if dZ.shape != (N, K, d) or W1.shape[2] != F:
         raise ValueError("inconsistent projection shapes")
-    dW1, db1 = _empty_like(W1), _empty_like(b1)
-    dW2 = _empty_like(W2) if two else None
-    db2 = _empty((K, d), torch.float32, x.device) if two else None
+    # the (up to) four gradients are carved out of ONE allocation, back to back: the sharded training step all-reduces
+    # them as one flat tensor without packing (dist.allreduce_gradients), every piece 16-byte aligned
+    shapes = [tuple(W1.shape), tuple(b1.shape)] + ([tuple(W2.shape), (K, d)] if two else [])
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    if all(n % 4 == 0 for n in sizes):
+        flat = _empty((sum(sizes),), torch.float32, x.device)
+        parts, off = [], 0
+        for sh, n in zip(shapes, sizes):
+            parts.append(flat[off:off + n].view(sh))
+            off += n
+    else:
+        parts = [_empty(sh, torch.float32, x.device) for sh in shapes]
+    dW1, db1 = parts[0], parts[1]
+    dW2, db2 = (parts[2], parts[3]) if two else (None, None)
     ws = _ws.get(int(lib.dl_project_bwd_workspace_bytes(N, F, K, nhid, d, int(two))), x.device)
     _lib.check(lib.dl_project_bwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
                                   W2.data_ptr() if two else None, dZ.data_ptr(),

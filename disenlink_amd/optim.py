@@ -15,6 +15,49 @@ from __future__ import annotations
 import torch
 
 
+def stacked_grad(ps, buf) -> torch.Tensor:
+    """The K gradients of one parameter group as ONE [K, ...] tensor shaped like the group's shared buffer.  The
+    projection's backward hands out the K slices of a stacked gradient (ops.ProjectStacked): when the K .grad tensors
+    lie back to back in one storage — checked by address, since views made in a backward (grad mode off) carry no
+    ``_base`` — the stacked tensor is a view over them (no copy); otherwise they are stacked (one copy)."""
+    g0 = ps[0].grad
+    if g0 is None:
+        raise RuntimeError("a parameter has no gradient")
+    if g0.is_contiguous() and g0.dtype == buf.dtype and g0.shape == buf.shape[1:]:
+        # (autograd hands every parameter a gradient of its own shape and dtype, and the K parameters of a group are
+        # alike: what is left to check per gradient is its address and that it is dense; this runs every step)
+        p0, step, gl = g0.data_ptr(), g0.numel() * g0.element_size(), ps[-1].grad
+        st0 = g0.untyped_storage()
+        if gl is not None and gl.untyped_storage().data_ptr() == st0.data_ptr() and \
+                st0.nbytes() >= (p0 - st0.data_ptr()) + len(ps) * step:
+            i = 0
+            for p in ps:
+                g = p.grad
+                if g is None or g.data_ptr() != p0 + i * step or not g.is_contiguous():
+                    break
+                i += 1
+            else:
+                return g0.as_strided(tuple(buf.shape), tuple(buf.stride()))     # the K gradients ARE one stacked tensor
+    return torch.stack([p.grad for p in ps])
+
+
+def flat_view(tensors):
+    """One 1-D view over `tensors` when they are dense, of one dtype and lie back to back in ONE storage (the projection
+    backward carves its four stacked gradients out of one allocation), else None."""
+    t0 = tensors[0]
+    st0 = t0.untyped_storage()
+    off = t0.data_ptr()
+    total = 0
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != t0.dtype or t.untyped_storage().data_ptr() != st0.data_ptr() \
+                or t.data_ptr() != off + total * t0.element_size():
+            return None
+        total += t.numel()
+    if st0.nbytes() < (off - st0.data_ptr()) + total * t0.element_size():
+        return None
+    return t0.as_strided((total,), (1,))
+
+
 class StackedAdam:
     """Drop-in for the training loop's use of ``torch.optim.Adam`` (zero_grad / step / state for graph capture);
     ``capturable=True`` keeps the step counters on the device and does nothing that a HIP-graph capture forbids."""
@@ -58,31 +101,7 @@ class StackedAdam:
                     p.grad.zero_()
 
     def _stacked_grad(self, key) -> torch.Tensor:
-        """The K gradients of one parameter group as ONE [K, ...] tensor.  The projection's backward hands out the K
-        slices of a stacked gradient (ops.ProjectStacked): when the K .grad tensors lie back to back in one storage —
-        checked by address, since views made in a backward (grad mode off) carry no ``_base`` — the stacked tensor is a
-        view over them (no copy); otherwise they are stacked (one copy)."""
-        ps = self.groups[key]
-        g0 = ps[0].grad
-        if g0 is None:
-            raise RuntimeError("StackedAdam.step(): a parameter has no gradient")
-        buf = self.model._stacked[key]
-        if g0.is_contiguous() and g0.dtype == buf.dtype and g0.shape == buf.shape[1:]:
-            # (autograd hands every parameter a gradient of its own shape and dtype, and the K parameters of a group are
-            # alike: what is left to check per gradient is its address and that it is dense; this runs every step)
-            p0, step, gl = g0.data_ptr(), g0.numel() * g0.element_size(), ps[-1].grad
-            st0 = g0.untyped_storage()
-            if gl is not None and gl.untyped_storage().data_ptr() == st0.data_ptr() and \
-                    st0.nbytes() >= (p0 - st0.data_ptr()) + len(ps) * step:
-                i = 0
-                for p in ps:
-                    g = p.grad
-                    if g is None or g.data_ptr() != p0 + i * step or not g.is_contiguous():
-                        break
-                    i += 1
-                else:
-                    return g0.as_strided(tuple(buf.shape), tuple(buf.stride()))     # the K gradients ARE one stacked tensor
-        return torch.stack([p.grad for p in ps])
+        return stacked_grad(self.groups[key], self.model._stacked[key])
 
     @torch.no_grad()
     def step(self):

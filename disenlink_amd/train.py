@@ -241,3 +241,100 @@ def _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log) -> RunR
     res.test_auc = float(auc_tie_avg(run.label_test, prob, check=False))
     res.best_val_auc = best_auc
     return res
+
+
+# --------------------------------------------------------------------------- the same loop, row-sharded
+@dataclass
+class ShardedRun:
+    shard: object                   # dist.Shard over [pos_train | neg_train | val] sorted by (u, v)
+    test_shard: object              # the same partition and local graph with the test pairs
+    label_all: torch.Tensor         # [P_total] labels of the sorted list (replicated)
+    weight_all: torch.Tensor        # [P_total] loss weights: 1/n_pos, 1/(m n_neg), 0 on the validation pairs
+    val_local: torch.Tensor         # positions (in the LOCAL slice) of this rank's validation pairs
+    val_plan: object                # metrics.ShardedAucPlan over them
+    test_plan: object
+
+
+def prepare_run_sharded(split: LinkSplit, rank: int, world: int, device, row_bytes: int = 2048, group=None,
+                        n_chunks: int = 1) -> ShardedRun:
+    """Every rank holds the (host) split; the scored list [pos_train | neg_train | val] is sorted by (u, v) — pairs are
+    scored by the owner of u — and its labels / loss weights are permuted along (validation pairs: weight 0, so one
+    fused loss runs over the whole list, as in the single-GPU loop)."""
+    from . import dist as dd
+    from .metrics import ShardedAucPlan
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u, split.val.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v, split.val.v])
+    n_pos, n_neg, n_val = split.pos_train.u.size, split.neg_train.u.size, split.val.u.size
+    label = np.concatenate([split.pos_train.label, split.neg_train.label, split.val.label]).astype(np.float32)
+    weight = np.concatenate([np.full(n_pos, 1.0 / max(n_pos, 1), np.float32),
+                             np.full(n_neg, 1.0 / (split.m * max(n_neg, 1)), np.float32), np.zeros(n_val, np.float32)])
+    is_val = np.concatenate([np.zeros(n_pos + n_neg, bool), np.ones(n_val, bool)])
+    order = np.lexsort((pv, pu))
+    pu, pv, label, weight, is_val = pu[order], pv[order], label[order], weight[order], is_val[order]
+    shard = dd.Shard.build(rank, world, split.n_nodes, split.train_src, split.train_dst, pu, pv, device,
+                           row_bytes=row_bytes, n_chunks=n_chunks)
+    q0, q1 = shard.pair_lo, shard.pair_hi
+    t = lambda a_: torch.as_tensor(a_, device=device)
+    val_local = t(np.flatnonzero(is_val[q0:q1]))
+    val_plan = ShardedAucPlan(t(label[q0:q1][is_val[q0:q1]]), group)
+    to = np.lexsort((split.test.v, split.test.u))
+    test_shard = shard.with_pairs(split.test.u[to], split.test.v[to])
+    test_plan = ShardedAucPlan(t(split.test.label[to][test_shard.pair_lo:test_shard.pair_hi].astype(np.float32)), group)
+    for plan, what in ((val_plan, "validation"), (test_plan, "test")):
+        if plan.n_pos == 0 or plan.n_neg == 0:
+            raise ValueError(f"AUC undefined with one class ({what} pairs)")
+    return ShardedRun(shard, test_shard, t(label), t(weight), val_local, val_plan, test_plan)
+
+
+def run_link_prediction_sharded(model, x_local: torch.Tensor, run: ShardedRun, epochs: int = 2000, lr: float = 1e-4,
+                                patience: int = 200, weight_decay: float = 5e-4, log=None, backend=None,
+                                group=None) -> RunResult:
+    """main_disentangled.py:191-224 with the rows of the graph, of the features and of the pair list sharded over the
+    ranks of `group` (one process per GPU): `x_local` = the feature rows of ``run.shard.local_real_rows()``; `model` = a
+    replica with IDENTICAL initial weights on every rank.  Per epoch: dist.sharded_forward_loss (all-gathers of Z, s, H;
+    the one-pass scorer over the rank's incidence rows where the backend has it), backward, ONE all-reduce of the weight
+    gradients (dist.allreduce_gradients), the same Adam step on every replica; the loss value and the tie-aware
+    validation AUC (metrics.ShardedAucPlan: from that forward's probabilities, i.e. the weights before the step) cross
+    the ranks in one small all-reduce — every rank sees the same numbers, so early stopping and the best-weights
+    snapshot stay in lock-step without a broadcast.  Test AUC with the best weights, as :215-219."""
+    import torch.distributed as dist
+    from . import dist as dd
+    on_gpu = bool(x_local.is_cuda)
+    opt = _make_adam(model, on_gpu, lr, weight_decay)
+    snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
+    best_auc, stale, weights = 0.0, 0, snapshot()
+    res = RunResult(float("nan"), 0.0, 0)
+    cpu_wire = on_gpu and dist.get_backend(group) == "gloo"
+    for epoch in range(epochs):
+        model.train()
+        _emb, prob, loss = dd.sharded_forward_loss(model, x_local, run.shard, run.label_all, run.weight_all,
+                                                   backend=backend, group=group)
+        opt.zero_grad()
+        loss.backward()
+        dd.allreduce_gradients(model, group)
+        opt.step()
+        model.eval()
+        both = torch.stack([loss.detach().double(), run.val_plan.partial(prob.detach().index_select(0, run.val_local))])
+        if cpu_wire:
+            both = both.cpu()
+        dist.all_reduce(both, group=group)                          # global loss, global 2U: one message
+        loss_v, u2 = both.tolist()                                  # the one device->host sync of the epoch
+        auc = run.val_plan.auc_from_sum(u2)
+        res.losses.append(loss_v)
+        res.val_aucs.append(auc)
+        res.epochs_run = epoch + 1
+        if auc > best_auc:
+            stale, best_auc = 0, auc
+            weights = snapshot()                                    # state AFTER the step, like :209
+        else:
+            stale += 1
+        if stale > patience:
+            break
+        if log is not None:
+            log(f"epoch: {epoch} loss: {res.losses[-1]} val_auc: {best_auc}")
+    model.load_state_dict(weights)
+    with torch.no_grad():
+        _emb, prob = dd.sharded_forward(model, x_local, run.test_shard, backend=backend, group=group)
+    res.test_auc = run.test_plan.auc(prob)
+    res.best_val_auc = best_auc
+    return res

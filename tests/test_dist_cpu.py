@@ -86,12 +86,14 @@ def _worker(rank, world, port, pb, sd, out, n_chunks=1, z_by_peer=False):
         dist.destroy_process_group()
 
 
-def _loss_worker(rank, world, port, pb, sd, out, table, z_by_peer=False):
+def _loss_worker(rank, world, port, pb, sd, out, table, z_by_peer=False, dh_wire=None):
     """The training step through sharded_forward_loss: one-pass scorer over the local incidence rows, no (prob, g_prob)
     all-gather; `table` = storage type of the gathered tables."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if dh_wire is not None:
+        os.environ["DL_DH_GATHER"] = dh_wire
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from disenlink_amd import dist as dd
@@ -306,3 +308,132 @@ def test_partition_helpers():
     assert dd.pair_slices(pu, 10, 4).tolist() == [0, 3, 6, 7, 8]
     with pytest.raises(ValueError, match="sorted by pu"):
         dd.Shard.build(0, 2, 10, [0], [1], [3, 1], [0, 0], "cpu")
+
+
+# --------------------------------------------------------------------------- the sharded train / eval loop
+def _split_from_trajectory(g):
+    """The reference caller's masks of a trajectory fixture as the pair lists of a LinkSplit (mask == 1 for the train
+    sets — summed masks, main_disentangled.py:176-179,195 — binarised validation / test masks, labels from ori_adj)."""
+    from disenlink_amd.splits import LinkSplit, PairSet
+    ori = g["ori_adj"]
+
+    def pairs(mask, only_single):
+        u, v = np.nonzero(mask == 1 if only_single else mask != 0)
+        return PairSet(u.astype(np.int64), v.astype(np.int64), ori[u, v].astype(np.float32))
+
+    src, dst = np.nonzero(g["adj"])
+    return LinkSplit(int(g["meta"]["N"]), src.astype(np.int64), dst.astype(np.int64), pairs(g["mask__pos_train"], True),
+                     pairs(g["mask__neg_train"], True), pairs(g["mask__val"], False), pairs(g["mask__test"], False),
+                     int(g["meta"]["m"]))
+
+
+def _train_worker(rank, world, port, name, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_trajectory
+        from disenlink_amd.model import Disentangle
+        from disenlink_amd.train import prepare_run_sharded, run_link_prediction_sharded
+        from oracle_backend import OracleBackend
+        torch.set_num_threads(1)
+        g = load_trajectory(name)
+        m = g["meta"]
+        model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
+        model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")})
+        run = prepare_run_sharded(_split_from_trajectory(g), rank, world, "cpu", n_chunks=2)
+        r0, r1 = run.shard.local_real_rows()
+        res = run_link_prediction_sharded(model, torch.from_numpy(g["x"][r0:r1]), run, epochs=m["epochs"], lr=m["lr"],
+                                          patience=200, backend=OracleBackend())
+        out[rank] = dict(losses=res.losses, val_aucs=res.val_aucs, test_auc=res.test_auc, best=res.best_val_auc,
+                         sd={k: v.numpy().copy() for k, v in model.state_dict().items()},
+                         val=(run.val_plan.n_pos, run.val_plan.n_neg), rows=(r0, r1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("traj_k4", 2), ("traj_k8", 2), ("traj_k4", 4)])
+def test_sharded_training_loop_reproduces_the_reference_trajectories(name, world):
+    """train.run_link_prediction_sharded over gloo (rows, features and pair list sharded; gradient all-reduce; the
+    tie-aware validation / test AUC summed across the ranks) against the trajectories recorded from the REFERENCE model
+    under the reference's own schedule (tests/golden/traj_*.npz): per-epoch loss and validation AUC, the test AUC with the
+    best weights — to the tolerances of the single-process trajectory test.  Every rank must see identical numbers and end
+    with identical weights (lock-step early stopping without a broadcast)."""
+    from conftest import load_trajectory
+    g = load_trajectory(name)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
+    r = out[0]
+    n_val = int((g["mask__val"] != 0).sum())
+    assert sum(r["val"]) == n_val
+    for ep in range(g["meta"]["epochs"]):
+        assert abs(r["losses"][ep] - g["losses"][ep]) <= 2e-4 * abs(g["losses"][ep]), (ep, r["losses"][ep], g["losses"][ep])
+        assert abs(r["val_aucs"][ep] - g["val_aucs"][ep]) <= 2e-3, (ep, r["val_aucs"][ep], g["val_aucs"][ep])
+    assert abs(r["test_auc"] - float(g["test_auc"])) <= 5e-3
+    for k, v in r["sd"].items():                                  # best weights == the reference's best weights
+        np.testing.assert_allclose(v, g["best__" + k], rtol=2e-3, atol=2e-5, err_msg=k)
+    for q in range(1, world):
+        assert out[q]["losses"] == r["losses"] and out[q]["val_aucs"] == r["val_aucs"] and out[q]["test_auc"] == r["test_auc"]
+        for k, v in r["sd"].items():
+            assert np.array_equal(out[q]["sd"][k], v), k
+
+
+def _auc_worker(rank, world, port, label, score, cuts, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disenlink_amd.metrics import ShardedAucPlan
+        a, b = cuts[rank], cuts[rank + 1]
+        plan = ShardedAucPlan(torch.from_numpy(label[a:b]))
+        out[rank] = plan.auc(torch.from_numpy(score[a:b]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cross_rank_auc_equals_sklearn_on_the_concatenated_vectors():
+    """metrics.ShardedAucPlan: the Mann-Whitney counts are additive over slices — every rank counts its positives
+    against the all-gathered negatives, the counts are all-reduced.  Checked against the sklearn golden vectors (heavy
+    ties at 1.0, all ties, no ties) cut into 3 UNEQUAL slices, one of them holding a single class only."""
+    import glob
+    from conftest import GOLDEN_DIR
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "auc_*.npz"))):
+        g = np.load(path)
+        y, sc = g["y"].astype(np.float32), g["score"].astype(np.float32)
+        order = np.argsort(-y, kind="stable")                     # positives first: the last slice is negatives only
+        y, sc = y[order], sc[order]
+        n = y.size
+        cuts = [0, n // 7, n // 2, n]
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_auc_worker, args=(3, _free_port(), y, sc, cuts, out), nprocs=3, join=True)
+        for r in range(3):
+            assert abs(out[r] - float(g["auc"])) <= 1e-12, (path, r, out[r], float(g["auc"]))
+
+
+def test_bf16_wire_of_the_dH_gather_costs_less_than_the_bf16_tables_themselves():
+    """With bf16 forward tables the backward's dH all-gather — its largest message — travels as bf16 too
+    (dist.gather_grad_rows; a rank's own rows stay exact).  Stated error: against the SAME run with an fp32 wire
+    (DL_DH_GATHER=f32) the summed weight gradients move by less than 6e-3 of the largest gradient entry per tensor —
+    well inside what the bf16 Z / H tables already cost against the fp32 reference (8e-2 in the test above) — and the
+    forward (loss, probabilities) is untouched bit for bit."""
+    from disenlink_amd.model import Disentangle
+    pb = _skewed_problem()
+    torch.manual_seed(0)
+    sd = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"]).state_dict()
+    runs = {}
+    for wire in ("f32", "bf16"):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_loss_worker, args=(4, _free_port(), pb, sd, out, "bf16", False, wire), nprocs=4, join=True)
+        runs[wire] = {r: out[r] for r in range(4)}
+    worst = 0.0
+    for k, g32 in runs["f32"][0]["grads"].items():
+        g16 = runs["bf16"][0]["grads"][k]
+        worst = max(worst, float(np.abs(g16 - g32).max() / max(np.abs(g32).max(), 1e-30)))
+    assert 0.0 < worst < 6e-3, worst                             # it IS a different wire, and it costs this little
+    for r in range(4):
+        assert runs["f32"][r]["loss"] == runs["bf16"][r]["loss"]
+        assert np.array_equal(runs["f32"][r]["prob"], runs["bf16"][r]["prob"])

@@ -1734,3 +1734,33 @@ def test_bench_gpus_2_launches_itself_and_reports_a_self_contained_scaling_recor
             assert b["parity"]["max_abs_dprob_sharded_vs_unsharded_rank0_slice"] == 0.0, (name, b["parity"])
             assert b["parity"]["pairs_compared"] > 0
     assert line["n1_same_problem_ms"] == line["blocks"]["snap_patents_strong"]["n1_same_problem_ms"]
+
+
+def test_cli_gpus_2_trains_row_sharded_and_matches_the_single_gpu_run():
+    """`python -m disenlink_amd.main --gpus 2` (main_disentangled.py's flags; the command launches its two ranks itself;
+    on this one-GPU box they share cuda:0 and gloo carries the collectives) against the same command on one GPU: same
+    seeded split and initial weights, 6 epochs of the reference schedule — the test AUC with the best weights and the
+    per-epoch loss must agree (the sharded step sums the weight gradients in another order: 1e-3 on the AUC)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--dataset", "chameleon", "--synthetic", "--epochs", "6", "--run", "1", "--nfactor", "8", "--nembed", "64",
+              "--nhidden", "64", "--lr", "0.005", "--seed", "3"]
+
+    def run(extra, env_extra):
+        r = subprocess.run([sys.executable, "-m", "disenlink_amd.main", *common, *extra], env=dict(env, **env_extra),
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        losses = [float(x) for x in re.findall(r"loss: ([0-9.eE+-]+)", r.stdout)]
+        auc = float(re.findall(r"test auc: ([0-9.eE+-]+)", r.stdout)[-1])
+        return losses, auc
+
+    l1, a1 = run(["--no-graph"], {})
+    l2, a2 = run(["--gpus", "2"], {"DL_REHEARSE_ON_ONE_GPU": "1"})
+    assert len(l1) == len(l2) == 6
+    np.testing.assert_allclose(l2, l1, rtol=2e-4)
+    assert abs(a1 - a2) <= 1e-3, (a1, a2)
+    assert 0.5 < a2 <= 1.0
