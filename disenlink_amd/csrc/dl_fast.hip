@@ -22,6 +22,7 @@
 //
 // Tables Z and H may be stored as fp32 or bf16 (dl_dtype); all arithmetic and all gradients are fp32.
 #include <stdlib.h>
+#include <type_traits>
 #include "dl_common.h"
 #include "dl_kernels.h"
 
@@ -1031,7 +1032,7 @@ __global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score
             for (int i = 0; i < VPL; ++i) {
                 const float ek = ek_lane[i];
                 ch_lane[i] = gl == 0.0f ? 0.0f : gl * ek;
-                cz_lane[i] = gl == 0.0f ? 0.0f : gl * pq[i] * ek / t;
+                cz_lane[i] = gl == 0.0f ? 0.0f : div_t(gl * pq[i] * ek, t);     // x / 1 == x: t == 1 skips the IEEE division
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -1058,6 +1059,239 @@ __global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score
                 store4(o, r[q]);
             } else {
                 store4(part + (size_t)si.slot * 2 * ROW + 4 * x, r[q]);       // [dZ row | dH row]
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- one-pass training scorer, wave per entry
+// Round 4.  The kernel above gives every entry to a group of 16 lanes (4 entries per wave step): each lane then carries
+// the WHOLE K x 2 accumulator set (64 registers, replicated in all four groups) next to the 64 registers of gathered
+// rows — 165 registers, three waves per SIMD, and no room to request the next rows before the current ones are used:
+// it issues 16 loads, waits for all of them, runs ~270 vector instructions, and only then asks for the next 16 KB.
+// Measured on squirrel: the vector pipe 51 % busy, the L1 at 48 % of its 64 B/clk, neither hidden behind the other.
+//
+// Here the 64 lanes of the wave share ONE entry: lane l holds float4 number j * 64 + l of a row (j < NJ = K*D/256), i.e.
+// with D = 64 a DPP row of 16 lanes holds one factor slice.  Per lane: 2 NJ accumulators (16 registers at K = 8
+// instead of 64), the node's own rows in 16 registers instead of LDS reads, and U = 4 entries per step in flight.
+// That leaves room for TWO register sets of gathered rows: the rows of step s + 1 are requested before step s is
+// computed (software pipelining; the loop body is straight-line code — behind a join the compiler's wait-count
+// insertion assumes the arm that issued no loads and waits for everything outstanding).  Per step the 4 entries share
+// one expf (8 (entry, factor) exponents live in 8 lanes of a row) and one sigmoid (entry e's logit is summed into DPP
+// row e by a transposed reduction over the four rows), so the per-entry vector work stays what it was.
+// Entries are accumulated in ascending order by every lane: the sums depend on the row alone (shard-independent).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {             // old value undefined: no zeroing move in front of the DPP move
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int I>
+__device__ __forceinline__ float row_bcast(float v) { return dpp_mov<0x150 + I>(v); }      // row_newbcast:I
+// Sum over the 16 lanes of a DPP row, in every lane, by ROTATIONS (row_ror 8, 4, 2, 1): each step is ONE v_add_f32_dpp
+// (the xor butterfly needs a move + an add for its xor-4 step: 5 instructions per value, 80 per step of this kernel).
+// All 16 lanes end with the same bits: after the rotation by r every lane holds the sum of its coset of <r>, formed as
+// (coset of the previous step) + (the other one) — the same two addends in every lane of the coset, addition commutes.
+template <int CTRL>
+__device__ __forceinline__ float add_dpp(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_allreduce_sum(float v) {
+    v = add_dpp<0x128>(v);      // row_ror:8
+    v = add_dpp<0x124>(v);      // row_ror:4
+    v = add_dpp<0x122>(v);      // row_ror:2
+    return add_dpp<0x121>(v);   // row_ror:1
+}
+
+#ifndef DL_TRAIN_WAVE_KERNEL
+#define DL_TRAIN_WAVE_KERNEL 1        // -DDL_TRAIN_WAVE_KERNEL=0: the group-per-entry kernel above, for A/B runs
+#endif
+#ifndef DL_TRAIN_PIPE
+#define DL_TRAIN_PIPE 0               // 1 (or env DL_TRAIN_PIPE=1): a second register set, the next rows requested before the current step is computed
+#endif
+template <int K, int D>
+struct TrainWave {
+    static constexpr bool ok = DL_TRAIN_WAVE_KERNEL && D == 64 && (K == 4 || K == 8);
+    static constexpr int NJ = K * D / 256;                          // float4 per lane per row
+    static constexpr int U = 4;                                     // entries per step
+};
+
+template <int K, int D, bool T1, bool PIPE, bool UREG = PIPE>
+__global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_train_wave_kernel(
+        dl_csr_plan g, const int32_t* __restrict__ inc_pair, const float* __restrict__ Z, const float* __restrict__ H, float t,
+        float* __restrict__ dZ, float* __restrict__ dH, float* __restrict__ part, const float* __restrict__ y,
+        const float* __restrict__ w, float* __restrict__ prob_out) {
+    using TW = TrainWave<K, D>;
+    constexpr int NJ = TW::NJ, U = TW::U, ROW = K * D, NV = U * NJ;
+    static_assert(D == 64 && NJ >= 1 && NV <= 8, "one DPP row of 16 lanes per factor slice; at most 8 exponents per row and step");
+    using US = Stage<K, D, float, 2, true>;                         // one [dZ row | dH row] per wave for the unit sum
+    __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
+    const int wave = ws.wave, lane = lane_id();
+    const int r = lane >> 4, i = lane & 15;                         // DPP row (its factors: r, r + 4, ...) and position in it
+    float4 az[NJ], ah[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) az[j] = ah[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the node's own rows: in registers (UREG) or re-read from the wave's LDS region at every step (4 ds_read_b128 per
+    // lane and step — 16 registers fewer, which is what lets a fourth wave onto the SIMD)
+    float4* const mine = reinterpret_cast<float4*>(US::region(red, wave));
+    if (ws.active) {
+        float4 uz[UREG ? NJ : 1], uh[UREG ? NJ : 1];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4 a4 = *reinterpret_cast<const float4*>(Z + (size_t)si.grow * ROW + (j * 64 + lane) * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(H + (size_t)si.grow * ROW + (j * 64 + lane) * 4);
+            if constexpr (UREG) {
+                uz[j] = a4;
+                uh[j] = b4;
+            } else {
+                mine[j * 64 + lane] = a4;                           // read back by this lane only: no barrier needed
+                mine[ROW / 4 + j * 64 + lane] = b4;
+            }
+        }
+        int my_col = si.grow, my_q = 0;
+        float my_y = 0.0f, my_w = 0.0f;                             // w = 0 past the segment end: no gradient, no output
+        if (si.beg + lane < si.end) {
+            my_col = g.col[si.beg + lane];
+            my_q = inc_pair[si.beg + lane];
+            my_y = y[my_q];
+            my_w = w[my_q];
+        }
+        auto load_rows = [&](float4 (&zv)[U][NJ], float4 (&hv)[U][NJ], int step) {
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                // the entry is wave-uniform: its row address is a scalar, the lane offset a constant
+                const size_t v = (size_t)(unsigned)__builtin_amdgcn_readlane(my_col, (step * U + e) & 63);
+                const float* zr = Z + v * ROW + lane * 4;
+                const float* hr = H + v * ROW + lane * 4;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    zv[e][j] = *reinterpret_cast<const float4*>(zr + j * 256);
+                    hv[e][j] = *reinterpret_cast<const float4*>(hr + j * 256);
+                }
+            }
+        };
+        auto consume = [&](const float4 (&zv)[U][NJ], const float4 (&hv)[U][NJ], int step) {
+            // 16 partial dot products per lane: index = table * 8 + chunk * 4 + entry (z_u . z_v below 8, h_u . h_v above)
+            float val[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) val[x] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float4 a4, b4;
+                if constexpr (UREG) {
+                    a4 = uz[j];
+                    b4 = uh[j];
+                } else {                                            // (one chunk of the node's rows live at a time)
+                    a4 = mine[j * 64 + lane];
+                    b4 = mine[ROW / 4 + j * 64 + lane];
+                }
+#pragma unroll
+                for (int e = 0; e < U; ++e) {
+                    val[j * 4 + e] = fmaf(a4.w, zv[e][j].w, fmaf(a4.z, zv[e][j].z, fmaf(a4.y, zv[e][j].y, a4.x * zv[e][j].x)));
+                    val[8 + j * 4 + e] = fmaf(b4.w, hv[e][j].w, fmaf(b4.z, hv[e][j].z, fmaf(b4.y, hv[e][j].y, b4.x * hv[e][j].x)));
+                }
+                if constexpr (!UREG) __builtin_amdgcn_sched_barrier(0);   // keep the chunks apart: fewer temporaries live at once
+            }
+            // 16 values over the 16 lanes of the DPP row, halving the value count at every exchange: lane i ends with the
+            // complete sum number i — lanes 0..7: z_u . z_v of (chunk i / 4, entry i % 4), lanes 8..15: h_u . h_v of the same
+            TransposedReduce<16, 8>::run(val, i);
+            const float mine_v = val[0];
+            // ONE expf for the step (lanes 8..15 exponentiate a value nobody reads) ...
+            const float ex = expf(T1 ? mine_v : mine_v / t);
+            // ... its partner lane (i ^ 8) forms (h_u . h_v) exp(z_u . z_v / t); two chunks of an entry sit 4 lanes apart
+            const float ttv = mine_v * xor_lane<8>(ex);                                      // valid in lanes 8..15
+            float term = ttv;
+            if constexpr (NJ == 2) term += dpp_mov<0x104>(ttv);                               // row_shl:4: lane 8 + e takes 12 + e
+            const float logit = add_xor<32>(add_xor<16>(term));                              // lanes 8..11: entry i - 8, all 4 rows
+            const float p = sigmoid_ref(logit);
+            const int idx = step * U + (i & 3);
+            const float yy = __shfl(my_y, idx, DL_WAVE), ww = __shfl(my_w, idx, DL_WAVE);
+            const int qq = __shfl(my_q, idx, DL_WAVE);
+            // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(q, 1e-12) * q with q = p (1 - p) — i.e.
+            // w (p - y) itself unless q underflows the clamp (saturated scores: q = 0 gives exactly 0), without the division
+            const float pr = p * (1.0f - p);
+            const float gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (pr >= 1e-12f ? 1.0f : pr * 1e12f);
+            if (lane >= 8 && lane < 12 && si.beg + idx < si.end) prob_out[qq] = p;
+            // 0 * inf must stay 0: an overflowed exponent saturates p, so its gl is exactly 0 — the factors are clamped to
+            // the largest finite value (finite values pass unchanged, a NaN gl still gives NaN) instead of branching
+            const float exc = fminf(ex, 3.402823466e38f);
+            const float ttc = __builtin_amdgcn_fmed3f(T1 ? ttv : ttv / t, -3.402823466e38f, 3.402823466e38f);
+            float ge[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) ge[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), 8 + e));   // scalars
+            float Eb[NJ][U], Tb[NJ][U];                              // this row's factors' terms, handed to all its lanes
+            Eb[0][0] = row_bcast<0>(exc); Eb[0][1] = row_bcast<1>(exc); Eb[0][2] = row_bcast<2>(exc); Eb[0][3] = row_bcast<3>(exc);
+            Tb[0][0] = row_bcast<8>(ttc); Tb[0][1] = row_bcast<9>(ttc); Tb[0][2] = row_bcast<10>(ttc); Tb[0][3] = row_bcast<11>(ttc);
+            if constexpr (NJ == 2) {
+                Eb[1][0] = row_bcast<4>(exc); Eb[1][1] = row_bcast<5>(exc); Eb[1][2] = row_bcast<6>(exc); Eb[1][3] = row_bcast<7>(exc);
+                Tb[1][0] = row_bcast<12>(ttc); Tb[1][1] = row_bcast<13>(ttc); Tb[1][2] = row_bcast<14>(ttc); Tb[1][3] = row_bcast<15>(ttc);
+            }
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float ch = ge[e] * Eb[j][e];
+                    const float cz = ge[e] * Tb[j][e];
+                    ah[j].x = fmaf(ch, hv[e][j].x, ah[j].x); ah[j].y = fmaf(ch, hv[e][j].y, ah[j].y);
+                    ah[j].z = fmaf(ch, hv[e][j].z, ah[j].z); ah[j].w = fmaf(ch, hv[e][j].w, ah[j].w);
+                    az[j].x = fmaf(cz, zv[e][j].x, az[j].x); az[j].y = fmaf(cz, zv[e][j].y, az[j].y);
+                    az[j].z = fmaf(cz, zv[e][j].z, az[j].z); az[j].w = fmaf(cz, zv[e][j].w, az[j].w);
+                }
+            }
+        };
+        const int nsteps = (si.end - si.beg + U - 1) / U;           // entries past the end repeat a valid row with w = 0
+        float4 zA[U][NJ], hA[U][NJ];
+        if constexpr (PIPE) {
+            float4 zB[U][NJ], hB[U][NJ];
+            if (nsteps > 0) load_rows(zA, hA, 0);
+            int s = 0;
+            // (the scheduling barriers keep the stages in THIS order: left alone, the scheduler renames a register set and
+            // hoists its loads over the step that still reads the old copy — three sets live, 42 spilled registers)
+            for (; s + 2 < nsteps; s += 2) {                        // straight-line body: waits are vmcnt(<loads of the newer set>)
+                __builtin_amdgcn_sched_barrier(0);
+                load_rows(zB, hB, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(zA, hA, s);
+                __builtin_amdgcn_sched_barrier(0);
+                load_rows(zA, hA, s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(zB, hB, s + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nsteps - s == 2) {
+                load_rows(zB, hB, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(zA, hA, s);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(zB, hB, s + 1);
+            } else if (nsteps - s == 1) {
+                consume(zA, hA, s);
+            }
+        } else {
+            for (int s = 0; s < nsteps; ++s) {
+                load_rows(zA, hA, s);
+                consume(zA, hA, s);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            mine[j * 64 + lane] = az[j];
+            mine[ROW / 4 + j * 64 + lane] = ah[j];
+        }
+    }
+    __syncthreads();
+    if (!ws.head) return;
+    float4 o[US::NQ];
+    US::sum(red, wave, ws.n_unit, lane, o);
+#pragma unroll
+    for (int q = 0; q < US::NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < US::F4) {
+            if (si.slot < 0) {
+                float* dst = x < ROW / 4 ? dZ + (size_t)si.grow * ROW + 4 * x : dH + (size_t)si.grow * ROW + 4 * (x - ROW / 4);
+                store4(dst, o[q]);
+            } else {
+                store4(part + (size_t)si.slot * 2 * ROW + 4 * x, o[q]);       // [dZ row | dH row]
             }
         }
     }
@@ -1313,6 +1547,26 @@ struct Ops {
                            const float* w, float* prob, float* dZ, float* dH, float* part, hipStream_t st) {
         const dl_csr_plan* g = &inc->csr;
         const float* no_x = nullptr;
+        if constexpr (std::is_same<T, float>::value && TrainWave<K, D>::ok) {
+            if (g->seg_len <= 64 && g->seg_len % TrainWave<K, D>::U == 0 && !getenv("DL_TRAIN_GROUP_KERNEL")) {
+                static const bool pipe = getenv("DL_TRAIN_PIPE") ? atoi(getenv("DL_TRAIN_PIPE")) != 0 : (DL_TRAIN_PIPE != 0);
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair, (const float*)Z,
+                                       (const float*)H, t, dZ, dH, part, y, w, prob);
+                };
+                if (t == 1.0f) {
+                    if (pipe) launch(score_train_wave_kernel<K, D, true, true>);
+                    else launch(score_train_wave_kernel<K, D, true, false>);
+                } else {
+                    if (pipe) launch(score_train_wave_kernel<K, D, false, true>);
+                    else launch(score_train_wave_kernel<K, D, false, false>);
+                }
+                if (g->n_multi > 0)
+                    hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g,
+                                       part, 2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
+                return check_launch("score_pairs_train(fast, wave per entry)");
+            }
+        }
         hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,
                            (const T*)Z, (const T*)H, t, no_x, no_x, dZ, dH, part, y, w, prob);
         if (g->n_multi > 0)

@@ -1649,8 +1649,8 @@ def test_stacked_adam_is_torch_adam(use_graph, monkeypatch):
     make = optim.StackedAdam
     for mode in ("stacked_torch_kernel", "torch", "stacked_dl_kernel"):
         monkeypatch.setattr(train, "_STACKED_ADAM", mode != "torch")
-        monkeypatch.setattr(optim, "StackedAdam", (lambda *a, **k: make(*a, use_torch_kernel=True, **k))
-                            if mode == "stacked_torch_kernel" else make)
+        # DL_ADAM_KERNEL=torch: torch._fused_adam_ over the stacked buffers (the switch parity runs use)
+        monkeypatch.setattr(train, "_ADAM_KERNEL", "torch" if mode == "stacked_torch_kernel" else "dl")
         torch.manual_seed(0)
         model = Disentangle(sg.n_feat, 64, 64, nfactor=8, beta=0.6, t=1).to(DEV)
         res = train.run_link_prediction(model, x, run, epochs=12, lr=1e-3, use_graph=use_graph)

@@ -9,7 +9,7 @@ src = sys.argv[1]
 pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else re.compile(".")
 only_spills = "--spills" in sys.argv
 out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Iinclude",
-                      "-Idisenlink_amd/csrc", "-c", src, "-o", "/tmp/kr.o", "-Rpass-analysis=kernel-resource-usage"],
+                      "-Idisenlink_amd/csrc", *__import__("os").environ.get("DL_CXXFLAGS","").split(), "-c", src, "-o", "/tmp/kr.o", "-Rpass-analysis=kernel-resource-usage"],
                      capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
