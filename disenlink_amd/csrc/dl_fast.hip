@@ -1067,19 +1067,24 @@ __global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score
 // ---------------------------------------------------------------------------- one-pass training scorer, wave per entry
 // Round 4.  The kernel above gives every entry to a group of 16 lanes (4 entries per wave step): each lane then carries
 // the WHOLE K x 2 accumulator set (64 registers, replicated in all four groups) next to the 64 registers of gathered
-// rows — 165 registers, three waves per SIMD, and no room to request the next rows before the current ones are used:
-// it issues 16 loads, waits for all of them, runs ~270 vector instructions, and only then asks for the next 16 KB.
-// Measured on squirrel: the vector pipe 51 % busy, the L1 at 48 % of its 64 B/clk, neither hidden behind the other.
+// rows — 165 registers, three waves per SIMD.  Measured on squirrel: the vector pipe 51 % busy, the L1 at 48 % of its
+// 64 B/clk, neither hidden behind the other.
 //
 // Here the 64 lanes of the wave share ONE entry: lane l holds float4 number j * 64 + l of a row (j < NJ = K*D/256), i.e.
 // with D = 64 a DPP row of 16 lanes holds one factor slice.  Per lane: 2 NJ accumulators (16 registers at K = 8
-// instead of 64), the node's own rows in 16 registers instead of LDS reads, and U = 4 entries per step in flight.
-// That leaves room for TWO register sets of gathered rows: the rows of step s + 1 are requested before step s is
-// computed (software pipelining; the loop body is straight-line code — behind a join the compiler's wait-count
-// insertion assumes the arm that issued no loads and waits for everything outstanding).  Per step the 4 entries share
-// one expf (8 (entry, factor) exponents live in 8 lanes of a row) and one sigmoid (entry e's logit is summed into DPP
-// row e by a transposed reduction over the four rows), so the per-entry vector work stays what it was.
+// instead of 64, and no sum over lane groups at the end), the node's own rows re-read from the wave's LDS region, the
+// per-entry scalars (label, weight, pair id) in LDS too, row addresses as scalar base + lane offset: 128 registers, FOUR
+// waves per SIMD.  A step still gathers U = 4 entries (16 KB per wave in flight).  The 16 partial dot products of a
+// step (4 entries x 2 chunks x {z.z, h.h}) are reduced over the 16 lanes of the DPP row by ONE transposed reduction
+// (lane i ends with complete sum number i), so the step needs one expf (lanes 0..7) and one sigmoid (lanes 8..15),
+// and the two coefficients of every (entry, chunk) are formed in the lane that holds them and handed to the row by
+// row_newbcast moves: 226 vector instructions per step against 271 above.
 // Entries are accumulated in ascending order by every lane: the sums depend on the row alone (shard-independent).
+// Same-box A/B (tools/r4_train_ab.sh): real squirrel 442 -> 387 us, chameleon 96 -> 78.
+// Tried and dropped: a second register set with the next step's rows requested before the current step is computed
+// (two waves per SIMD; hipcc renamed the sets in the two-step unrolled loop, kept three of them live and spilled 28-50
+// registers: 630-980 us); the per-value xor / rotation all-reduces instead of the transposed reduction (+35 instructions
+// per step, the same time: at four waves the kernel is not bound by vector issue).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {             // old value undefined: no zeroing move in front of the DPP move
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -1101,11 +1106,18 @@ __device__ __forceinline__ float row_allreduce_sum(float v) {
     return add_dpp<0x121>(v);   // row_ror:1
 }
 
+// 4-element dot product as two packed operations and one add (v_pk_mul_f32, v_pk_fma_f32: two lanes of fp32 per
+// instruction on gfx950) instead of a chain of four; symmetric in its arguments, so both endpoints of a pair still
+// compute the same bits.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot4_packed(const float4& a, const float4& b) {
+    const v2f a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    const v2f p = __builtin_elementwise_fma(a1, b1, a0 * b0);
+    return p.x + p.y;
+}
+
 #ifndef DL_TRAIN_WAVE_KERNEL
 #define DL_TRAIN_WAVE_KERNEL 1        // -DDL_TRAIN_WAVE_KERNEL=0: the group-per-entry kernel above, for A/B runs
-#endif
-#ifndef DL_TRAIN_PIPE
-#define DL_TRAIN_PIPE 0               // 1 (or env DL_TRAIN_PIPE=1): a second register set, the next rows requested before the current step is computed
 #endif
 template <int K, int D>
 struct TrainWave {
@@ -1114,8 +1126,8 @@ struct TrainWave {
     static constexpr int U = 4;                                     // entries per step
 };
 
-template <int K, int D, bool T1, bool PIPE, bool UREG = PIPE>
-__global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_train_wave_kernel(
+template <int K, int D, bool T1, bool UREG = false>
+__global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel(
         dl_csr_plan g, const int32_t* __restrict__ inc_pair, const float* __restrict__ Z, const float* __restrict__ H, float t,
         float* __restrict__ dZ, float* __restrict__ dH, float* __restrict__ part, const float* __restrict__ y,
         const float* __restrict__ w, float* __restrict__ prob_out) {
@@ -1124,6 +1136,8 @@ __global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_trai
     static_assert(D == 64 && NJ >= 1 && NV <= 8, "one DPP row of 16 lanes per factor slice; at most 8 exponents per row and step");
     using US = Stage<K, D, float, 2, true>;                         // one [dZ row | dH row] per wave for the unit sum
     __shared__ __attribute__((aligned(16))) float red[US::FLOATS];
+    __shared__ float ent_y[WAVES_PER_BLOCK][DL_WAVE], ent_w[WAVES_PER_BLOCK][DL_WAVE];     // per-entry scalars of the segment:
+    __shared__ int ent_q[WAVES_PER_BLOCK][DL_WAVE];                                        // 3 registers fewer than lane copies
     const WaveSeg ws = load_wave_seg(g);
     const SegInfo si = ws.si;
     const int wave = ws.wave, lane = lane_id();
@@ -1148,21 +1162,32 @@ __global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_trai
                 mine[ROW / 4 + j * 64 + lane] = b4;
             }
         }
-        int my_col = si.grow, my_q = 0;
-        float my_y = 0.0f, my_w = 0.0f;                             // w = 0 past the segment end: no gradient, no output
-        if (si.beg + lane < si.end) {
-            my_col = g.col[si.beg + lane];
-            my_q = inc_pair[si.beg + lane];
-            my_y = y[my_q];
-            my_w = w[my_q];
+        int my_col = si.grow;
+        {
+            int my_q = 0;
+            float my_y = 0.0f, my_w = 0.0f;                         // w = 0 past the segment end: no gradient, no output
+            if (si.beg + lane < si.end) {
+                my_col = g.col[si.beg + lane];
+                my_q = inc_pair[si.beg + lane];
+                my_y = y[my_q];
+                my_w = w[my_q];
+            }
+            ent_y[wave][lane] = my_y;                               // written and read by this wave only: no barrier
+            ent_w[wave][lane] = my_w;
+            ent_q[wave][lane] = my_q;
         }
         auto load_rows = [&](float4 (&zv)[U][NJ], float4 (&hv)[U][NJ], int step) {
 #pragma unroll
             for (int e = 0; e < U; ++e) {
                 // the entry is wave-uniform: its row address is a scalar, the lane offset a constant
                 const size_t v = (size_t)(unsigned)__builtin_amdgcn_readlane(my_col, (step * U + e) & 63);
-                const float* zr = Z + v * ROW + lane * 4;
-                const float* hr = H + v * ROW + lane * 4;
+                // the row base stays a SCALAR (the empty asm keeps the compiler from folding the loop-invariant lane offset
+                // into a hoisted 64-bit vector base per table): global_load ... v_lane_offset, s[base] — 3 registers fewer
+                const float* zs = Z + v * ROW;
+                const float* hs = H + v * ROW;
+                asm volatile("" : "+s"(zs), "+s"(hs));
+                const float* zr = zs + lane * 4;
+                const float* hr = hs + lane * 4;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     zv[e][j] = *reinterpret_cast<const float4*>(zr + j * 256);
@@ -1187,8 +1212,8 @@ __global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_trai
                 }
 #pragma unroll
                 for (int e = 0; e < U; ++e) {
-                    val[j * 4 + e] = fmaf(a4.w, zv[e][j].w, fmaf(a4.z, zv[e][j].z, fmaf(a4.y, zv[e][j].y, a4.x * zv[e][j].x)));
-                    val[8 + j * 4 + e] = fmaf(b4.w, hv[e][j].w, fmaf(b4.z, hv[e][j].z, fmaf(b4.y, hv[e][j].y, b4.x * hv[e][j].x)));
+                    val[j * 4 + e] = dot4_packed(a4, zv[e][j]);
+                    val[8 + j * 4 + e] = dot4_packed(b4, hv[e][j]);
                 }
                 if constexpr (!UREG) __builtin_amdgcn_sched_barrier(0);   // keep the chunks apart: fewer temporaries live at once
             }
@@ -1201,37 +1226,37 @@ __global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_trai
             // ... its partner lane (i ^ 8) forms (h_u . h_v) exp(z_u . z_v / t); two chunks of an entry sit 4 lanes apart
             const float ttv = mine_v * xor_lane<8>(ex);                                      // valid in lanes 8..15
             float term = ttv;
-            if constexpr (NJ == 2) term += dpp_mov<0x104>(ttv);                               // row_shl:4: lane 8 + e takes 12 + e
-            const float logit = add_xor<32>(add_xor<16>(term));                              // lanes 8..11: entry i - 8, all 4 rows
+            if constexpr (NJ == 2) term += xor_lane<4>(ttv);                                  // lanes 8..15: entry i % 4, both chunks
+            const float logit = add_xor<32>(add_xor<16>(term));                              // ... over the 4 rows (all factors)
             const float p = sigmoid_ref(logit);
             const int idx = step * U + (i & 3);
-            const float yy = __shfl(my_y, idx, DL_WAVE), ww = __shfl(my_w, idx, DL_WAVE);
-            const int qq = __shfl(my_q, idx, DL_WAVE);
+            const float yy = ent_y[wave][idx & 63], ww = ent_w[wave][idx & 63];
+            const int qq = ent_q[wave][idx & 63];
             // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(q, 1e-12) * q with q = p (1 - p) — i.e.
             // w (p - y) itself unless q underflows the clamp (saturated scores: q = 0 gives exactly 0), without the division
             const float pr = p * (1.0f - p);
-            const float gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (pr >= 1e-12f ? 1.0f : pr * 1e12f);
+            const float gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (pr >= 1e-12f ? 1.0f : pr * 1e12f);     // valid in lanes 8..15
             if (lane >= 8 && lane < 12 && si.beg + idx < si.end) prob_out[qq] = p;
-            // 0 * inf must stay 0: an overflowed exponent saturates p, so its gl is exactly 0 — the factors are clamped to
-            // the largest finite value (finite values pass unchanged, a NaN gl still gives NaN) instead of branching
+            // the two coefficients of (entry, chunk), formed ONCE in the lane that holds its exponent / its product and
+            // handed to the row afterwards: lanes 0..7: gl e^., lanes 8..15: gl (h.h) e^. / t.  0 * inf must stay 0 (an
+            // overflowed exponent saturates p, so its gl is exactly 0): the factors are clamped to the largest finite value
+            // first — finite values pass unchanged, a NaN gl still gives NaN
             const float exc = fminf(ex, 3.402823466e38f);
             const float ttc = __builtin_amdgcn_fmed3f(T1 ? ttv : ttv / t, -3.402823466e38f, 3.402823466e38f);
-            float ge[U];
-#pragma unroll
-            for (int e = 0; e < U; ++e) ge[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), 8 + e));   // scalars
-            float Eb[NJ][U], Tb[NJ][U];                              // this row's factors' terms, handed to all its lanes
-            Eb[0][0] = row_bcast<0>(exc); Eb[0][1] = row_bcast<1>(exc); Eb[0][2] = row_bcast<2>(exc); Eb[0][3] = row_bcast<3>(exc);
-            Tb[0][0] = row_bcast<8>(ttc); Tb[0][1] = row_bcast<9>(ttc); Tb[0][2] = row_bcast<10>(ttc); Tb[0][3] = row_bcast<11>(ttc);
+            const float coef = (i & 8) ? gl * ttc : xor_lane<8>(gl) * exc;
+            float Eb[NJ][U], Tb[NJ][U];
+            Eb[0][0] = row_bcast<0>(coef); Eb[0][1] = row_bcast<1>(coef); Eb[0][2] = row_bcast<2>(coef); Eb[0][3] = row_bcast<3>(coef);
+            Tb[0][0] = row_bcast<8>(coef); Tb[0][1] = row_bcast<9>(coef); Tb[0][2] = row_bcast<10>(coef); Tb[0][3] = row_bcast<11>(coef);
             if constexpr (NJ == 2) {
-                Eb[1][0] = row_bcast<4>(exc); Eb[1][1] = row_bcast<5>(exc); Eb[1][2] = row_bcast<6>(exc); Eb[1][3] = row_bcast<7>(exc);
-                Tb[1][0] = row_bcast<12>(ttc); Tb[1][1] = row_bcast<13>(ttc); Tb[1][2] = row_bcast<14>(ttc); Tb[1][3] = row_bcast<15>(ttc);
+                Eb[1][0] = row_bcast<4>(coef); Eb[1][1] = row_bcast<5>(coef); Eb[1][2] = row_bcast<6>(coef); Eb[1][3] = row_bcast<7>(coef);
+                Tb[1][0] = row_bcast<12>(coef); Tb[1][1] = row_bcast<13>(coef); Tb[1][2] = row_bcast<14>(coef); Tb[1][3] = row_bcast<15>(coef);
             }
 #pragma unroll
             for (int e = 0; e < U; ++e) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const float ch = ge[e] * Eb[j][e];
-                    const float cz = ge[e] * Tb[j][e];
+                    const float ch = Eb[j][e];
+                    const float cz = Tb[j][e];
                     ah[j].x = fmaf(ch, hv[e][j].x, ah[j].x); ah[j].y = fmaf(ch, hv[e][j].y, ah[j].y);
                     ah[j].z = fmaf(ch, hv[e][j].z, ah[j].z); ah[j].w = fmaf(ch, hv[e][j].w, ah[j].w);
                     az[j].x = fmaf(cz, zv[e][j].x, az[j].x); az[j].y = fmaf(cz, zv[e][j].y, az[j].y);
@@ -1241,37 +1266,9 @@ __global__ __launch_bounds__(BLOCK, (PIPE ? 2 : (UREG ? 3 : 4))) void score_trai
         };
         const int nsteps = (si.end - si.beg + U - 1) / U;           // entries past the end repeat a valid row with w = 0
         float4 zA[U][NJ], hA[U][NJ];
-        if constexpr (PIPE) {
-            float4 zB[U][NJ], hB[U][NJ];
-            if (nsteps > 0) load_rows(zA, hA, 0);
-            int s = 0;
-            // (the scheduling barriers keep the stages in THIS order: left alone, the scheduler renames a register set and
-            // hoists its loads over the step that still reads the old copy — three sets live, 42 spilled registers)
-            for (; s + 2 < nsteps; s += 2) {                        // straight-line body: waits are vmcnt(<loads of the newer set>)
-                __builtin_amdgcn_sched_barrier(0);
-                load_rows(zB, hB, s + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(zA, hA, s);
-                __builtin_amdgcn_sched_barrier(0);
-                load_rows(zA, hA, s + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(zB, hB, s + 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (nsteps - s == 2) {
-                load_rows(zB, hB, s + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(zA, hA, s);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(zB, hB, s + 1);
-            } else if (nsteps - s == 1) {
-                consume(zA, hA, s);
-            }
-        } else {
-            for (int s = 0; s < nsteps; ++s) {
-                load_rows(zA, hA, s);
-                consume(zA, hA, s);
-            }
+        for (int s = 0; s < nsteps; ++s) {
+            load_rows(zA, hA, s);
+            consume(zA, hA, s);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -1549,18 +1546,12 @@ struct Ops {
         const float* no_x = nullptr;
         if constexpr (std::is_same<T, float>::value && TrainWave<K, D>::ok) {
             if (g->seg_len <= 64 && g->seg_len % TrainWave<K, D>::U == 0 && !getenv("DL_TRAIN_GROUP_KERNEL")) {
-                static const bool pipe = getenv("DL_TRAIN_PIPE") ? atoi(getenv("DL_TRAIN_PIPE")) != 0 : (DL_TRAIN_PIPE != 0);
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair, (const float*)Z,
                                        (const float*)H, t, dZ, dH, part, y, w, prob);
                 };
-                if (t == 1.0f) {
-                    if (pipe) launch(score_train_wave_kernel<K, D, true, true>);
-                    else launch(score_train_wave_kernel<K, D, true, false>);
-                } else {
-                    if (pipe) launch(score_train_wave_kernel<K, D, false, true>);
-                    else launch(score_train_wave_kernel<K, D, false, false>);
-                }
+                if (t == 1.0f) launch(score_train_wave_kernel<K, D, true>);
+                else launch(score_train_wave_kernel<K, D, false>);
                 if (g->n_multi > 0)
                     hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g,
                                        part, 2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
