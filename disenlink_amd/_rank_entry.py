@@ -1,6 +1,8 @@
-"""Script form of ``python -m disenlink_amd.main`` for torch.distributed.run: its argument parser takes a SCRIPT PATH
-followed by the script's arguments verbatim, whereas after ``-m module`` it still tries to match the module's own options
-(``--run`` is "ambiguous" to it).  Started by disenlink_amd/launch.py, one process per rank."""
+"""Rank entry of ``python -m disenlink_amd.main --gpus N`` under torch.distributed.run.  The CLI's own arguments travel in
+the environment (DL_MAIN_ARGV, JSON): torch.distributed.run's argument parser classifies every ``--option`` on its command
+line before it reaches the script's remainder, and the reference's ``--run`` is an ambiguous prefix of its ``--run-path``.
+Started by disenlink_amd/launch.py, one process per rank."""
+import json
 import os
 import sys
 
@@ -8,4 +10,4 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 if __name__ == "__main__":
     from disenlink_amd.main import main
-    main(sys.argv[1:])
+    main(json.loads(os.environ["DL_MAIN_ARGV"]))

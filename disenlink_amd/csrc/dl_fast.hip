@@ -252,7 +252,7 @@ struct Stage {
 // ---------------------------------------------------------------------------- route
 // p[e], a[e] for the entries of the plan's segments.  MIRROR: the plan covers col >= row only and
 // every result is also written to the reverse entry (routing is symmetric, bitwise).
-template <int K, int D, typename T, bool MIRROR>
+template <int K, int D, typename T, bool MIRROR, bool BALLOT = false>
 __global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 6 : (K <= 16 ? 4 : 1))) void route_seg_kernel(dl_csr_plan g, const int32_t* __restrict__ rev,
                                                           const T* __restrict__ Z, float t,
                                                           uint8_t* __restrict__ p, float* __restrict__ a) {
@@ -293,7 +293,31 @@ __global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 
             const float al = ex[i] / S;
             if (kb + i < K && (win == 255 || beats(al, best))) { best = al; win = kb + i; }
         }
-        group_argmax_first<G>(best, win);
+        if constexpr (BALLOT && VPL == 1 && G <= 32) {
+            // BALLOT arg-max (round 4): every lane holds at most one candidate, and lanes follow the factor order — so the
+            // first maximal factor is the lowest set bit of the group's "equals the group maximum" mask: four DPP max
+            // steps, one compare into a wave mask, a shift and a find-first-bit (~14 instructions) instead of four
+            // (value, index) exchange-and-compare steps (32).  torch.argmax order kept: a NaN beats everything, the first
+            // one wins (v_max ignores NaN, so NaN candidates get a mask of their own).
+            const bool valid = win != 255;
+            const bool isn = valid && best != best;
+            float m = valid && !isn ? best : -__builtin_inff();
+            m = fmaxf(m, xor_lane<1>(m));
+            if constexpr (G >= 4) m = fmaxf(m, xor_lane<2>(m));
+            if constexpr (G >= 8) m = fmaxf(m, xor_lane<4>(m));
+            if constexpr (G >= 16) m = fmaxf(m, xor_lane<8>(m));
+            if constexpr (G >= 32) m = fmaxf(m, xor_lane<16>(m));
+            const unsigned long long eqm = __builtin_amdgcn_ballot_w64(valid && best == m);
+            const unsigned long long nam = __builtin_amdgcn_ballot_w64(isn);
+            const int sh = lane & ~(G - 1);
+            constexpr unsigned GM = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
+            const unsigned ge = (unsigned)(eqm >> sh) & GM, gn = (unsigned)(nam >> sh) & GM;
+            const int src = __builtin_ctz(gn ? gn : (ge | (1u << (G - 1))));           // (ge is never empty; the guard bit keeps ctz defined)
+            win = FL::factor_base(src);
+            best = gn ? __builtin_nanf("") : m;
+        } else {
+            group_argmax_first<G>(best, win);
+        }
         if (MIRROR) {
             const int r = __shfl(my_rev, e - si.beg, DL_WAVE);
             if (live && c == 0) { p[e] = (uint8_t)win; a[e] = best; }
@@ -1448,12 +1472,23 @@ struct Ops {
     static int route_fwd(const dl_csr_plan* g, const dl_csr_plan* route, bool mirror, const int32_t* rev,
                          const void* Z, float t, uint8_t* p, float* a, float* s, float* s_part, hipStream_t st) {
         const dl_csr_plan* rp = route ? route : g;
-        if (mirror)
-            hipLaunchKernelGGL((route_seg_kernel<K, D, T, true>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
-                               (const T*)Z, t, p, a);
-        else
-            hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
-                               (const T*)Z, t, p, a);
+        // DL_ROUTE_BALLOT=1: the ballot arg-max (A/B switch; see the kernel)
+        static const bool ballot = getenv("DL_ROUTE_BALLOT") && atoi(getenv("DL_ROUTE_BALLOT")) != 0;
+        if (mirror) {
+            if (ballot)
+                hipLaunchKernelGGL((route_seg_kernel<K, D, T, true, true>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
+                                   (const T*)Z, t, p, a);
+            else
+                hipLaunchKernelGGL((route_seg_kernel<K, D, T, true>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
+                                   (const T*)Z, t, p, a);
+        } else {
+            if (ballot)
+                hipLaunchKernelGGL((route_seg_kernel<K, D, T, false, true>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
+                                   (const T*)Z, t, p, a);
+            else
+                hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
+                                   (const T*)Z, t, p, a);
+        }
         (void)s_part;
         launch_s_rowsum(g, K, p, a, s, st);
         return check_launch("route_fwd(fast)");

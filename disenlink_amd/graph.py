@@ -101,6 +101,26 @@ def _i32(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.int32).contiguous()
 
 
+# Integer handles of live Graph / PairList objects (the registered operators of torch_ops.py take handles, not Python
+# objects).  Held WEAKLY and assigned at construction: reading a handle is then a plain attribute access — traceable by
+# torch.compile — and a caller that builds a new pair list per epoch does not accumulate GPU plans in a registry.
+import itertools
+import weakref
+
+_HANDLES: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDictionary()
+_next_handle = itertools.count(1)
+
+
+def _assign_handle(obj) -> None:
+    obj._dl_handle = next(_next_handle)
+    _HANDLES[obj._dl_handle] = obj
+
+
+def by_handle(handle: int, kind):
+    obj = _HANDLES.get(int(handle))
+    return obj if isinstance(obj, kind) else None
+
+
 @dataclass
 class CsrPlan:
     """Rows [row_offset, row_offset + n_rows) of a CSR over n_total nodes + its segment plan.
@@ -295,6 +315,9 @@ class Graph:
                                          # edge is computed once and written to both entries through rev
     _struct: _lib.DlGraph | None = field(default=None, repr=False)
 
+    def __post_init__(self):
+        _assign_handle(self)
+
     # convenience views
     n_nodes = property(lambda self: self.plan.n_total)
     n_rows = property(lambda self: self.plan.n_rows)
@@ -401,6 +424,9 @@ class PairList:
     inc_pair: torch.Tensor
     _struct: _lib.DlPairIncidence | None = field(default=None, repr=False)
     _struct_u: _lib.DlPairIncidence | None = field(default=None, repr=False)
+
+    def __post_init__(self):
+        _assign_handle(self)
 
     @property
     def n_pairs(self) -> int:

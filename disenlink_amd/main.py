@@ -139,7 +139,9 @@ def main(argv=None):
         from .launch import launch_ranks, under_launcher
         if not under_launcher():                                    # BEFORE any GPU call: the parent starts and waits
             entry = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_entry.py")
-            raise SystemExit(launch_ranks(args.gpus, [entry], list(sys.argv[1:] if argv is None else argv)))
+            import json
+            raise SystemExit(launch_ranks(args.gpus, [entry], [], env_extra={
+                "DL_MAIN_ARGV": json.dumps(list(sys.argv[1:] if argv is None else argv))}))
         if args.no_cuda or not torch.cuda.is_available():
             raise SystemExit("disenlink_amd runs on the GPU only (libdisenlink_hip.so has no CPU fallback)")
         return main_sharded(args)

@@ -449,10 +449,12 @@ def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True, keep_hid: bool = 
     return (Z, hid) if keep_hid else Z
 
 
-def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
+def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None, one_allocation: bool = True):
     """Weight / bias gradients of the projection from dZ [N,K,d]: (dW1, db1, dW2, db2), shaped like the weights
     (dW2 = db2 = None for the single layer).  autograd of model.py:13-15 / 24-27.  hid: the hidden layer kept
-    by project_fwd(keep_hid=True), else it is recomputed."""
+    by project_fwd(keep_hid=True), else it is recomputed.  one_allocation: the gradients are views of ONE flat buffer (the
+    sharded step all-reduces it as it is); False gives four separate tensors (registered operators may not return
+    outputs that share storage)."""
     lib = _lib.load()
     x, W1, b1, dZ = _f32c(x), _f32c(W1), _f32c(b1), _f32c(dZ)
     _need_cuda(x, W1, b1, dZ)
@@ -468,10 +470,10 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
         dZp = torch.nn.functional.pad(dZ, (0, dp - d_true))
         if W2 is None:
             W1p, b1p = _pad_out_rows(W1, b1, dp)
-            dW1, db1, _n1, _n2 = project_bwd(x, W1p, b1p, None, dZp, pad=pad)
+            dW1, db1, _n1, _n2 = project_bwd(x, W1p, b1p, None, dZp, pad=pad, one_allocation=one_allocation)
             return dW1[:, :d_true].contiguous(), db1[:, :d_true].contiguous(), None, None
         W2p = torch.nn.functional.pad(_f32c(W2), (0, 0, 0, dp - d_true))
-        dW1, db1, dW2, db2 = project_bwd(x, W1, b1, W2p, dZp, pad=pad, hid=hid)
+        dW1, db1, dW2, db2 = project_bwd(x, W1, b1, W2p, dZp, pad=pad, hid=hid, one_allocation=one_allocation)
         return dW1, db1, dW2[:, :d_true].contiguous(), db2[:, :d_true].contiguous()
     F_true = x.shape[1]
     if pad:
@@ -490,7 +492,7 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None):
     # them as one flat tensor without packing (dist.allreduce_gradients), every piece 16-byte aligned
     shapes = [tuple(W1.shape), tuple(b1.shape)] + ([tuple(W2.shape), (K, d)] if two else [])
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
-    if all(n % 4 == 0 for n in sizes):
+    if one_allocation and all(n % 4 == 0 for n in sizes):
         flat = _empty((sum(sizes),), torch.float32, x.device)
         parts, off = [], 0
         for sh, n in zip(shapes, sizes):

@@ -18,64 +18,49 @@ scorer: model.py:109-113, backward: autograd under main_disentangled.py:198).
 """
 from __future__ import annotations
 
-import weakref
-
 import torch
 from torch import Tensor
 
 from . import _lib, ops
-from .graph import Graph, PairList
+from .graph import Graph, PairList, by_handle
 
-# handle -> object, held WEAKLY: an operator call holds its Graph / PairList through the caller's own reference (the
-# module's forward_pairs has them as arguments), so a caller that builds a new Graph or PairList per epoch (resampled
-# negatives, sweeps) does not accumulate their GPU plans here.  The handle is remembered on the object itself.
-_graphs: "weakref.WeakValueDictionary[int, Graph]" = weakref.WeakValueDictionary()
-_pairs: "weakref.WeakValueDictionary[int, PairList]" = weakref.WeakValueDictionary()
+# Handles live in disenlink_amd/graph.py: assigned when a Graph / PairList is BUILT and held weakly there — an operator
+# call holds its objects through the caller's own references (the module's forward_pairs has them as arguments), so a
+# caller that builds a new Graph or PairList per epoch (resampled negatives, sweeps) accumulates nothing here.
 _pinned: dict[int, object] = {}            # register_*(…, pin=True): kept alive until release(handle)
-_next = [1]
-
-
-def _register(table, obj, pin: bool) -> int:
-    h = getattr(obj, "_dl_handle", None)
-    if h is None or table.get(h) is not obj:
-        h = _next[0]
-        _next[0] += 1
-        obj._dl_handle = h
-        table[h] = obj
-    if pin:
-        _pinned[h] = obj
-    return h
 
 
 def register_graph(g: Graph, pin: bool = False) -> int:
-    """-> handle of `g` for the operators below (idempotent per object).  The registry does NOT keep the graph alive
-    unless ``pin=True`` (then until ``release(handle)``): keep your own reference for as long as operators use it."""
-    return _register(_graphs, g, pin)
+    """-> handle of `g` for the operators below (a plain attribute read: torch.compile traces it).  Nothing keeps the
+    graph alive unless ``pin=True`` (then until ``release(handle)``): hold your own reference while operators use it."""
+    if pin:
+        _pinned[g._dl_handle] = g
+    return g._dl_handle
 
 
 def register_pairs(p: PairList, pin: bool = False) -> int:
-    return _register(_pairs, p, pin)
+    if pin:
+        _pinned[p._dl_handle] = p
+    return p._dl_handle
 
 
 def release(handle: int) -> None:
-    """Forget a handle (and drop the pin, if any).  Unpinned handles vanish by themselves with their object."""
+    """Drop the pin of a handle, if any.  Handles vanish by themselves with their object."""
     _pinned.pop(handle, None)
-    _graphs.pop(handle, None)
-    _pairs.pop(handle, None)
 
 
 def _g(h: int) -> Graph:
-    try:
-        return _graphs[h]
-    except KeyError:
-        raise ValueError(f"no graph registered under handle {h} (torch_ops.register_graph)") from None
+    g = by_handle(h, Graph)
+    if g is None:
+        raise ValueError(f"no graph registered under handle {h} (torch_ops.register_graph; the object must still be alive)")
+    return g
 
 
 def _p(h: int) -> PairList:
-    try:
-        return _pairs[h]
-    except KeyError:
-        raise ValueError(f"no pair list registered under handle {h} (torch_ops.register_pairs)") from None
+    p = by_handle(h, PairList)
+    if p is None:
+        raise ValueError(f"no pair list registered under handle {h} (torch_ops.register_pairs; the object must still be alive)")
+    return p
 
 
 # ---------------------------------------------------------------------------------------------- routing + aggregation
@@ -212,7 +197,7 @@ def _(x, W1, b1, W2, b2):
 @torch.library.custom_op("disenlink::project_bwd", mutates_args=(), device_types="cuda")
 def project_bwd(x: Tensor, W1: Tensor, b1: Tensor, W2: Tensor, dZ: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
     """(dW1, db1, dW2, db2) — dl_project_bwd (the hidden layer is recomputed)"""
-    return ops.project_bwd(x, W1, b1, W2, dZ.contiguous())
+    return ops.project_bwd(x, W1, b1, W2, dZ.contiguous(), one_allocation=False)
 
 
 @project_bwd.register_fake
