@@ -102,6 +102,31 @@ def pmc_traffic(workload_key: str, phases=None):
     return out, entry.get("source", "profiles/pmc_traffic_latest.json")
 
 
+PMC_L2_SUMMARY = os.path.join(ROOT, "profiles", "pmc_l2_latest.json")
+
+
+def pmc_l2(workload_key: str, phases=None):
+    """Bytes the compute units REQUESTED from the XCD L2s per launch and phase (rocprofv3 TCC_READ / TCC_WRITE passes,
+    tools/pmc_l2_run.sh: reads x 128 B + writes x 64 B) — the counter behind `moved_bytes` — with the L2 hit rate, or None
+    when no pass exists for this workload or it belongs to other kernel sources."""
+    try:
+        entry = json.load(open(PMC_L2_SUMMARY)).get(workload_key)
+    except (OSError, ValueError):
+        return None
+    if not entry or entry.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    out = {}
+    for phase, kernels in (phases or PHASE_KERNELS).items():
+        tot, hit, miss = 0.0, 0.0, 0.0
+        for kname, v in entry["kernels"].items():
+            if kname.split("<")[0].split("::")[-1] in kernels:
+                tot += v["l2_bytes"]
+                hit += v["hit"]
+                miss += v["miss"]
+        out[phase] = dict(l2_bytes=tot, hit_rate=hit / (hit + miss) if hit + miss > 0 else None)
+    return out
+
+
 HBM_ACHIEVABLE_FRAC = 6.3 / 8.0     # MI355X_MICROARCH.md §HBM: ~6.3 of the 8 TB/s are achievable
 
 
@@ -252,20 +277,25 @@ def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=
                 seconds_per_pass=med)
 
 
-def steady_warmup(run_block, min_s=0.3, tol=0.02, max_s=4.0):
+WARM_S = [0.3]          # --warm-s / --min-region-s (profiler passes set both to 0: a PMC pass serialises every launch)
+REGION_S = [1.0]
+
+
+def steady_warmup(run_block, min_s=None, tol=0.02, max_s=4.0):
     """Blocks of the step (run_block() -> seconds for one block, synchronised) until >= min_s have elapsed AND three
     consecutive blocks agree within tol (or max_s is up) -> (blocks run, seconds spent, settled?)."""
+    min_s = WARM_S[0] if min_s is None else min(min_s, WARM_S[0])
     hist, t0 = [], time.perf_counter()
     while True:
         hist.append(run_block())
         el = time.perf_counter() - t0
         last = hist[-3:]
         settled = len(last) == 3 and (max(last) - min(last)) <= tol * min(last)
-        if (el >= min_s and settled) or el >= max_s:
+        if (el >= min_s and (settled or min_s == 0.0)) or el >= max_s:
             return len(hist), el, settled
 
 
-def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats, min_region_s=1.0, info=None):
+def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats, min_region_s=None, info=None):
     """-> (per-block seconds per step, per-phase kernel seconds (HIP events on the launch stream, median)).
     W warm-up steps, warm-up by time (steady_warmup), then max(repeats, enough for min_region_s) blocks of exactly
     `steps` steps."""
@@ -282,6 +312,7 @@ def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats, min_regi
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
+    min_region_s = REGION_S[0] if min_region_s is None else min(min_region_s, REGION_S[0])
     for _ in range(warmup):
         step()
     n_warm, warm_s, settled = steady_warmup(block)
@@ -308,7 +339,7 @@ def time_forward(ops, graph, pairs, Z, beta, t, steps, warmup, repeats, min_regi
     return blocks, ktime
 
 
-def phase_table(ktime, abytes, mbytes, peak, traffic=None):
+def phase_table(ktime, abytes, mbytes, peak, traffic=None, l2=None):
     out = {}
     for n in NAMES:
         out[n] = dict(avg_us=ktime[n] * 1e6, algorithmic_bytes=abytes[n], moved_bytes=mbytes[n],
@@ -318,6 +349,12 @@ def phase_table(ktime, abytes, mbytes, peak, traffic=None):
             out[n]["traffic"] = traffic[n]
             out[n]["hbm_GBs"] = traffic[n] / ktime[n] / 1e9
             out[n]["hbm_frac"] = traffic[n] / ktime[n] / 1e9 / HBM_PEAK_GBS
+        if l2 is not None and n in l2:
+            out[n]["l2_traffic"] = l2[n]["l2_bytes"]                       # counted at the L2s' request side
+            out[n]["l2_traffic_over_moved"] = l2[n]["l2_bytes"] / mbytes[n] if mbytes[n] else None
+            out[n]["l2_hit_rate"] = l2[n]["hit_rate"]
+            out[n]["l2_GBs"] = l2[n]["l2_bytes"] / ktime[n] / 1e9
+            out[n]["l2_frac"] = l2[n]["l2_bytes"] / ktime[n] / 1e9 / L2_PEAK_GBS
     return out
 
 
@@ -347,7 +384,7 @@ def hbm_bound_section(ops, device, K, d, nhid, steps, warmup, repeats, workload=
     key = f"{workload}x{scale:g}_K{K}_d{d}_{dtype}"
     traffic, src = pmc_traffic(key)
     _bound, _peak, bound_how = memory_bound(2 * N * K * d * wb, mb, traffic)
-    kernels = phase_table(ktime, ab, mb, HBM_PEAK_GBS, traffic)
+    kernels = phase_table(ktime, ab, mb, HBM_PEAK_GBS, traffic, pmc_l2(key))
     dom = max(NAMES, key=lambda n: ktime[n])
     med = float(np.median(blocks))
     out = {"workload": f"{workload}-synthetic x{scale:g} (seed 0): N={N}, E_sym={E}, P={P}, K={K}, d={d}, {dtype}; "
@@ -427,7 +464,10 @@ def main():
                     help="comma list of: headline, hbm_bound, fwd_bwd, scorer_train, projection, dense, cpu (default all)")
     ap.add_argument("--hbm-scale", type=float, default=0.25, help="scale of the snap_patents graph of the hbm_bound block")
     ap.add_argument("--hbm-steps", type=int, default=5)
+    ap.add_argument("--warm-s", type=float, default=0.3, help="warm up by time for at least this long (0: --warmup steps only)")
+    ap.add_argument("--min-region-s", type=float, default=1.0, help="timed region: at least this long (0: --repeats blocks)")
     args = ap.parse_args()
+    WARM_S[0], REGION_S[0] = args.warm_s, args.min_region_s
     want = lambda s: args.sections == "all" or s in args.sections.split(",")
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -500,7 +540,8 @@ def main():
     traffic, traffic_src = pmc_traffic(pmc_key)
     bound, peak, bound_how = memory_bound(table_bytes, mbytes, traffic)
     in_cache = bound == "l2"
-    kernels = phase_table(ktime, abytes, mbytes, peak, traffic)
+    l2 = pmc_l2(pmc_key)
+    kernels = phase_table(ktime, abytes, mbytes, peak, traffic, l2)
     kernels["score"]["pairs_per_s"] = P / ktime["score"]                  # P / t_score
     dom = max(NAMES, key=lambda n: ktime[n])
 
@@ -571,6 +612,7 @@ def main():
             "aggregate": (med(1, 2), mbytes["aggregate"], abytes["aggregate"]),
         }
         fb_traffic, fb_traffic_src = pmc_traffic(pmc_key + "_train", phases=TRAIN_PHASE_KERNELS)
+        fb_l2 = pmc_l2(pmc_key + "_train", phases=TRAIN_PHASE_KERNELS)
         fb_kernels = {}
         for name, (sec, mv, ab) in fb_model.items():
             e = {"avg_us": sec * 1e6, "moved_bytes": mv, "algorithmic_bytes": ab}
@@ -579,6 +621,10 @@ def main():
             key = "scorer" if name.startswith("scorer") else name
             if fb_traffic is not None and key in fb_traffic:
                 e.update(traffic=fb_traffic[key], hbm_frac=fb_traffic[key] / sec / 1e9 / HBM_PEAK_GBS)
+            if fb_l2 is not None and key in fb_l2 and fb_l2[key]["l2_bytes"] > 0:
+                e.update(l2_traffic=fb_l2[key]["l2_bytes"], l2_hit_rate=fb_l2[key]["hit_rate"],
+                         l2_traffic_over_moved=fb_l2[key]["l2_bytes"] / mv if mv else None,
+                         l2_frac_by_counter=fb_l2[key]["l2_bytes"] / sec / 1e9 / L2_PEAK_GBS)
             fb_kernels[name] = e
         fb_kernels["_sum_of_kernels_us"] = sum(v[0] for v in fb_model.values()) * 1e6
         fb_kernels["_traffic_source"] = fb_traffic_src
@@ -716,6 +762,10 @@ def main():
                      "peak": peak, "unit": "GB/s", "frac": kernels[dom]["frac"],
                      "traffic": kernels[dom].get("traffic"), "traffic_source": traffic_src,
                      "hbm_frac": kernels[dom].get("hbm_frac"),
+                     "l2_traffic": kernels[dom].get("l2_traffic"), "l2_traffic_over_moved": kernels[dom].get("l2_traffic_over_moved"),
+                     "l2_hit_rate": kernels[dom].get("l2_hit_rate"), "l2_frac_by_counter": kernels[dom].get("l2_frac"),
+                     "l2_traffic_source": "profiles/pmc_l2_latest.json (rocprofv3 TCC_READ x 128 B + TCC_WRITE x 64 B per launch)"
+                     if l2 is not None else "no L2-request passes committed for this build and workload",
                      "moved_bytes": kernels[dom]["moved_bytes"], "algorithmic_bytes": kernels[dom]["algorithmic_bytes"],
                      "avg_us": kernels[dom]["avg_us"], "l2_gather_reference_GBs": list(L2_GATHER_REF_GBS),
                      "note": bound_note},

@@ -10,10 +10,10 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o out -- python3 "$root/bench.py" "$@" --no-cpu-baseline > /tmp/pmc_$c.log 2>&1 < /dev/null || { echo "pass $c failed"; tail -n 5 /tmp/pmc_$c.log; exit 1; }
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o out -- python3 "$root/bench.py" "$@" --no-cpu-baseline --warm-s 0 --min-region-s 0 > /tmp/pmc_$c.log 2>&1 < /dev/null || { echo "pass $c failed"; tail -n 5 /tmp/pmc_$c.log; exit 1; }
 done
 f=$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -n 1)
 w=$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -n 1)
 if [ -z "$f" ] || [ -z "$w" ]; then echo "PMC output missing"; tail -n 5 /tmp/pmc_FETCH_SIZE.log; exit 1; fi
 python3 "$root/tools/pmc_traffic.py" "$f" "$w" "$root/gpurun_out/${tag}_pmc_traffic.json" "$key" \
-  "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py $* --no-cpu-baseline"
+  "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py $* --no-cpu-baseline --warm-s 0 --min-region-s 0"
