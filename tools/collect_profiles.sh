@@ -5,11 +5,13 @@ set -e
 tag=$1
 cd "$(dirname "$0")/.."
 for f in bench_line.json chameleon_bench_line.json penn94_K16_d128_bf16_bench_line.json chameleon_kernel_stats.csv \
-         hbm_bound_kernel_stats.csv headline_kernel_stats.csv penn94_K16_d128_bf16_kernel_stats.csv pmc_traffic.json; do
+         hbm_bound_kernel_stats.csv headline_kernel_stats.csv penn94_K16_d128_bf16_kernel_stats.csv pmc_traffic.json \
+         training_kernel_stats.csv pmc_l2.json; do
   cp gpurun_out/${tag}_$f profiles/${tag}_$f
 done
 cp gpurun_out/${tag}_pmc_traffic_latest.json profiles/pmc_traffic_latest.json
-(cd profiles && for w in headline hbm_bound chameleon penn94_K16_d128_bf16; do
+cp gpurun_out/${tag}_pmc_l2_latest.json profiles/pmc_l2_latest.json
+(cd profiles && for w in headline training hbm_bound chameleon penn94_K16_d128_bf16; do
    echo "## $w"; echo; python3 ../tools/stats_md.py ${tag}_${w}_kernel_stats.csv 10; echo; done) > profiles/${tag}_kernel_stats.md
 python3 - <<PY
 import json
