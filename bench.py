@@ -502,6 +502,9 @@ def main():
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            # RCCL prints its version banner on STDOUT at NCCL_DEBUG=VERSION (this image's default): stdout is one JSON line
+            if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+                os.environ["NCCL_DEBUG"] = "WARN"
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from disenlink_amd import _lib, ops
