@@ -1267,7 +1267,8 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
             // first — finite values pass unchanged, a NaN gl still gives NaN
             const float exc = fminf(ex, 3.402823466e38f);
             const float ttc = __builtin_amdgcn_fmed3f(T1 ? ttv : ttv / t, -3.402823466e38f, 3.402823466e38f);
-            const float coef = (i & 8) ? gl * ttc : xor_lane<8>(gl) * exc;
+            const float gl_partner = xor_lane<8>(gl);              // OUTSIDE the select: a DPP move under a divergent branch reads 0 from the masked-off lanes
+            const float coef = (i & 8) ? gl * ttc : gl_partner * exc;
             float Eb[NJ][U], Tb[NJ][U];
             Eb[0][0] = row_bcast<0>(coef); Eb[0][1] = row_bcast<1>(coef); Eb[0][2] = row_bcast<2>(coef); Eb[0][3] = row_bcast<3>(coef);
             Tb[0][0] = row_bcast<8>(coef); Tb[0][1] = row_bcast<9>(coef); Tb[0][2] = row_bcast<10>(coef); Tb[0][3] = row_bcast<11>(coef);

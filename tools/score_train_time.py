@@ -34,4 +34,5 @@ for name, fn in (("one pass", one_pass), ("separate", separate), ("one pass", on
     e1.record(); e1.synchronize()
     print(f"{sys.argv[1:]} {name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
 a, b = one_pass(), separate()
-print("max|prob diff|", float((a[0] - b[0]).abs().max()), "max|dZ diff|/max", float((a[1] - b[1]).abs().max() / b[1].abs().max()))
+print("max|prob diff|", float((a[0] - b[0]).abs().max()), "max|dZ diff|/max", float((a[1] - b[1]).abs().max() / b[1].abs().max()),
+      "max|dH diff|/max", float((a[2] - b[2]).abs().max() / b[2].abs().max()))
