@@ -1660,7 +1660,9 @@ def test_stacked_adam_is_torch_adam(use_graph, monkeypatch):
     for a_, b_ in zip(a[3], b[3]):
         assert torch.equal(a_, b_)
     # dl_adam_step (the default): torch.optim.Adam's arithmetic up to the rounding of the bias corrections
-    np.testing.assert_allclose(c[0], b[0], rtol=2e-5)
+    # (12 epochs from a saturated start — loss 19: a pair whose sigmoid sits one ulp from 1.0 carries gradient w or 0,
+    # so a last-bit difference in the weights can move one pair's whole contribution: 2.4e-5 was seen with the round-4 scorer)
+    np.testing.assert_allclose(c[0], b[0], rtol=6e-5)
     np.testing.assert_allclose(c[1], b[1], atol=2e-4)
     for c_, b_ in zip(c[3], b[3]):
         assert torch.allclose(c_, b_, rtol=1e-3, atol=2e-5), float((c_ - b_).abs().max())
