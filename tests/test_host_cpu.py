@@ -521,3 +521,39 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "disagree" in r.stderr
+
+
+def test_bench_warmup_settles_and_parity_block_reports_both_sides():
+    """bench.steady_warmup: blocks until >= min_s have passed AND three consecutive blocks agree within tol (a ramp keeps
+    it going; max_s bounds it).  bench.parity_block: max |dprob| and the tie-aware AUC of both sides (the GPU side's AUC
+    falls back to the torch form on CPU tensors), with the tolerances the metric names."""
+    import time
+    import bench
+    ramp = iter([1.0, 0.8, 0.7, 0.65, 0.64, 0.64, 0.641, 0.64, 0.64])
+    calls = []
+
+    def block():
+        calls.append(1)
+        time.sleep(0.002)
+        return next(ramp)
+    n, el, settled = bench.steady_warmup(block, min_s=1e-6, tol=0.02, max_s=5.0)
+    assert settled and n == 6, (n, settled)                     # 0.65, 0.64, 0.64 is the first triple within 2 %
+    n, el, settled = bench.steady_warmup(lambda: (time.sleep(0.01), 1.0)[1], min_s=0.05, tol=0.02, max_s=5.0)
+    assert settled and el >= 0.05 and n >= 5
+    k = [0]
+    def never():
+        k[0] += 1
+        time.sleep(0.005)
+        return float(k[0])
+    n, el, settled = bench.steady_warmup(never, min_s=1e-6, tol=0.02, max_s=0.05)
+    assert bench.steady_warmup(never, min_s=0.0)[0] == 1             # --warm-s 0 (profiler passes): one block, no waiting
+    assert not settled and el >= 0.05
+    rng = np.random.default_rng(0)
+    label = (rng.random(500) < 0.3).astype(np.float32)
+    prob = rng.random(500).astype(np.float32)
+    par = bench.parity_block(prob.copy(), label, torch.from_numpy(prob))
+    assert par["ok"] and par["max_abs_dprob"] == 0.0 and abs(par["auc_gpu"] - par["auc_cpu"]) < 1e-12 and par["pairs"] == 500
+    off = prob.copy()
+    off[7] += 1e-3
+    par = bench.parity_block(off, label, torch.from_numpy(prob))
+    assert not par["ok"] and abs(par["max_abs_dprob"] - 1e-3) < 1e-6
