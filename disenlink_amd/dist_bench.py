@@ -154,6 +154,7 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     from . import _lib
     from .model import Disentangle
     lib = _lib.load()
+    _bench.WARM_S[0], _bench.REGION_S[0] = args.warm_s, args.min_region_s     # (this import is a second copy of the __main__ script)
     K, d, beta, t = spec["K"], spec["d"], 0.5, 1.0
     tab = torch.bfloat16 if spec["dtype"] == "bf16" else torch.float32
     wb = 2 if spec["dtype"] == "bf16" else 4
