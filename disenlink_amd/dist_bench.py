@@ -217,13 +217,18 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     # ---- how the tables travel: measured here, on this node's links ------------------------------------------------
     forced = os.environ.get("DL_GATHER_MODE")
     reps = 3 if world > 1 else 1
-    z_ab = {}
+    z_ab, ab_errors = {}, {}
     for mode in dd.GATHER_MODES:
         if forced and mode != forced:
             continue
         def z_gather(mode=mode):
             dd.gather_table(Z, part, rank, mode, src=Z_loc)
-        z_ab[mode] = _timed(z_gather, reps, red_dev) * 1e3
+        try:                                        # a transport the backend refuses is left out, not fatal (the plain
+            z_ab[mode] = _timed(z_gather, reps, red_dev) * 1e3      # all-gather is the form every backend has)
+        except Exception as e:                      # noqa: BLE001
+            if mode == "allgather":
+                raise
+            ab_errors[mode] = f"{type(e).__name__}: {e}"[:300]
     z_mode = min(z_ab, key=z_ab.get)
     p, a = backend.route_fwd(shard.graph, Z, t, s)
     dd.all_gather_rows(s, shard.lo, shard.hi)
@@ -240,7 +245,16 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     if shard.pair_groups:
         h_forms["chunked"] = h_chunked
     want_form = os.environ.get("DL_H_GATHER")
-    h_ab = {name: _timed(fn, reps, red_dev) * 1e3 for name, fn in h_forms.items() if not want_form or name == want_form}
+    h_ab = {}
+    for name, fn in h_forms.items():
+        if want_form and name != want_form:
+            continue
+        try:
+            h_ab[name] = _timed(fn, reps, red_dev) * 1e3
+        except Exception as e:                      # noqa: BLE001
+            if name == "blocking":
+                raise
+            ab_errors["h_" + name] = f"{type(e).__name__}: {e}"[:300]
     h_form = min(h_ab, key=h_ab.get)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -374,7 +388,7 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
                                                   value / ((n1["E"] + n1["P"]) / (n1["ms"] * 1e-3))),
         "parity": parity,
         "gather_ab": {"z_gather_ms": z_ab, "z_gather_used": z_mode, "h_phase_ms": h_ab, "h_phase_used": h_form,
-                      "forced": {"DL_GATHER_MODE": forced, "DL_H_GATHER": want_form},
+                      "forced": {"DL_GATHER_MODE": forced, "DL_H_GATHER": want_form}, "refused": ab_errors,
                       "note": "allgather = one all_gather_into_tensor into the table itself (in place); p2p = one grouped "
                               "batch of W-1 direct sends + W-1 receives landing in place; broadcast = W broadcasts; "
                               "H phase: blocking gather + one scoring launch vs row chunks pushed directly with the "
