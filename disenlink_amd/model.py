@@ -292,6 +292,12 @@ class Disentangle(nn.Module):
         table_bytes = 2 * Z.shape[0] * Z.shape[1] * Z.shape[2] * (4 if self.table_dtype == torch.float32 else 2)
         one_pass = mode == "1" or (mode != "0" and (self.table_dtype == torch.float32 or table_bytes > (512 << 20)))
         if one_pass and ops.score_pairs_train_supported(pairs, Z.shape[1], Z.shape[2], dt):
+            if self.table_dtype == torch.float32 and Z.dtype == torch.float32 and graph.n_rows == graph.n_nodes:
+                from . import native                            # the compiled binding: the same step as ONE C++ autograd node
+                if native.available():
+                    H, prob, loss = native.hot_path_pairs_loss(Z, graph, pairs, float(self.beta), float(self.temperature),
+                                                               label, weight)
+                    return H.view(H.shape[0], -1), prob, loss
             H, prob, loss = ops.HotPathPairsLoss.apply(Z, graph, pairs, float(self.beta), float(self.temperature),
                                                        self.table_dtype, label, weight)
             return H.view(H.shape[0], -1), prob, loss

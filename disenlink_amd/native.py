@@ -1,0 +1,59 @@
+"""The COMPILED torch binding (libdisenlink_torch.so, csrc/torch/dl_torch.cpp): the training step's hot path as one C++
+autograd node registered with TORCH_LIBRARY over the same C ABI the ctypes binding uses — ``torch.ops.disenlink_native.*``.
+
+    from disenlink_amd import native
+    if native.available():
+        H, prob, loss = native.hot_path_pairs_loss(Z, graph, pairs, beta, t, label, weight)
+
+Same kernels and bits as ``ops.HotPathPairsLoss`` (route + aggregate + one-pass scorer + loss value; backward: routing /
+aggregation with d/dloss applied inside the last kernel); what it removes is the Python between the launches (ctypes
+marshalling, autograd.Function frames): host time of the eager loop on small graphs.  fp32 tables only; a gradient arriving
+on ``prob`` needs the Python operator.  ``Disentangle.forward_pairs_loss`` uses it when it is built and the shape has a
+tuned kernel (``DL_NATIVE_OPS=0`` keeps the Python operators).  There is no fallback inside: a missing library means
+``available()`` is False and the ctypes path runs — which itself has no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib, ops
+from .graph import Graph, PairList
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdisenlink_torch.so")
+_state = {"loaded": None}
+
+
+def load() -> bool:
+    """Load libdisenlink_torch.so once (after libdisenlink_hip.so, whose symbols it binds) -> whether it is there."""
+    if _state["loaded"] is None:
+        ok = False
+        if os.path.exists(LIB_PATH) and os.environ.get("DL_NATIVE_OPS", "1") != "0":
+            _lib.load()
+            torch.ops.load_library(LIB_PATH)
+            ok = hasattr(torch.ops, "disenlink_native") and hasattr(torch.ops.disenlink_native, "hot_path_pairs_loss")
+        _state["loaded"] = ok
+    return _state["loaded"]
+
+
+def available() -> bool:
+    return load()
+
+
+def hot_path_pairs_loss(Z: torch.Tensor, graph: Graph, pairs: PairList, beta: float, t: float, label, weight):
+    """(H [N,K,d], prob [P], loss) — see ops.HotPathPairsLoss; Z fp32 on the GPU, graph unsharded."""
+    if not load():
+        raise _lib.DisenlinkHipError("libdisenlink_torch.so is not built (python -m disenlink_amd.build)")
+    N, K, d = Z.shape
+    P = int(label.numel())
+    if P != pairs.n_pairs:
+        raise ValueError("label / weight must cover the pair list")
+    graph.c_struct()
+    pairs.c_struct(P)
+    ws_g = ops._workspace(graph.c_plan(), Z.device, K, d)
+    ws_p = ops._workspace(pairs.c_plan(), Z.device, K, d)
+    ws_b = ops._ws_bce(Z.device)
+    return torch.ops.disenlink_native.hot_path_pairs_loss(Z, C.addressof(graph._struct), C.addressof(pairs._struct),
+                                                          graph.n_edges, float(beta), float(t), label, weight, ws_g, ws_p, ws_b)

@@ -92,6 +92,16 @@ class _Workspace:
 
 
 _ws = _Workspace()
+_bce_ws: dict = {}
+
+
+def _ws_bce(device) -> torch.Tensor:
+    """dl_pair_bce's 8 KiB of scratch: a buffer of its own (the shared grow-only workspace is handed to the plans' kernels
+    in the same step; the compiled binding passes all three scratch tensors into one call)."""
+    t = _bce_ws.get(device)
+    if t is None:
+        t = _bce_ws[device] = torch.empty(8192, dtype=torch.uint8, device=device)
+    return t
 
 
 _ws_need: dict = {}

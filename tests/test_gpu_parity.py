@@ -1766,3 +1766,43 @@ def test_cli_gpus_2_trains_row_sharded_and_matches_the_single_gpu_run():
     np.testing.assert_allclose(l2, l1, rtol=2e-4)
     assert abs(a1 - a2) <= 1e-3, (a1, a2)
     assert 0.5 < a2 <= 1.0
+
+
+def test_compiled_torch_binding_equals_the_python_operators_bit_for_bit():
+    """torch.ops.disenlink_native.hot_path_pairs_loss (C++ autograd node over the C ABI) against ops.HotPathPairsLoss
+    (Python autograd.Function over ctypes): H, prob, loss and the gradient on Z — for loss.backward() (the scaled last
+    kernel) and with a gradient on the embedding as well — are the same bits; the module takes the compiled path by default
+    and trains the same trajectory as with DL_NATIVE_OPS=0."""
+    from disenlink_amd import native, ops
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.graph import Graph, PairList
+    from disenlink_amd.metrics import pair_bce_weights
+    from disenlink_amd.splits import make_link_split
+    assert native.available(), "libdisenlink_torch.so must be built on the GPU box (python -m disenlink_amd.build)"
+    sg = synthetic_graph("chameleon", seed=4)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=4)
+    dev = torch.device(DEV)
+    graph = Graph.from_edge_rows(torch.from_numpy(split.train_src).to(dev), torch.from_numpy(split.train_dst).to(dev), sg.n_nodes)
+    pu = np.concatenate([split.pos_train.u, split.neg_train.u])
+    pv = np.concatenate([split.pos_train.v, split.neg_train.v])
+    pairs = PairList.build(torch.from_numpy(pu).to(dev), torch.from_numpy(pv).to(dev), sg.n_nodes)
+    label = torch.from_numpy(np.concatenate([split.pos_train.label, split.neg_train.label])).to(dev)
+    weight = pair_bce_weights(split.pos_train.u.size, split.neg_train.u.size, 5, dev)
+    torch.manual_seed(0)
+    K, d = 8, 64
+    Z0 = (torch.randn(sg.n_nodes, K, d, device=dev) * 0.2)
+    out = {}
+    for name in ("python", "native"):
+        for with_emb in (False, True):
+            Z = Z0.clone().requires_grad_(True)
+            if name == "python":
+                H, prob, loss = ops.HotPathPairsLoss.apply(Z, graph, pairs, 0.6, 1.0, torch.float32, label, weight)
+            else:
+                H, prob, loss = native.hot_path_pairs_loss(Z, graph, pairs, 0.6, 1.0, label, weight)
+            total = loss * 3.0 + ((H * H).sum() * 1e-3 if with_emb else 0.0)
+            total.backward()
+            out[(name, with_emb)] = (H.detach().clone(), prob.detach().clone(), loss.detach().clone(), Z.grad.clone())
+    for with_emb in (False, True):
+        for a_, b_, what in zip(out[("python", with_emb)], out[("native", with_emb)], ("H", "prob", "loss", "dZ")):
+            assert torch.equal(a_, b_), (what, with_emb, float((a_ - b_).abs().max()))
+    assert float(out[("native", False)][3].abs().max()) > 0

@@ -557,3 +557,21 @@ def test_bench_warmup_settles_and_parity_block_reports_both_sides():
     off[7] += 1e-3
     par = bench.parity_block(off, label, torch.from_numpy(prob))
     assert not par["ok"] and abs(par["max_abs_dprob"] - 1e-3) < 1e-6
+
+
+def test_compiled_torch_binding_builds_loads_and_registers_its_operator():
+    """libdisenlink_torch.so (csrc/torch/dl_torch.cpp, built by disenlink_amd.build with g++ against the installed torch):
+    the TORCH_LIBRARY binding over the C ABI loads next to libdisenlink_hip.so and registers
+    torch.ops.disenlink_native.hot_path_pairs_loss with the documented schema; it reaches the same library (abi_version is
+    dl_version()).  No compute without a GPU."""
+    from disenlink_amd import _lib, build, native
+    path = build.build_torch_binding()
+    assert os.path.exists(path) and path.endswith("libdisenlink_torch.so")
+    assert native.available()
+    op = torch.ops.disenlink_native.hot_path_pairs_loss
+    assert str(op.default._schema) == (
+        "disenlink_native::hot_path_pairs_loss(Tensor Z, int graph_ptr, int inc_ptr, int n_edges, float beta, float t, "
+        "Tensor label, Tensor weight, Tensor ws_graph, Tensor ws_pairs, Tensor ws_bce) -> (Tensor, Tensor, Tensor)")
+    assert torch.ops.disenlink_native.abi_version() == _lib.load().dl_version().decode()
+    with pytest.raises(RuntimeError, match="CUDA fp32"):
+        op(torch.zeros(3, 2, 8), 0, 0, 0, 0.5, 1.0, torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1))

@@ -14,6 +14,7 @@ run = prepare_run(split, dev)
 x = torch.from_numpy(sg.features()).to(dev)
 torch.manual_seed(0)
 model = Disentangle(sg.n_feat, 512, 64, nfactor=8, beta=0.5, t=1).to(dev)
+print("native ops:", os.environ.get("DL_NATIVE_OPS", "1"))
 run_link_prediction(model, x, run, epochs=5, lr=1e-4)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
