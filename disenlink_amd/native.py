@@ -32,8 +32,13 @@ def load() -> bool:
         ok = False
         if os.path.exists(LIB_PATH) and os.environ.get("DL_NATIVE_OPS", "1") != "0":
             _lib.load()
-            torch.ops.load_library(LIB_PATH)
-            ok = hasattr(torch.ops, "disenlink_native") and hasattr(torch.ops.disenlink_native, "hot_path_pairs_loss")
+            try:
+                torch.ops.load_library(LIB_PATH)
+                ok = hasattr(torch.ops, "disenlink_native") and hasattr(torch.ops.disenlink_native, "hot_path_pairs_loss")
+            except OSError as e:           # built against another torch: the ctypes binding (the same HIP kernels) carries on
+                import warnings
+                warnings.warn(f"libdisenlink_torch.so does not load ({e}); rebuild with python -m disenlink_amd.build — "
+                              "using the ctypes binding of the same C ABI")
         _state["loaded"] = ok
     return _state["loaded"]
 
