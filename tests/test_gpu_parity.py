@@ -1664,8 +1664,8 @@ def test_stacked_adam_is_torch_adam(use_graph, monkeypatch):
     # so a last-bit difference in the weights can move one pair's whole contribution: 2.4e-5 was seen with the round-4 scorer)
     np.testing.assert_allclose(c[0], b[0], rtol=6e-5)
     np.testing.assert_allclose(c[1], b[1], atol=2e-4)
-    for c_, b_ in zip(c[3], b[3]):
-        assert torch.allclose(c_, b_, rtol=1e-3, atol=2e-5), float((c_ - b_).abs().max())
+    for c_, b_ in zip(c[3], b[3]):                                  # (5.7e-5 seen, for the same reason as the loss above)
+        assert torch.allclose(c_, b_, rtol=1e-3, atol=1e-4), float((c_ - b_).abs().max())
     assert fast and all(fast), fast[:8]                             # every gradient arrived stacked: no stacking copy
 
 

@@ -388,14 +388,27 @@ def test_bench_pmc_table_covers_every_phase_kernel():
     for key, entry in table.items():
         assert len(entry["kernel_source_hash"]) == 16 and "rocprofv3" in entry["source"], key
         bases = {k.split("<")[0].split("::")[-1]: v for k, v in entry["kernels"].items()}
-        for phase, names in bench.PHASE_KERNELS.items():
+        # `<workload>_train` entries (round 4) are passes over `--sections fwd_bwd`: the training step's kernels
+        phases = bench.TRAIN_PHASE_KERNELS if key.endswith("_train") else bench.PHASE_KERNELS
+        for phase, names in phases.items():
             assert any(n in bases and bases[n]["traffic_bytes"] > 0 for n in names), (key, phase)
-        got, why = bench.pmc_traffic(key)
+        got, why = bench.pmc_traffic(key, phases=phases)
         if entry["kernel_source_hash"] == bench.kernel_source_hash():
-            assert set(got) == set(bench.PHASE_KERNELS) and all(v > 0 for v in got.values())
+            assert set(got) == set(phases) and all(v > 0 for v in got.values())
         else:
             assert got is None and entry["kernel_source_hash"] in why
     assert bench.pmc_traffic("no_such_workload")[0] is None
+    # the L2-side request passes (round 4): what the kernels ask of the L2s, next to what leaves them
+    l2 = json.load(open(bench.PMC_L2_SUMMARY))
+    assert l2, "no L2-request passes committed"
+    for key, entry in l2.items():
+        assert len(entry["kernel_source_hash"]) == 16 and "TCC_READ_sum" in entry["source"], key
+        phases = bench.TRAIN_PHASE_KERNELS if key.endswith("_train") else bench.PHASE_KERNELS
+        got = bench.pmc_l2(key, phases=phases)
+        if entry["kernel_source_hash"] == bench.kernel_source_hash():
+            assert set(got) == set(phases) and all(v["l2_bytes"] > 0 and 0 <= v["hit_rate"] <= 1 for v in got.values()), key
+        else:
+            assert got is None
 
 
 def test_bench_prices_against_the_measured_roof():
