@@ -306,9 +306,9 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     est = torch.tensor([(time.perf_counter() - t0) / args.steps], dtype=torch.float64, device=red_dev)
     dist.all_reduce(est, op=dist.ReduceOp.MAX)
     est_s = max(float(est), 1e-6)
-    for _ in range(min(2000, int(0.3 / est_s))):
+    for _ in range(min(2000, int(args.warm_s / est_s))):
         step()
-    n_blocks = int(min(50, max(args.repeats, math.ceil(1.0 / (est_s * args.steps)))))
+    n_blocks = int(min(500, max(args.repeats, math.ceil(args.min_region_s / (est_s * args.steps)))))
     blocks = []
     for _ in range(n_blocks):
         torch.cuda.synchronize()
