@@ -400,7 +400,7 @@ def test_sharded_training_step_over_rccl_matches_the_unsharded_module():
         tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1,
                                  device_id=torch.device(DEV))
     try:
-        # n_chunks=2: the H all-gather goes through the asynchronous chunked path (RCCL all_gather into table views)
+        # n_chunks=2: the H exchange goes through the asynchronous chunked path (grouped point-to-point batches; one rank: no-ops)
         shard = dl_dist.Shard.build(0, 1, sg.n_nodes, split.train_src, split.train_dst, pu, pv, torch.device(DEV), n_chunks=2)
         assert len(shard.pair_groups) == 3 and int(shard.pair_groups[0][0].numel()) == shard.pairs.n_pairs
         emb_s, prob_s = dl_dist.sharded_forward(model, x, shard)
