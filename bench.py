@@ -499,13 +499,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            # RCCL prints its version banner on STDOUT at NCCL_DEBUG=VERSION (this image's default): stdout is one JSON line
-            if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-                os.environ["NCCL_DEBUG"] = "WARN"
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from disenlink_amd.launch import stdout_to_stderr
+        with stdout_to_stderr():        # backends print connection banners from C++ on fd 1: stdout is ONE JSON line
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":      # RCCL's version banner (this image's default)
+                    os.environ["NCCL_DEBUG"] = "WARN"
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                dist.barrier()          # (communicators come up here, not inside the first timed collective)
 
     from disenlink_amd import _lib, ops
     lib = _lib.load()

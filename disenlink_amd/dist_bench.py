@@ -425,7 +425,11 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     emu = int(os.environ.get("DL_EMULATE_WORLD", "0"))
     if emu > 1 and world == 1:
         return bench_emulated(args, emu, device)
-    ctrl = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    from .launch import stdout_to_stderr
+    with stdout_to_stderr():                # gloo announces its connections on fd 1
+        ctrl = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+        if ctrl is not None:
+            dist.barrier(group=ctrl)
     if args.workload in ("auto", "multi"):
         specs = [dict(b) for b in DEFAULT_BLOCKS]
         only = os.environ.get("DL_BENCH_BLOCKS")

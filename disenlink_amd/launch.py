@@ -55,3 +55,21 @@ def launch_ranks(n_ranks: int, target: list[str], argv: list[str], cwd: str | No
     if rc == 0:
         print(line, flush=True)
     return rc
+
+
+class stdout_to_stderr:
+    """File-descriptor-level redirect of stdout into stderr for the duration of a block: communication backends print
+    connection banners from C++ on fd 1 ("[Gloo] Rank 0 is connected to ...", RCCL's version banner), and a rank that
+    promises ONE JSON line on stdout has to keep them off it."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
