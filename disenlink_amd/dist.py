@@ -347,6 +347,25 @@ class HipBackend:
         """-> prob [P total] (entries of the pairs touching the plan's rows), dZ, dH [n_pad,K,d] (the plan's rows)"""
         return self.ops.score_pairs_train(Z, H, inc, t, label, weight)
 
+    def score_pairs_fwd_terms(self, Z, H, pairs, t):
+        """-> prob [P], coef ([2,P,K] per-factor terms for the coefficient-gather backward, or None where the tuned scorer
+        does not hand them out)"""
+        return self.ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+
+    def score_pairs_bwd_terms(self, Z, H, pairs, t, prob, g_prob, coef, dZ_out, dH_out):
+        self.ops.score_pairs_bwd(Z, H, pairs, t, prob, g_prob, dZ_out=dZ_out, dH_out=dH_out, coef=coef)
+
+    def pair_bce_grad(self, prob, label, weight):
+        """-> (sum_q weight BCE(prob, label), d that / d prob) from ONE kernel (dl_pair_bce)"""
+        lib = self.ops._lib.load()
+        loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+        g = torch.empty_like(prob)
+        ws = self.ops._ws_bce(prob.device)
+        self.ops._lib.check(lib.dl_pair_bce(prob.data_ptr(), label.data_ptr(), weight.data_ptr(), prob.numel(),
+                                            loss.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream().cuda_stream), "dl_pair_bce")
+        return loss[0], g
+
     def pair_bce_sum(self, prob, label, weight):
         """sum_q weight BCE(prob, label) with the reference's clamps (no autograd: the gradient came from the scorer)"""
         lib = self.ops._lib.load()
@@ -399,6 +418,8 @@ class Shard:
     # none; empty list = one routing pass after a blocking all-gather
     route_by_peer: list = field(default_factory=list)
     row_bytes: int = 2048
+    _touch: object = field(default=None, repr=False)      # touching(): built on first use
+    _global_pairs: tuple | None = field(default=None, repr=False)     # (pu, pv) of the whole list, padded ids (device)
 
     @staticmethod
     def build(rank: int, world: int, n_nodes: int, edge_src, edge_dst, pu, pv, device,
@@ -464,7 +485,7 @@ class Shard:
                 route.rowptr, route.col = graph.plan.rowptr, graph.plan.col       # the SAME arrays: only the segments differ
                 by_peer.append(Graph(graph.plan, None, route, False))
         return Shard(rank, world, n_nodes, n_pad, lo, hi, graph, pairs, inc, q0, q1, int(pu.size), block, cuts,
-                     part, groups, by_peer, row_bytes)
+                     part, groups, by_peer, row_bytes, None, (tpu, tpv) if with_backward else None)
 
     def with_pairs(self, pu, pv, with_backward: bool = False) -> "Shard":
         """The same partition and local graph with ANOTHER global pair list (sorted by pu; e.g. the test pairs, scored
@@ -484,7 +505,29 @@ class Shard:
         inc = _incidence_only(tpu, tpv, self.n_pad, self.lo, self.hi, self.row_bytes) if with_backward else None
         block = int(np.max(np.diff(cuts))) if pu.size else 0
         return Shard(self.rank, self.world, self.n_nodes, self.n_pad, self.lo, self.hi, self.graph, pairs, inc, q0, q1,
-                     int(pu.size), block, cuts, part, [], self.route_by_peer, self.row_bytes)
+                     int(pu.size), block, cuts, part, [], self.route_by_peer, self.row_bytes, None,
+                     (tpu, tpv) if with_backward else None)
+
+    def touching(self):
+        """(idx, pairs, own_lo, own_hi): the pairs that TOUCH this rank's nodes — either endpoint local — as a pair list of
+        their own (local pair ids; forward plan over all their first endpoints, incidence rows = the local nodes), `idx` =
+        their positions in the global list (ascending: the list order is kept), and the contiguous range of it whose FIRST
+        endpoint is local (the pairs this rank owns).  With it a rank can run the scorer's training step from kernels that
+        need per-pair terms WITHOUT any exchange of per-pair data: it scores every touching pair itself (2 P / W of them
+        on average, the same count the one-pass scorer walks) and feeds the terms to the coefficient-gather backward."""
+        if self._touch is None:
+            if self._global_pairs is None:
+                raise ValueError("Shard.build(with_backward=True) is needed for the touching-pair list")
+            tpu, tpv = self._global_pairs
+            keep = ((tpu >= self.lo) & (tpu < self.hi)) | ((tpv >= self.lo) & (tpv < self.hi))
+            idx = torch.nonzero(keep).reshape(-1)
+            pu_t, pv_t = tpu[idx], tpv[idx]
+            own_lo = int((pu_t < self.lo).sum())
+            own_hi = int((pu_t < self.hi).sum())
+            pl = PairList.build(pu_t, pv_t, self.n_pad, row_range=(self.lo, self.hi), by_u_range=(0, self.n_pad),
+                                row_bytes=self.row_bytes)
+            self._touch = (idx, pl, own_lo, own_hi)
+        return self._touch
 
     def pad_rows(self, x_local_real: torch.Tensor) -> torch.Tensor:
         """Feature rows of this rank's block, zero rows for padding nodes."""
@@ -627,7 +670,12 @@ class ShardedHotPathLoss(torch.autograd.Function):
     sum_{q: u local} w BCE — the caller all-reduces it for the value; its gradient factor must be the same on every rank."""
 
     @staticmethod
-    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype, label, weight):
+    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype, label, weight,
+                scorer: str = "one_pass"):
+        """scorer = "one_pass": dl_score_pairs_train over the rank's incidence rows; "terms": the rank scores every pair
+        that touches its nodes with the forward scorer (keeping the per-factor terms), forms the BCE gradient of those
+        pairs itself and runs the coefficient-gather backward (Shard.touching) — for shapes whose one-pass kernel is slow
+        (K = 16, d = 128: one wave per SIMD) or missing; neither form exchanges per-pair data."""
         ctx.set_materialize_grads(False)
         sh = shard
         K, d = Z_loc.shape[1], Z_loc.shape[2]
@@ -637,9 +685,20 @@ class ShardedHotPathLoss(torch.autograd.Function):
         H = torch.empty_like(Z)
         backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
         all_gather_rows(H, sh.lo, sh.hi, group)
-        prob_all, dZs, dHs = backend.score_pairs_train(Z, H, sh.inc, t, label, weight)
         q0, q1 = sh.pair_lo, sh.pair_hi
-        prob = prob_all[q0:q1].clone()                            # the pairs this rank owns (first endpoint local)
+        if scorer == "terms":
+            idx, touch, a0, a1 = sh.touching()
+            y_t, w_t = label.index_select(0, idx).contiguous(), weight.index_select(0, idx).contiguous()
+            prob_t, coef = backend.score_pairs_fwd_terms(Z, H, touch, t)
+            _tot, g_t = backend.pair_bce_grad(prob_t, y_t, w_t)           # d (sum over the touching pairs) / d prob
+            dZs = torch.zeros(Z.shape, dtype=torch.float32, device=dev)
+            dHs = torch.zeros(Z.shape, dtype=torch.float32, device=dev)
+            backend.score_pairs_bwd_terms(Z, H, touch, t, prob_t, g_t, coef, dZs, dHs)
+            prob = prob_t[a0:a1].clone()                                  # the pairs this rank owns (first endpoint local)
+            assert a1 - a0 == q1 - q0
+        else:
+            prob_all, dZs, dHs = backend.score_pairs_train(Z, H, sh.inc, t, label, weight)
+            prob = prob_all[q0:q1].clone()                            # the pairs this rank owns (first endpoint local)
         loss = backend.pair_bce_sum(prob, label[q0:q1].contiguous(), weight[q0:q1].contiguous()) if q1 > q0 else \
             torch.zeros((), dtype=torch.float32, device=dev)
         ctx.shard, ctx.backend, ctx.beta, ctx.t, ctx.group, ctx.p = sh, backend, beta, t, group, p
@@ -659,7 +718,7 @@ class ShardedHotPathLoss(torch.autograd.Function):
         if gH_loc is not None:
             dH[sh.lo:sh.hi] += gH_loc
         _route_aggregate_bwd_sharded(be, sh, Z, ctx.beta, ctx.t, ctx.p, a, s, dH, dZ, ctx.group)
-        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None, None, None
+        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None, None, None, None
 
 
 def sharded_forward(model, x_local: torch.Tensor, shard: Shard, backend=None, group=None):
@@ -682,10 +741,20 @@ def sharded_forward_loss(model, x_local: torch.Tensor, shard: Shard, label: torc
     tab = getattr(model, "table_dtype", torch.float32)
     Z_loc = model.project(shard.pad_rows(x_local))
     K, d = Z_loc.shape[1], Z_loc.shape[2]
-    if shard.inc is not None and hasattr(backend, "score_pairs_train") and \
-            backend.score_pairs_train_supported(shard.inc, K, d, tab):
+    # Which scorer (the module's own rule, model.forward_pairs_loss): one pass for fp32 tables and for bf16 tables beyond
+    # 512 MiB; bf16 tables that sit in the caches — and shapes without a one-pass kernel — take the forward scorer with
+    # stored terms + the coefficient-gather backward over the pairs that touch the rank's nodes (at K = 16, d = 128 the
+    # one-pass kernel runs one wave per SIMD: 104 ms against 23 on Penn94).  DL_ONE_PASS_SCORER=0/1 forces.
+    mode = os.environ.get("DL_ONE_PASS_SCORER", "auto")
+    table_bytes = 2 * shard.n_pad * K * d * (4 if tab == torch.float32 else 2)
+    want_one = mode == "1" or (mode != "0" and (tab == torch.float32 or table_bytes > (512 << 20)))
+    has_one = shard.inc is not None and hasattr(backend, "score_pairs_train") and \
+        backend.score_pairs_train_supported(shard.inc, K, d, tab)
+    has_terms = shard._global_pairs is not None and hasattr(backend, "score_pairs_fwd_terms")
+    scorer = "one_pass" if has_one and (want_one or not has_terms) else ("terms" if has_terms else None)
+    if scorer is not None:
         H_loc, prob, loss = ShardedHotPathLoss.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature),
-                                                     group, tab, label, weight)
+                                                     group, tab, label, weight, scorer)
         return H_loc.reshape(H_loc.shape[0], -1), prob, loss
     H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group, tab)
     q0, q1 = shard.pair_lo, shard.pair_hi

@@ -443,7 +443,7 @@ def _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_
     ppu, ppv = part.to_padded(prob.pu), part.to_padded(prob.pv)
     tpu, tpv = torch.as_tensor(ppu, device=device), torch.as_tensor(ppv, device=device)
     inc = dd._incidence_only(tpu, tpv, shard.n_pad, shard.lo, shard.hi, K * d * wb)
-    sh = dataclasses.replace(shard, inc=inc)
+    sh = dataclasses.replace(shard, inc=inc, _global_pairs=(tpu, tpv), _touch=None)
     P = int(prob.pu.size)
     label = ((tpu * 2654435761 + tpv) % 6 == 0).to(torch.float32)            # ~1/6 "positives", the same on every rank
     weight = torch.full((P,), 1.0 / P, dtype=torch.float32, device=device)
@@ -470,7 +470,8 @@ def _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_
         ts.append((time.perf_counter() - t0) / steps)
     step_s = _median_max_over_ranks(ts, red_dev)
     out = {"ms_per_step": step_s * 1e3, "steps": steps, "gradient_allreduce": how,
-           "scorer": "one pass over the rank's incidence rows (dl_score_pairs_train)",
+           "scorer": "sharded_forward_loss's choice: one pass over the rank's incidence rows (fp32 tables, bf16 beyond 512 MiB), "
+                     "else forward-with-terms + coefficient-gather backward over the pairs touching the rank's nodes",
            "what": "sharded_forward_loss + backward + allreduce_gradients, max over ranks, median of 3 blocks"}
     del sh, inc
     torch.cuda.empty_cache()

@@ -95,6 +95,18 @@ class OracleBackend:
         dZ[lo:lo + n], dH[lo:lo + n] = accZ, accH
         return torch.from_numpy(prob), torch.from_numpy(dZ), torch.from_numpy(dH)
 
+    # ---- the same training step from the forward scorer + the backward over a pair list of its own (Shard.touching)
+    def score_pairs_fwd_terms(self, Z, H, pairs, t):
+        return self.score_pairs_fwd(Z, H, pairs, t), None
+
+    def score_pairs_bwd_terms(self, Z, H, pairs, t, prob, g_prob, coef, dZ_out, dH_out):
+        self.score_pairs_bwd(Z, H, pairs, t, prob, g_prob, dZ_out, dH_out)
+
+    def pair_bce_grad(self, prob, label, weight):
+        pr, y, w = prob.numpy().astype(f32), label.numpy(), weight.numpy()
+        g = (w * (pr - y) / np.maximum(pr * (f32(1) - pr), f32(1e-12))).astype(f32)
+        return self.pair_bce_sum(prob, label, weight), torch.from_numpy(g)
+
     def pair_bce_sum(self, prob, label, weight):
         from oracle import metrics_ref  # noqa: F401
         pr, y, w = prob.numpy().astype(f32), label.numpy(), weight.numpy()

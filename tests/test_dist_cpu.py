@@ -86,7 +86,7 @@ def _worker(rank, world, port, pb, sd, out, n_chunks=1, z_by_peer=False):
         dist.destroy_process_group()
 
 
-def _loss_worker(rank, world, port, pb, sd, out, table, z_by_peer=False, dh_wire=None):
+def _loss_worker(rank, world, port, pb, sd, out, table, z_by_peer=False, dh_wire=None, one_pass=None):
     """The training step through sharded_forward_loss: one-pass scorer over the local incidence rows, no (prob, g_prob)
     all-gather; `table` = storage type of the gathered tables."""
     sys.path.insert(0, ROOT)
@@ -94,6 +94,8 @@ def _loss_worker(rank, world, port, pb, sd, out, table, z_by_peer=False, dh_wire
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if dh_wire is not None:
         os.environ["DL_DH_GATHER"] = dh_wire
+    if one_pass is not None:
+        os.environ["DL_ONE_PASS_SCORER"] = one_pass
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from disenlink_amd import dist as dd
@@ -437,3 +439,40 @@ def test_bf16_wire_of_the_dH_gather_costs_less_than_the_bf16_tables_themselves()
     for r in range(4):
         assert runs["f32"][r]["loss"] == runs["bf16"][r]["loss"]
         assert np.array_equal(runs["f32"][r]["prob"], runs["bf16"][r]["prob"])
+
+
+@pytest.mark.parametrize("world,table", [(2, "f32"), (4, "f32"), (4, "bf16")])
+def test_sharded_training_step_from_the_touching_pairs(world, table):
+    """The other scorer of sharded_forward_loss (DL_ONE_PASS_SCORER=0; the default for cache-resident bf16 tables, where
+    the one-pass kernel of wide shapes runs one wave per SIMD): every rank scores the pairs that TOUCH its nodes itself
+    (Shard.touching), forms their BCE gradient and runs the scorer backward over that list — no per-pair data crosses the
+    ranks.  Same results as the one-pass form: losses, probabilities of the owned pairs, summed weight gradients against
+    the unsharded dense oracle."""
+    from disenlink_amd.model import Disentangle
+    pb = _skewed_problem()
+    torch.manual_seed(0)
+    sd = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"]).state_dict()
+    emb_ref, prob_ref, loss_ref, grads_ref = _reference(pb, sd)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_loss_worker, args=(world, _free_port(), pb, sd, out, table, False, None, "0"), nprocs=world, join=True)
+    tol = dict(rtol=1e-5, atol=1e-6) if table == "f32" else dict(rtol=5e-2, atol=2e-2)
+    gtol = 2e-4 if table == "f32" else 8e-2
+    for r in range(world):
+        o = out[r]
+        q0, q1 = o["pairs"]
+        np.testing.assert_allclose(o["prob"], prob_ref[q0:q1], **tol)
+        r0, r1 = o["rows"]
+        np.testing.assert_allclose(o["emb"], emb_ref[r0:r1], **tol)
+        assert abs(o["loss"] - loss_ref) <= (1e-5 if table == "f32" else 5e-2) * max(1.0, abs(loss_ref))
+        for k, g in o["grads"].items():
+            ref = grads_ref[k]
+            assert np.abs(g - ref).max() <= gtol * max(np.abs(ref).max(), 1e-6), (k, np.abs(g - ref).max(), np.abs(ref).max())
+    # the touching list: every pair with a local endpoint, the owned ones a contiguous range of it
+    from disenlink_amd import dist as dd
+    sh = dd.Shard.build(1, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4)
+    idx, touch, a0, a1 = sh.touching()
+    ppu, ppv = sh.part.to_padded(pb["pu"]), sh.part.to_padded(pb["pv"])
+    want = np.flatnonzero(((ppu >= sh.lo) & (ppu < sh.hi)) | ((ppv >= sh.lo) & (ppv < sh.hi)))
+    assert np.array_equal(idx.numpy(), want) and a1 - a0 == sh.pair_hi - sh.pair_lo
+    assert np.array_equal(idx.numpy()[a0:a1], np.arange(sh.pair_lo, sh.pair_hi))

@@ -415,10 +415,25 @@ def test_sharded_training_step_over_rccl_matches_the_unsharded_module():
         loss_l.backward()
         dl_dist.allreduce_gradients(model)
         got_l = [p.grad.clone() for p in model.parameters()]
+        # ... and from the pairs that touch the rank's nodes: forward scorer keeping its terms + coefficient-gather backward
+        import os
+        os.environ["DL_ONE_PASS_SCORER"] = "0"
+        try:
+            emb_t, prob_t, loss_t = dl_dist.sharded_forward_loss(model, x, shard, lab, wts)
+            model.zero_grad()
+            loss_t.backward()
+            dl_dist.allreduce_gradients(model)
+            got_t = [p.grad.clone() for p in model.parameters()]
+        finally:
+            del os.environ["DL_ONE_PASS_SCORER"]
         torch.cuda.synchronize()
     finally:
         if own_group:
             tdist.destroy_process_group()
+    np.testing.assert_allclose(prob_t.detach().cpu().numpy(), prob.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert abs(float(loss_t.detach()) - float(loss_l.detach())) <= 1e-6 * abs(float(loss_l.detach()))
+    for g3, w in zip(got_t, want):
+        assert float((g3 - w).abs().max()) <= 2e-5 * max(float(w.abs().max()), 1e-8)
     np.testing.assert_allclose(emb_s.detach().cpu().numpy(), emb.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(prob_s.detach().cpu().numpy(), prob.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(prob_l.detach().cpu().numpy(), prob.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
