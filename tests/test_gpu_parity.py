@@ -1538,7 +1538,8 @@ def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,d,dtype", [(8, 64, torch.float32), (4, 32, torch.float32), (16, 128, torch.float32), (8, 64, torch.bfloat16)])
+@pytest.mark.parametrize("K,d,dtype", [(8, 64, torch.float32), (4, 64, torch.float32), (4, 32, torch.float32), (16, 128, torch.float32),
+                                       (8, 64, torch.bfloat16)])
 def test_one_pass_training_scorer_matches_the_separate_kernels(K, d, dtype):
     """dl_score_pairs_train (scorer forward + weighted-BCE gradient + scorer backward in one pass over the incidence
     plan) against dl_score_pairs_fwd -> dl_pair_bce -> dl_score_pairs_bwd: prob, loss, dZ, dH and the full autograd
