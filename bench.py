@@ -491,6 +491,10 @@ def main():
     # DL_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the collectives go through gloo — a functional
     # rehearsal of the N>1 code on a one-GPU box (RCCL refuses two ranks on one device); never a measurement.
     rehearse = bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU"))
+    if rehearse and world > 1 and args.scale == 1.0 and not os.environ.get("DL_REHEARSE_FULL_SIZE"):
+        # gloo carries a device table through host memory: at full snap-patents size one gather takes seconds.  The
+        # rehearsal is functional only, so it runs the same blocks at 2 % of their size (the line says so).
+        args.scale = 0.02
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

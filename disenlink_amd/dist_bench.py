@@ -538,7 +538,11 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
             "cpu_baseline_note": "timed on rank 0 at N=1 only (bench.py --gpus 1), as the contract says",
             "blocks": {r["name"]: r for r in results},
             "launch": {"self_launched": bool(os.environ.get("DL_BENCH_SELF_LAUNCHED")),
-                       "backend": dist.get_backend(), "rehearsal_on_one_gpu": bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU"))}}
+                       "backend": dist.get_backend(), "rehearsal_on_one_gpu": bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU")),
+                       "scale": args.scale,
+                       "note": ("REHEARSAL: all ranks on cuda:0, gloo through host memory, blocks at 2 % of their size unless "
+                                "DL_REHEARSE_FULL_SIZE=1 — functional only, never a measurement")
+                       if os.environ.get("DL_REHEARSE_ON_ONE_GPU") else "one rank per GPU over RCCL"}}
     return line
 
 
