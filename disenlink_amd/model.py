@@ -290,7 +290,11 @@ class Disentangle(nn.Module):
         # one-pass kernel's registers are not); bf16 tables in HBM — one pass again.  DL_ONE_PASS_SCORER=0/1 forces.
         mode = os.environ.get("DL_ONE_PASS_SCORER", "auto")
         table_bytes = 2 * Z.shape[0] * Z.shape[1] * Z.shape[2] * (4 if self.table_dtype == torch.float32 else 2)
-        one_pass = mode == "1" or (mode != "0" and (self.table_dtype == torch.float32 or table_bytes > (512 << 20)))
+        # (round 4 re-measurement, tools/score_train_time.py: bf16 tables at K = 8, d = 64 now favour one pass too — Penn94-sized
+        # 3.49 vs 4.37 ms, squirrel 395 vs 458 us; the exception that remains is the WIDE shape, K d >= 2048, whose one-pass
+        # kernel sits at one wave per SIMD: K = 16, d = 128 bf16 104 vs 22.6 ms — while fp32 there is 29.8 vs 48.1)
+        one_pass = mode == "1" or (mode != "0" and (self.table_dtype == torch.float32 or table_bytes > (512 << 20)
+                                                    or Z.shape[1] * Z.shape[2] < 2048))
         if one_pass and ops.score_pairs_train_supported(pairs, Z.shape[1], Z.shape[2], dt):
             if self.table_dtype == torch.float32 and Z.dtype == torch.float32 and graph.n_rows == graph.n_nodes:
                 from . import native                            # the compiled binding: the same step as ONE C++ autograd node
