@@ -418,8 +418,10 @@ def self_launch(n_gpus: int, argv) -> int:
     (non-zero when any rank failed or no line came back).  This process makes NO GPU / HIP call — it neither asks
     torch.cuda anything nor loads the library — and replaces no running program (no os.exec*)."""
     from disenlink_amd.launch import launch_ranks
-    return launch_ranks(n_gpus, [os.path.abspath(__file__)], list(argv), cwd=ROOT, result_marker='"metric"',
-                        env_extra={"DL_BENCH_SELF_LAUNCHED": "1"})
+    # the arguments travel in the environment: torch.distributed.run's parser classifies every "--option" on its command
+    # line before it reaches the script's remainder, and e.g. "--d" is an ambiguous prefix of its "--duplicate-*-filters"
+    return launch_ranks(n_gpus, [os.path.abspath(__file__)], [], cwd=ROOT, result_marker='"metric"',
+                        env_extra={"DL_BENCH_SELF_LAUNCHED": "1", "DL_BENCH_ARGV": json.dumps(list(argv))})
 
 
 def launch_check(rank: int, world: int) -> int:
@@ -467,7 +469,8 @@ def main():
     ap.add_argument("--hbm-steps", type=int, default=5)
     ap.add_argument("--warm-s", type=float, default=0.3, help="warm up by time for at least this long (0: --warmup steps only)")
     ap.add_argument("--min-region-s", type=float, default=1.0, help="timed region: at least this long (0: --repeats blocks)")
-    args = ap.parse_args()
+    argv = json.loads(os.environ["DL_BENCH_ARGV"]) if os.environ.get("DL_BENCH_ARGV") and under_launcher() else None
+    args = ap.parse_args(argv)                                 # (self-launched ranks: see self_launch)
     WARM_S[0], REGION_S[0] = args.warm_s, args.min_region_s
     want = lambda s: args.sections == "all" or s in args.sections.split(",")
     if args.gpus < 1:
