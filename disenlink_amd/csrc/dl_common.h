@@ -245,7 +245,8 @@ struct WaveSeg {
     bool active;      // a real segment (not padding, not past the end)
     bool head;        // first wave of its unit: sums the unit and writes its result
     int wave;         // wave index in the workgroup
-    int n_unit;       // head: number of waves (segments) in the unit
+    int n_unit;       // number of waves (segments) of the unit from this wave on (head: the whole unit)
+    int upos;         // position of this wave inside its unit (head: 0)
 };
 
 __device__ __forceinline__ WaveSeg load_wave_seg(const dl_csr_plan& c) {
@@ -286,6 +287,15 @@ __device__ __forceinline__ WaveSeg load_wave_seg(const dl_csr_plan& c) {
         if (u >= w.wave) {
             run = run && rows[u] == mine && slots[u] == slot;
             w.n_unit += run ? 1 : 0;
+        }
+    }
+    w.upos = 0;
+    bool back = true;
+#pragma unroll
+    for (int u = WAVES_PER_BLOCK - 1; u >= 0; --u) {
+        if (u < w.wave) {
+            back = back && rows[u] == mine && slots[u] == slot;
+            w.upos += back ? 1 : 0;
         }
     }
     w.si.row = mine;

@@ -9,9 +9,10 @@
 //                                                  ws_graph, ws_pairs, ws_bce) -> (H, prob, loss)
 //
 // graph_ptr / inc_ptr: addresses of the dl_graph / dl_pair_incidence structs the Python Graph / PairList objects own
-// (they must outlive the call and its backward); ws_*: the caller's scratch tensors (the C ABI never allocates).
+// (they must outlive the call and its backward: disenlink_amd/native.py hangs the Python objects on the node's metadata);
+// ws_*: the caller's scratch tensors (the C ABI never allocates).
 // Replaces model.py:56-75, 109-113 + the loss of main_disentangled.py:195 on a pair list, like ops.HotPathPairsLoss —
-// same kernels, same bits.  fp32 tables; gradients on `prob` are not supported here (the Python operator has them).
+// same kernels, same bits, also for a gradient arriving on `prob` or on the embedding.  fp32 tables.
 // Built by disenlink_amd/build.py with g++ against the installed torch (no device code in this file).
 #include <torch/library.h>
 #include <torch/autograd.h>
@@ -59,27 +60,32 @@ struct HotPathPairsLoss : public torch::autograd::Function<HotPathPairsLoss> {
         check(dl_pair_bce(prob.data_ptr<float>(), label.data_ptr<float>(), weight.data_ptr<float>(), (int)P, loss.data_ptr<float>(),
                           gbce.data_ptr<float>(), ws_b.data_ptr(), (size_t)ws_b.numel(), st), "dl_pair_bce");
         ctx->saved_data["graph"] = graph_ptr;
+        ctx->saved_data["inc"] = inc_ptr;
         ctx->saved_data["beta"] = beta;
         ctx->saved_data["t"] = t;
-        ctx->save_for_backward({Z, p, a, s, dZs, dHs, ws_g});
+        // H and prob are outputs of this node (autograd handles saved outputs without a reference cycle); they and the
+        // pair workspace serve the general backward (a gradient arriving on prob)
+        ctx->save_for_backward({Z, p, a, s, dZs, dHs, ws_g, H, prob, ws_p});
         ctx->set_materialize_grads(false);
         Tensor loss0 = loss.select(0, 0);
-        ctx->mark_non_differentiable({prob});
         return {H, prob, loss0};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const auto saved = ctx->get_saved_variables();
         const Tensor &Z = saved[0], &p = saved[1], &a = saved[2], &s = saved[3], &dZs = saved[4], &dHs = saved[5], &ws_g = saved[6];
+        const Tensor &H = saved[7], &prob = saved[8], &ws_p = saved[9];
         const auto* g = reinterpret_cast<const dl_graph*>(ctx->saved_data["graph"].toInt());
+        const auto* inc = reinterpret_cast<const dl_pair_incidence*>(ctx->saved_data["inc"].toInt());
         const float beta = (float)ctx->saved_data["beta"].toDouble(), t = (float)ctx->saved_data["t"].toDouble();
         const int K = (int)Z.size(1), d = (int)Z.size(2);
         const Tensor& g_emb = grads[0];
+        const Tensor& g_prob = grads[1];
         const Tensor& g_loss = grads[2];
         at::AutoDispatchBelowADInplaceOrView guard;
         void* st = stream();
         Tensor dZ;
-        if (g_loss.defined() && !g_emb.defined()) {
+        if (g_loss.defined() && !g_emb.defined() && !g_prob.defined()) {
             // loss.backward(): everything downstream is linear in the scorer's gradients, so d/dloss scales the RESULT
             // inside the last kernel (dl_route_aggregate_bwd_scaled) — no scaling passes over the two [N,K,d] arrays
             dZ = at::empty_like(Z);
@@ -89,9 +95,21 @@ struct HotPathPairsLoss : public torch::autograd::Function<HotPathPairsLoss> {
                                                 scale.data_ptr<float>(), dZ.data_ptr<float>(), ws_g.data_ptr(),
                                                 (size_t)ws_g.numel(), st), "dl_route_aggregate_bwd_scaled");
         } else {
+            // the general case, in the order of ops.HotPathPairsLoss.backward (same bits): the loss's share, then another
+            // function of the scores through the ordinary scorer backward (dl_score_pairs_bwd, recompute form), then a
+            // gradient on the embedding
             Tensor dH = g_loss.defined() ? dHs * g_loss : at::zeros_like(dHs);
             dZ = g_loss.defined() ? dZs * g_loss : at::zeros_like(dZs);
-            if (g_emb.defined()) dH = dH + g_emb.to(at::kFloat).reshape(dH.sizes());
+            if (g_prob.defined()) {
+                const Tensor gp = g_prob.to(at::kFloat).contiguous();
+                Tensor dZ2 = at::empty_like(Z), dH2 = at::empty_like(Z);
+                check(dl_score_pairs_bwd(Z.data_ptr(), H.data_ptr(), K, d, DL_F32, t, inc, prob.data_ptr<float>(), gp.data_ptr<float>(),
+                                         nullptr, dZ2.data_ptr<float>(), dH2.data_ptr<float>(), ws_p.data_ptr(), (size_t)ws_p.numel(),
+                                         st), "dl_score_pairs_bwd");
+                dZ.add_(dZ2);
+                dH.add_(dH2);
+            }
+            if (g_emb.defined()) dH.add_(g_emb.to(at::kFloat).reshape(dH.sizes()));
             dH = dH.contiguous();
             check(dl_route_aggregate_bwd(g, Z.data_ptr(), K, d, DL_F32, beta, t, p.data_ptr<uint8_t>(), a.data_ptr<float>(),
                                          s.data_ptr<float>(), dH.data_ptr<float>(), dZ.data_ptr<float>(), 1, ws_g.data_ptr(),

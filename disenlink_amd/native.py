@@ -7,8 +7,7 @@ autograd node registered with TORCH_LIBRARY over the same C ABI the ctypes bindi
 
 Same kernels and bits as ``ops.HotPathPairsLoss`` (route + aggregate + one-pass scorer + loss value; backward: routing /
 aggregation with d/dloss applied inside the last kernel); what it removes is the Python between the launches (ctypes
-marshalling, autograd.Function frames): host time of the eager loop on small graphs.  fp32 tables only; a gradient arriving
-on ``prob`` needs the Python operator.  ``Disentangle.forward_pairs_loss`` uses it when it is built and the shape has a
+marshalling, autograd.Function frames): host time of the eager loop on small graphs.  fp32 tables only.  ``Disentangle.forward_pairs_loss`` uses it when it is built and the shape has a
 tuned kernel (``DL_NATIVE_OPS=0`` keeps the Python operators).  There is no fallback inside: a missing library means
 ``available()`` is False and the ctypes path runs — which itself has no CPU fallback.
 """
@@ -35,7 +34,7 @@ def load() -> bool:
             try:
                 torch.ops.load_library(LIB_PATH)
                 ok = hasattr(torch.ops, "disenlink_native") and hasattr(torch.ops.disenlink_native, "hot_path_pairs_loss")
-            except OSError as e:           # built against another torch: the ctypes binding (the same HIP kernels) carries on
+            except (OSError, RuntimeError) as e:   # built against another torch / registered twice: the ctypes binding (the same HIP kernels) carries on
                 import warnings
                 warnings.warn(f"libdisenlink_torch.so does not load ({e}); rebuild with python -m disenlink_amd.build — "
                               "using the ctypes binding of the same C ABI")
@@ -60,5 +59,10 @@ def hot_path_pairs_loss(Z: torch.Tensor, graph: Graph, pairs: PairList, beta: fl
     ws_g = ops._workspace(graph.c_plan(), Z.device, K, d)
     ws_p = ops._workspace(pairs.c_plan(), Z.device, K, d)
     ws_b = ops._ws_bce(Z.device)
-    return torch.ops.disenlink_native.hot_path_pairs_loss(Z, C.addressof(graph._struct), C.addressof(pairs._struct),
-                                                          graph.n_edges, float(beta), float(t), label, weight, ws_g, ws_p, ws_b)
+    H, prob, loss = torch.ops.disenlink_native.hot_path_pairs_loss(Z, C.addressof(graph._struct), C.addressof(pairs._struct),
+                                                                   graph.n_edges, float(beta), float(t), label, weight, ws_g, ws_p, ws_b)
+    # the node's backward dereferences the two structs (and the device arrays they point to): they live exactly as long as
+    # the node does, whatever the caller does with its Graph / PairList in between (a per-epoch resampled pair list)
+    if loss.grad_fn is not None:
+        loss.grad_fn.metadata["disenlink_keepalive"] = (graph, pairs)
+    return H, prob, loss

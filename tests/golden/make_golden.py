@@ -151,6 +151,9 @@ TRAJ = [
     # name,       N,  F, K,  d, nhid, beta, t, x_scale, p_edge, m, epochs, lr
     ("traj_k4",  90, 12, 4, 32,  16, 0.7, 1, 0.4, 0.06, 3, 8, 1e-2),
     ("traj_k8", 120, 16, 8,  8,   1, 0.5, 1, 0.8, 0.05, 5, 8, 5e-3),
+    # round 5: the benchmark's factor shape (K=8, d=64) at temperature 2 — the `/ t` of model.py:56 inside the one-pass
+    # training scorer (its T1 = false instantiation) pinned by a training trajectory of the reference
+    ("traj_k8_d64_t2", 140, 16, 8, 64, 32, 0.6, 2, 0.5, 0.05, 5, 8, 5e-3),
 ]
 
 
@@ -284,9 +287,13 @@ def main():
         for idx, spec in enumerate(CASES):
             run_case(model_mod, spec, seed=100 + idx)
         auc_cases()
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]     # --only=traj_k8_d64_t2: one trajectory
     if "--adam-only" not in sys.argv:
         for idx, spec in enumerate(TRAJ):
-            run_trajectory(model_mod, spec, seed=300 + idx)
+            if not only or spec[0] in only:
+                run_trajectory(model_mod, spec, seed=300 + idx)
+    if only:
+        return
     for case, steps, lr in ADAM:
         run_adam_steps(model_mod, case, steps, lr)
 

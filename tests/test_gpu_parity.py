@@ -1612,6 +1612,142 @@ def test_one_pass_training_scorer_matches_the_separate_kernels(K, d, dtype):
     assert float((outs[True][2] - outs[False][2]).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-3) * scale
 
 
+def _one_pass_case(K, d, dtype, seed, overflow=False):
+    """A seeded scoring problem for the one-pass training scorer: tables, pair list, labels, loss weights — with a few
+    saturated scores (prob == 1 exactly), weight-0 pairs (validation pairs riding along), and optionally one node whose
+    exponent overflows (z.z / t > 88.7)."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import Graph, PairList
+    from disenlink_amd.metrics import pair_bce_weights
+    rng = np.random.default_rng(seed)
+    N, E, P = 600, 4000, 8000
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    pu, pv = rng.integers(0, N, P), rng.integers(0, N, P)
+    pu[:40], pv[:40] = 3, rng.integers(0, N, 40)                     # the saturated node's row gets several segments' worth
+    G = Graph.from_edge_rows(torch.from_numpy(src), torch.from_numpy(dst), N).to(DEV)
+    pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N, row_bytes=K * d * (4 if dtype == torch.float32 else 2))
+    amp = 0.35 * (32 / d) ** 0.5
+    Z = torch.randn(N, K, d, generator=torch.Generator().manual_seed(seed)) * amp
+    Z[3] *= 6.0                                                      # saturated scores
+    if overflow:
+        Z[5] = 2.0 * (128 / d) ** 0.5                                # z5.z5 = 512 per factor: exp(512 / 2) = inf, also at t = 2
+        pu[100:104], pv[100:104] = 5, 5
+        pairs = PairList.build(torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV), N, row_bytes=K * d * (4 if dtype == torch.float32 else 2))
+    Z = Z.to(DEV)
+    label = torch.from_numpy((rng.random(P) < 0.3).astype(np.float32)).to(DEV)
+    weight = pair_bce_weights(int(P * 0.2), P - int(P * 0.2), 5, DEV)
+    weight[-500:] = 0.0
+    return G, pairs, Z, label, weight, pu, pv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,d,dtype", [(8, 64, torch.float32), (4, 64, torch.float32),         # wave-per-entry kernel, T1 = false
+                                       (4, 32, torch.float32), (16, 128, torch.float32),       # the other fp32 shapes
+                                       (8, 64, torch.bfloat16), (16, 128, torch.bfloat16)])    # bf16 tables
+@pytest.mark.parametrize("t", [2.0, 1.0])
+def test_one_pass_training_scorer_matches_the_oracle_directly(K, d, dtype, t):
+    """dl_score_pairs_train against oracle/sparse_ref.score_pairs_bwd (NOT against the separate kernels): prob, dZ, dH at
+    temperature 2 (the `/ t` of model.py:56,113; main_disentangled.py:40) and 1, incl. saturated pairs (zero gradient),
+    weight-0 pairs (nothing at all) and — fp32 (8, 64) — a node whose exponent overflows.  bf16 tables: the oracle is
+    evaluated on the same bf16-rounded tables (the reference has no bf16 path)."""
+    from disenlink_amd import ops
+    overflow = (K, d, dtype) == (8, 64, torch.float32)
+    G, pairs, Z, label, weight, pu, pv = _one_pass_case(K, d, dtype, seed=K * 11 + d + int(t), overflow=overflow)
+    beta = 0.6
+    Zt = Z if dtype == torch.float32 else Z.to(dtype)
+    H = ops.aggregate_fwd(G, Zt, beta, *ops.route_fwd(G, Zt, t))
+    prob, dZ, dH = ops.score_pairs_train(Zt, H, pairs, t, label, weight)
+    Zh, Hh = Zt.float().cpu().numpy(), H.float().cpu().numpy()
+    lab, wgt = label.cpu().numpy(), weight.cpu().numpy()
+    prob_o, q_o, ex_o = sparse_ref.score_pairs(Zh, Hh, pu, pv, t, return_parts=True)
+    pr = prob.cpu().numpy()
+    assert np.array_equal(np.isnan(pr), np.isnan(prob_o))
+    fin = ~np.isnan(prob_o)
+    np.testing.assert_allclose(pr[fin], prob_o[fin], rtol=2e-5, atol=2e-6)
+    assert int((prob_o == 1.0).sum()) >= 20                          # the saturated pairs are really there
+    # the weighted-BCE gradient of main_disentangled.py:195 in probability space (F.binary_cross_entropy's clamp)
+    with np.errstate(invalid="ignore", over="ignore"):
+        g_prob = (wgt * (prob_o - lab) / np.maximum(prob_o * (1 - prob_o), np.float32(1e-12))).astype(np.float32)
+    g_prob[wgt == 0] = 0.0
+    # An overflowed exponent (e_k = inf) saturates the score, so its logit gradient is exactly 0; the reference's autograd
+    # then forms 0 * inf = NaN for EVERY parameter (MulBackward of model.py:113 — also for unmasked entries: a run that
+    # overflows is dead there).  The one-pass kernel keeps 0 * inf = 0 (documented in DESIGN.md): such pairs contribute
+    # nothing, which is what the oracle gives with those pairs left out.
+    keep = np.isfinite(ex_o).all(axis=1) & np.isfinite(q_o).all(axis=1)
+    assert overflow == bool((~keep).any())
+    dZ_o, dH_o = sparse_ref.score_pairs_bwd(Zh, Hh, pu[keep], pv[keep], t, g_prob[keep])
+    for name, got, want in (("dZ", dZ, dZ_o), ("dH", dH, dH_o)):
+        got = got.cpu().numpy()
+        assert np.isfinite(got).all(), name
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-12, (name, np.abs(got - want).max(), np.abs(want).max())
+    assert float(np.abs(dH_o).max()) > 0 and float(np.abs(dZ_o).max()) > 0
+
+
+@pytest.mark.gpu
+def test_compiled_binding_and_python_operator_agree_at_temperature_2_and_with_a_loss_on_prob():
+    """native.hot_path_pairs_loss (C++ autograd node) against ops.HotPathPairsLoss at t = 2 — the wave kernel's T1 = false
+    instantiation through both bindings — bit for bit, for loss.backward() and with another loss term on `prob` and on
+    the embedding (the advisor's round-4 finding: the compiled node used to drop a gradient arriving on prob); the graph
+    and pair list may be dropped by the caller between forward and backward."""
+    import gc
+    from disenlink_amd import native, ops
+    assert native.available()
+    for (K, d) in ((8, 64), (4, 64)):
+        out = {}
+        for name in ("python", "native"):
+            for extra in (False, True):
+                G, pairs, Z0, label, weight, _pu, _pv = _one_pass_case(K, d, torch.float32, seed=77)
+                Z = Z0.clone().requires_grad_(True)
+                if name == "python":
+                    H, prob, loss = ops.HotPathPairsLoss.apply(Z, G, pairs, 0.6, 2.0, torch.float32, label, weight)
+                else:
+                    H, prob, loss = native.hot_path_pairs_loss(Z, G, pairs, 0.6, 2.0, label, weight)
+                del G, pairs                                           # the node must keep what its backward dereferences
+                gc.collect()
+                total = loss * 3.0 + ((prob * prob).sum() * 1e-2 + (H * H).sum() * 1e-3 if extra else 0.0)
+                total.backward()
+                out[(name, extra)] = (H.detach().clone(), prob.detach().clone(), loss.detach().clone(), Z.grad.clone())
+        for extra in (False, True):
+            for a_, b_, what in zip(out[("python", extra)], out[("native", extra)], ("H", "prob", "loss", "dZ")):
+                assert torch.equal(a_, b_), (K, d, what, extra, float((a_ - b_).abs().max()))
+        assert not torch.equal(out[("native", False)][3] , out[("native", True)][3])          # the prob / emb terms did arrive
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native_ops", ["1", "0"])
+def test_pair_list_training_with_the_one_pass_scorer_follows_the_reference_trajectory_at_t2(native_ops, monkeypatch):
+    """tests/golden/traj_k8_d64_t2.npz — the REFERENCE model trained 8 epochs at K = 8, d = 64, temperature 2 under the
+    reference's schedule — followed by the pair-list training loop (forward_pairs_loss: route, aggregate, the one-pass
+    training scorer's wave kernel with T1 = false, Adam, AUC), through the compiled binding and through the Python
+    operators: per-epoch loss and validation AUC, test AUC with the best weights."""
+    import sys, os
+    from conftest import load_trajectory
+    from disenlink_amd import native
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_dist_cpu import _split_from_trajectory
+    monkeypatch.setenv("DL_NATIVE_OPS", native_ops)
+    monkeypatch.setenv("DL_ONE_PASS_SCORER", "1")
+    native._state["loaded"] = None                                    # re-read DL_NATIVE_OPS
+    try:
+        g = load_trajectory("traj_k8_d64_t2")
+        m = g["meta"]
+        assert (m["K"], m["d"], m["t"]) == (8, 64, 2)
+        model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
+        model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")})
+        model = model.to(DEV)
+        run = prepare_run(_split_from_trajectory(g), torch.device(DEV), row_bytes=m["K"] * m["d"] * 4)
+        res = run_link_prediction(model, torch.from_numpy(g["x"]).to(DEV), run, epochs=m["epochs"], lr=m["lr"], patience=200,
+                                  use_graph=False)
+        for ep in range(m["epochs"]):
+            assert abs(res.losses[ep] - g["losses"][ep]) <= 2e-4 * abs(g["losses"][ep]), (ep, res.losses[ep], g["losses"][ep])
+            assert abs(res.val_aucs[ep] - g["val_aucs"][ep]) <= 2e-3, (ep, res.val_aucs[ep], g["val_aucs"][ep])
+        assert abs(res.test_auc - float(g["test_auc"])) <= 5e-3
+    finally:
+        native._state["loaded"] = None
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_training_with_the_one_pass_scorer_follows_the_separate_kernels(use_graph, monkeypatch):
