@@ -564,8 +564,9 @@ def main():
     if want("fwd_bwd"):
         gp = torch.full((P,), 1.0 / P, device=device)
         yb_ = (torch.rand(P, device=device) < 0.2).float()
-        # the training loop's own choice (model.forward_pairs_loss): fp32 tables take the one-pass scorer
-        one_pass_fb = args.dtype == "f32" and ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32)
+        # the training loop's own choice (ops.one_pass_scorer_wanted, shared with model.forward_pairs_loss and dist)
+        one_pass_fb = ops.one_pass_scorer_wanted(torch.float32 if args.dtype == "f32" else torch.bfloat16, N, K, d) and \
+            ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32 if args.dtype == "f32" else ops._lib.DL_BF16)
         def train_step(ev=None):
             rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
             rec(0)
@@ -658,7 +659,7 @@ def main():
             return ops.score_pairs_train(Z, Hs, pairs, t, yb, wb)
         times = {}
         for name, fn in (("separate_us", separate), ("one_pass_us", one_pass)):
-            if name == "one_pass_us" and not ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32):
+            if name == "one_pass_us" and not ops.score_pairs_train_supported(pairs, K, d, ops._lib.DL_F32 if args.dtype == "f32" else ops._lib.DL_BF16):
                 continue
             for _ in range(2):
                 fn()

@@ -1319,6 +1319,271 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
     }
 }
 
+// ---------------------------------------------------------------------------- one-pass training scorer, wave per entry, wide rows
+// Round 5: the wave-per-entry form for rows of K*D = 2,048 elements (K = 16, d = 128: BASELINE configs[4]), where the
+// group-per-entry kernel above needs 256 registers (one wave per SIMD, 104 ms on the Penn94-shaped graph with bf16 tables)
+// and the module fell back to three separate kernels (22.5 ms, 3x the forward's gathers).
+//
+// A lane holds CHUNKS of 16 bytes of a table row as they lie in memory — 8 bf16 or 4 fp32 elements — chunk number
+// j * 64 + lane of the row, NJ chunks per lane and table: a factor slice (d = 128) is G = 16 consecutive lanes with bf16
+// tables (one DPP row), 32 with fp32 tables; lane group r holds the factors r, r + 64/G, ...  bf16 chunks stay PACKED in
+// the registers (a gathered entry = 32 registers instead of 64): the dot products with the node's own rows (packed too,
+// re-read from the wave's LDS region every step) are v_dot2c_f32_bf16 — two exact products and the running fp32 sum per
+// instruction, symmetric in its operands, so both endpoints of a pair still form the same bits — and the elements are
+// widened only where they are accumulated (a shift / a mask each).  Per lane: 64 accumulator registers (the node's
+// [dZ row | dH row], 2 x 32 elements) + U gathered entries.  bf16: U = 1, four waves per SIMD, 35 KB of LDS per
+// workgroup; fp32: U = 1 at two waves per SIMD (its own rows alone are 64 KB of LDS per workgroup).
+// The 2 U NJ partial dot products of a step are reduced over the G lanes by one transposed reduction (value index = the
+// top bits of the lane's position in its group: z.z below G/2, h.h above), one expf and one sigmoid per step, the
+// coefficients formed in the lanes that hold them and broadcast by DPP moves, as in the D = 64 kernel above.
+// Unit sum: the own-row regions (4 x 8 KB with bf16 tables) are too small to stage four [dZ | dH] rows of 16 KB at
+// once, so the unit is summed as a TREE in two rounds through two 16 KB slots — (s0 + s1) + (s2 + s3); which waves pair
+// up depends on the row's segments alone (shard-independent, reproducible).
+#ifndef DL_TRAIN_WIDE_KERNEL
+#define DL_TRAIN_WIDE_KERNEL 1        // -DDL_TRAIN_WIDE_KERNEL=0: the group-per-entry kernel, for A/B runs
+#endif
+#ifndef DL_TRAIN_WIDE_U_BF16
+#define DL_TRAIN_WIDE_U_BF16 1        // entries per step with bf16 tables ...
+#endif
+#ifndef DL_TRAIN_WIDE_WAVES_BF16
+#define DL_TRAIN_WIDE_WAVES_BF16 4    // ... and waves per SIMD (U = 2 needs 3)
+#endif
+#ifndef DL_TRAIN_WIDE_U_F32
+#define DL_TRAIN_WIDE_U_F32 1         // fp32 tables: U = 2 spills 17 registers at the 256 the two waves per SIMD allow
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 v2bf16 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct WideChunk;
+template <>
+struct WideChunk<bf16_t> {
+    static constexpr int CH = 8;                                    // elements per 16-byte chunk
+    // (the dwords are copied into scalars first: __builtin_bit_cast applied to a vector ELEMENT lvalue — bit_cast(a.y) — read
+    // element 0 every time with hipcc 7.2: four dot2c on the same registers)
+    static __device__ __forceinline__ float dot2(unsigned a, unsigned b, float s) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf16, a), __builtin_bit_cast(v2bf16, b), s, false);
+    }
+    static __device__ __forceinline__ float dot(const u32x4& a, const u32x4& b) {
+        const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+        return dot2(a3, b3, dot2(a2, b2, dot2(a1, b1, dot2(a0, b0, 0.0f))));
+    }
+    static __device__ __forceinline__ void fma(float (&acc)[8], float c, const u32x4& x) {
+        acc[0] = fmaf(c, __uint_as_float(x.x << 16), acc[0]); acc[1] = fmaf(c, __uint_as_float(x.x & 0xffff0000u), acc[1]);
+        acc[2] = fmaf(c, __uint_as_float(x.y << 16), acc[2]); acc[3] = fmaf(c, __uint_as_float(x.y & 0xffff0000u), acc[3]);
+        acc[4] = fmaf(c, __uint_as_float(x.z << 16), acc[4]); acc[5] = fmaf(c, __uint_as_float(x.z & 0xffff0000u), acc[5]);
+        acc[6] = fmaf(c, __uint_as_float(x.w << 16), acc[6]); acc[7] = fmaf(c, __uint_as_float(x.w & 0xffff0000u), acc[7]);
+    }
+};
+template <>
+struct WideChunk<float> {
+    static constexpr int CH = 4;
+    static __device__ __forceinline__ float dot(const u32x4& a, const u32x4& b) {
+        return dot4_packed(make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)),
+                           make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)));
+    }
+    static __device__ __forceinline__ void fma(float (&acc)[4], float c, const u32x4& x) {
+        acc[0] = fmaf(c, __uint_as_float(x.x), acc[0]); acc[1] = fmaf(c, __uint_as_float(x.y), acc[1]);
+        acc[2] = fmaf(c, __uint_as_float(x.z), acc[2]); acc[3] = fmaf(c, __uint_as_float(x.w), acc[3]);
+    }
+};
+
+template <int K, int D, typename T>
+struct TrainWide {
+    static constexpr bool ok = DL_TRAIN_WIDE_KERNEL && K == 16 && D == 128;
+    static constexpr int U = sizeof(T) == 2 ? DL_TRAIN_WIDE_U_BF16 : DL_TRAIN_WIDE_U_F32;
+    static constexpr int WAVES = sizeof(T) == 2 ? DL_TRAIN_WIDE_WAVES_BF16 : 2;      // fp32: 67 KB of LDS per workgroup
+};
+
+// value of lane `idx` (0 .. 15, a constant once the caller's loops are unrolled) of this lane's DPP row: row_newbcast
+__device__ __forceinline__ float row_bcast_idx(float v, int idx) {
+    switch (idx) {
+        case 0: return dpp_mov<0x150>(v);   case 1: return dpp_mov<0x151>(v);   case 2: return dpp_mov<0x152>(v);
+        case 3: return dpp_mov<0x153>(v);   case 4: return dpp_mov<0x154>(v);   case 5: return dpp_mov<0x155>(v);
+        case 6: return dpp_mov<0x156>(v);   case 7: return dpp_mov<0x157>(v);   case 8: return dpp_mov<0x158>(v);
+        case 9: return dpp_mov<0x159>(v);   case 10: return dpp_mov<0x15A>(v);  case 11: return dpp_mov<0x15B>(v);
+        case 12: return dpp_mov<0x15C>(v);  case 13: return dpp_mov<0x15D>(v);  case 14: return dpp_mov<0x15E>(v);
+        default: return dpp_mov<0x15F>(v);
+    }
+}
+
+// sum over the factor chunks j of a step: xor offsets OFF, OFF/2, ..., LO inside the lane group
+template <int OFF, int LO>
+__device__ __forceinline__ float sum_over_chunks(float v) {
+    if constexpr (OFF >= LO) {
+        return sum_over_chunks<OFF / 2, LO>(v + xor_lane<OFF>(v));
+    } else {
+        return v;
+    }
+}
+
+template <int K, int D, typename T, int U, int WAVES, bool T1>
+__global__ __launch_bounds__(BLOCK, WAVES) void score_train_wide_kernel(
+        dl_csr_plan g, const int32_t* __restrict__ inc_pair, const T* __restrict__ Z, const T* __restrict__ H, float t,
+        float* __restrict__ dZ, float* __restrict__ dH, float* __restrict__ part, const float* __restrict__ y,
+        const float* __restrict__ w, float* __restrict__ prob_out) {
+    using WC = WideChunk<T>;
+    constexpr int CH = WC::CH, ROW = K * D;
+    constexpr int NJ = ROW / (DL_WAVE * CH);                        // chunks per lane and table row
+    constexpr int G = D / CH;                                       // lanes per factor slice
+    constexpr int NVAL = 2 * U * NJ;                                // partial dot products per lane and step
+    constexpr int DUPL = G / NVAL;                                  // lanes that end up with the same complete sum
+    constexpr int F4 = CH / 4;                                      // float4 per accumulator chunk
+    constexpr int OWN16 = 2 * NJ * DL_WAVE;                         // 16-byte chunks of one wave's own rows [Z | H]
+    constexpr int SLOT16 = 2 * NJ * F4 * DL_WAVE;                   // float4s of one [dZ row | dH row]
+    constexpr int LDS16 = WAVES_PER_BLOCK * OWN16 > 2 * SLOT16 ? WAVES_PER_BLOCK * OWN16 : 2 * SLOT16;
+    static_assert(ROW % (DL_WAVE * CH) == 0 && (G == 16 || G == 32) && NVAL <= G && DUPL * NVAL == G, "lane geometry");
+    static_assert((U & (U - 1)) == 0 && U * DUPL * NJ * 2 == G, "value index = (chunk, entry) in the top bits of the group position");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[LDS16];
+    __shared__ float ent_y[WAVES_PER_BLOCK][DL_WAVE], ent_w[WAVES_PER_BLOCK][DL_WAVE];
+    __shared__ int ent_q[WAVES_PER_BLOCK][DL_WAVE];
+    const WaveSeg ws = load_wave_seg(g);
+    const SegInfo si = ws.si;
+    const int wave = ws.wave, lane = lane_id();
+    const int c = lane & (G - 1);                                   // position in the lane group
+    float az[NJ][CH], ah[NJ][CH];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) az[j][e] = ah[j][e] = 0.0f;
+    u32x4* const mine = lds + wave * OWN16;
+    if (ws.active) {
+        const u32x4* zu = reinterpret_cast<const u32x4*>(Z + (size_t)si.grow * ROW);
+        const u32x4* hu = reinterpret_cast<const u32x4*>(H + (size_t)si.grow * ROW);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            mine[j * DL_WAVE + lane] = zu[j * DL_WAVE + lane];       // read back by this lane only: no barrier needed
+            mine[(NJ + j) * DL_WAVE + lane] = hu[j * DL_WAVE + lane];
+        }
+        int my_col = si.grow;
+        {
+            int my_q = 0;
+            float my_y = 0.0f, my_w = 0.0f;                         // w = 0 past the segment end: no gradient, no output
+            if (si.beg + lane < si.end) {
+                my_col = g.col[si.beg + lane];
+                my_q = inc_pair[si.beg + lane];
+                my_y = y[my_q];
+                my_w = w[my_q];
+            }
+            ent_y[wave][lane] = my_y;                               // written and read by this wave only: no barrier
+            ent_w[wave][lane] = my_w;
+            ent_q[wave][lane] = my_q;
+        }
+        const int nsteps = (si.end - si.beg + U - 1) / U;           // entries past the end repeat a valid row with w = 0
+        for (int step = 0; step < nsteps; ++step) {
+            u32x4 zv[U][NJ], hv[U][NJ];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // the entry is wave-uniform: its row address is a scalar base, the lane offset a constant
+                const size_t v = (size_t)(unsigned)__builtin_amdgcn_readlane(my_col, (step * U + u) & 63);
+                const T* zs = Z + v * ROW;
+                const T* hs = H + v * ROW;
+                asm volatile("" : "+s"(zs), "+s"(hs));
+                const u32x4* zr = reinterpret_cast<const u32x4*>(zs) + lane;
+                const u32x4* hr = reinterpret_cast<const u32x4*>(hs) + lane;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    zv[u][j] = zr[j * DL_WAVE];
+                    hv[u][j] = hr[j * DL_WAVE];
+                }
+            }
+            // partial dot products: index = table * (U NJ) + j * U + u
+            float val[NVAL];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const u32x4 a16 = mine[j * DL_WAVE + lane], b16 = mine[(NJ + j) * DL_WAVE + lane];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    val[j * U + u] = WC::dot(a16, zv[u][j]);
+                    val[U * NJ + j * U + u] = WC::dot(b16, hv[u][j]);
+                }
+            }
+            // NVAL values over the G lanes of the group, halving the value count at every exchange: the lane at position c
+            // ends with complete sum number c / DUPL — below G/2: z_u . z_v of (chunk, entry), above: h_u . h_v of the same
+            TransposedReduce<NVAL, G / 2>::run(val, c);
+            const float mine_v = val[0];
+            const float ex = expf(T1 ? mine_v : mine_v / t);        // (the upper half exponentiates a value nobody reads)
+            const float ttv = mine_v * xor_lane<G / 2>(ex);          // valid above G/2: (h.h) e^(z.z/t) of (chunk, entry)
+            // sum over the chunks of this lane group (the chunk index sits in the bits above the entry and the duplicates),
+            // then over the lane groups: all factors
+            float logit = sum_over_chunks<G / 4, G / (2 * NJ)>(ttv);
+            if constexpr (G == 16) logit = add_xor<16>(logit);
+            logit = add_xor<32>(logit);
+            const float p = sigmoid_ref(logit);
+            const int idx = step * U + (((c & (G / 2 - 1)) / DUPL) & (U - 1));
+            const float yy = ent_y[wave][idx & 63], ww = ent_w[wave][idx & 63];
+            const int qq = ent_q[wave][idx & 63];
+            const float pr = p * (1.0f - p);
+            const float gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (pr >= 1e-12f ? 1.0f : pr * 1e12f);     // valid above G/2
+            if (lane >= G / 2 && lane < G / 2 + U * DUPL && (lane & (DUPL - 1)) == 0 && si.beg + idx < si.end) prob_out[qq] = p;
+            const float exc = fminf(ex, 3.402823466e38f);          // 0 * inf must stay 0 (see the D = 64 kernel)
+            const float ttc = __builtin_amdgcn_fmed3f(T1 ? ttv : ttv / t, -3.402823466e38f, 3.402823466e38f);
+            const float gl_partner = xor_lane<G / 2>(gl);           // OUTSIDE the select (a DPP move under a divergent branch reads 0)
+            const float coef = (c & (G / 2)) ? gl * ttc : gl_partner * exc;
+            // the DPP row that holds the coefficient of (side, chunk, entry): G = 16: this row, the h.h side 8 lanes up;
+            // G = 32: the lower row of the group holds the z.z side (-> dH), the upper row the h.h side (-> dZ)
+            float ce = coef, ct = coef;
+            if constexpr (G == 32) {
+                const float other = xor_lane<16>(coef);
+                ce = (c & 16) ? other : coef;
+                ct = (c & 16) ? coef : other;
+            }
+            constexpr int TB = G == 16 ? 8 : 0;                     // position of the h.h side inside its DPP row
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float ch = row_bcast_idx(ce, (j * U + u) * DUPL);
+                    const float cz = row_bcast_idx(ct, TB + (j * U + u) * DUPL);
+                    WC::fma(ah[j], ch, hv[u][j]);
+                    WC::fma(az[j], cz, zv[u][j]);
+                }
+            }
+        }
+    }
+    // ---- unit sum, as a tree in two rounds through two [dZ row | dH row] slots (the own rows are dead behind the barrier)
+    float4* const slot4 = reinterpret_cast<float4*>(lds);
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                slot4[slot * SLOT16 + (j * F4 + f) * DL_WAVE + lane] = make_float4(az[j][4 * f], az[j][4 * f + 1], az[j][4 * f + 2], az[j][4 * f + 3]);
+                slot4[slot * SLOT16 + ((NJ + j) * F4 + f) * DL_WAVE + lane] = make_float4(ah[j][4 * f], ah[j][4 * f + 1], ah[j][4 * f + 2], ah[j][4 * f + 3]);
+            }
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int f = 0; f < F4; ++f) {
+                const float4 a4 = slot4[slot * SLOT16 + (j * F4 + f) * DL_WAVE + lane];
+                const float4 b4 = slot4[slot * SLOT16 + ((NJ + j) * F4 + f) * DL_WAVE + lane];
+                az[j][4 * f] += a4.x; az[j][4 * f + 1] += a4.y; az[j][4 * f + 2] += a4.z; az[j][4 * f + 3] += a4.w;
+                ah[j][4 * f] += b4.x; ah[j][4 * f + 1] += b4.y; ah[j][4 * f + 2] += b4.z; ah[j][4 * f + 3] += b4.w;
+            }
+    };
+    const int upos = ws.upos, nfwd = ws.active ? ws.n_unit : 0;
+    __syncthreads();
+    if (ws.active && (upos & 1)) put(wave >> 1);                                      // round A: odd positions hand over ...
+    __syncthreads();
+    if (ws.active && !(upos & 1) && nfwd >= 2) add((wave + 1) >> 1);                  // ... to the even position below them
+    __syncthreads();
+    if (ws.active && upos == 2) put(0);                                               // round B: (s2 + s3) ...
+    __syncthreads();
+    if (!ws.head) return;
+    if (nfwd >= 3) add(0);                                                            // ... joins (s0 + s1)
+    float* oz = si.slot < 0 ? dZ + (size_t)si.grow * ROW : part + (size_t)si.slot * 2 * ROW;        // [dZ row | dH row]
+    float* oh = si.slot < 0 ? dH + (size_t)si.grow * ROW : part + (size_t)si.slot * 2 * ROW + ROW;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int f = 0; f < F4; ++f) {
+            store4(oz + (size_t)(j * DL_WAVE + lane) * CH + 4 * f, make_float4(az[j][4 * f], az[j][4 * f + 1], az[j][4 * f + 2], az[j][4 * f + 3]));
+            store4(oh + (size_t)(j * DL_WAVE + lane) * CH + 4 * f, make_float4(ah[j][4 * f], ah[j][4 * f + 1], ah[j][4 * f + 2], ah[j][4 * f + 3]));
+        }
+}
+
 // Scorer backward from stored per-factor terms: a weighted row gather, one launch per output.
 //   PASS 0: dZ[u] = sum_inc (gl/t) * (q_k e_k) * Z[v][k]      PASS 1: dH[u] = sum_inc gl * e_k * H[v][k]
 template <int K, int D, typename T, int PASS>
@@ -1592,6 +1857,21 @@ struct Ops {
                     hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g,
                                        part, 2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
                 return check_launch("score_pairs_train(fast, wave per entry)");
+            }
+        }
+        if constexpr (TrainWide<K, D, T>::ok) {
+            constexpr int U = TrainWide<K, D, T>::U, WV = TrainWide<K, D, T>::WAVES;
+            if (g->seg_len <= 64 && g->seg_len % U == 0 && !getenv("DL_TRAIN_GROUP_KERNEL")) {
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair, (const T*)Z, (const T*)H,
+                                       t, dZ, dH, part, y, w, prob);
+                };
+                if (t == 1.0f) launch(score_train_wide_kernel<K, D, T, U, WV, true>);
+                else launch(score_train_wide_kernel<K, D, T, U, WV, false>);
+                if (g->n_multi > 0)
+                    hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi, 2), dim3(BLOCK), 0, st, *g,
+                                       part, 2 * ROW, no_x, 0.0f, 1.0f, dZ, 0, part + ROW, dH);
+                return check_launch("score_pairs_train(fast, wave per entry, wide rows)");
             }
         }
         hipLaunchKernelGGL((score_bwd_seg_kernel<K, D, T, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, inc->inc_pair,

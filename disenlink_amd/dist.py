@@ -741,13 +741,11 @@ def sharded_forward_loss(model, x_local: torch.Tensor, shard: Shard, label: torc
     tab = getattr(model, "table_dtype", torch.float32)
     Z_loc = model.project(shard.pad_rows(x_local))
     K, d = Z_loc.shape[1], Z_loc.shape[2]
-    # Which scorer (the module's own rule, model.forward_pairs_loss): one pass for fp32 tables, for bf16 tables beyond
-    # 512 MiB and for narrow rows (K d < 2048); wide bf16 tables that sit in the caches — and shapes without a one-pass kernel — take the forward scorer with
-    # stored terms + the coefficient-gather backward over the pairs that touch the rank's nodes (at K = 16, d = 128 the
-    # one-pass kernel runs one wave per SIMD: 104 ms against 23 on Penn94).  DL_ONE_PASS_SCORER=0/1 forces.
-    mode = os.environ.get("DL_ONE_PASS_SCORER", "auto")
-    table_bytes = 2 * shard.n_pad * K * d * (4 if tab == torch.float32 else 2)
-    want_one = mode == "1" or (mode != "0" and (tab == torch.float32 or table_bytes > (512 << 20) or K * d < 2048))
+    # Which scorer: the module's own rule (ops.one_pass_scorer_wanted); shapes without a one-pass kernel — and wide bf16 rows
+    # that have only the group-per-entry one — take the forward scorer with stored terms + the coefficient-gather backward
+    # over the pairs that touch the rank's nodes.  DL_ONE_PASS_SCORER=0/1 forces.
+    from .ops import one_pass_scorer_wanted
+    want_one = one_pass_scorer_wanted(tab, shard.n_pad, K, d)
     has_one = shard.inc is not None and hasattr(backend, "score_pairs_train") and \
         backend.score_pairs_train_supported(shard.inc, K, d, tab)
     has_terms = shard._global_pairs is not None and hasattr(backend, "score_pairs_fwd_terms")

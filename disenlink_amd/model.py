@@ -283,18 +283,7 @@ class Disentangle(nn.Module):
         (ops.HotPathPairsLoss).  Falls back to forward_pairs + the fused loss where no tuned kernel exists."""
         Z = self.project(x)
         dt = ops._lib.DL_F32 if self.table_dtype == torch.float32 else ops._lib.DL_BF16
-        # One pass gathers 8 KB per pair instead of 12.  Measured (tools/score_train_time.py, round 2, after the per-group
-        # partials moved to LDS): fp32 tables — one pass wins or ties at every size (squirrel 536 vs 587 us, chameleon 150
-        # vs 158, Penn94-sized K=8 8.5 vs 8.7 ms, K=16 d=128 33 vs 46 ms); bf16 tables that sit in the caches — the separate
-        # kernels win (Penn94-sized K=16 d=128: 22.3 vs 26.3 ms, K=8: 5.5 vs 5.9: the gathers are half as heavy, the
-        # one-pass kernel's registers are not); bf16 tables in HBM — one pass again.  DL_ONE_PASS_SCORER=0/1 forces.
-        mode = os.environ.get("DL_ONE_PASS_SCORER", "auto")
-        table_bytes = 2 * Z.shape[0] * Z.shape[1] * Z.shape[2] * (4 if self.table_dtype == torch.float32 else 2)
-        # (round 4 re-measurement, tools/score_train_time.py: bf16 tables at K = 8, d = 64 now favour one pass too — Penn94-sized
-        # 3.49 vs 4.37 ms, squirrel 395 vs 458 us; the exception that remains is the WIDE shape, K d >= 2048, whose one-pass
-        # kernel sits at one wave per SIMD: K = 16, d = 128 bf16 104 vs 22.6 ms — while fp32 there is 29.8 vs 48.1)
-        one_pass = mode == "1" or (mode != "0" and (self.table_dtype == torch.float32 or table_bytes > (512 << 20)
-                                                    or Z.shape[1] * Z.shape[2] < 2048))
+        one_pass = ops.one_pass_scorer_wanted(self.table_dtype, Z.shape[0], Z.shape[1], Z.shape[2])     # the rule and its numbers: there
         if one_pass and ops.score_pairs_train_supported(pairs, Z.shape[1], Z.shape[2], dt):
             if self.table_dtype == torch.float32 and Z.dtype == torch.float32 and graph.n_rows == graph.n_nodes:
                 from . import native                            # the compiled binding: the same step as ONE C++ autograd node

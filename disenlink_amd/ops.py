@@ -234,6 +234,22 @@ def score_pairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob, dZ_out=None, 
     return dZ, dH
 
 
+def one_pass_scorer_wanted(table_dtype, n_nodes: int, K: int, d: int) -> bool:
+    """The training step's choice between the one-pass scorer (dl_score_pairs_train: 8 KB of partner rows per pair at K = 8,
+    d = 64) and forward-with-stored-terms + two coefficient gathers (12 KB per pair) — ONE rule for model.forward_pairs_loss,
+    dist.sharded_forward_loss and bench.py (DL_ONE_PASS_SCORER=0/1 forces either).  Measured (tools/score_train_time.py):
+    one pass wins or ties wherever a wave-per-entry kernel exists (K in {4, 8} at d = 64; K = 16, d = 128 in both table types
+    since round 5: Penn94-shaped bf16 15.9 vs 22.3 ms, fp32 29.9 vs 45.1) and for every fp32 shape (squirrel 387 vs 553 us);
+    what remains for the separate kernels is a WIDE row (K d >= 2048) of bf16 tables that sit in the caches and has only
+    the group-per-entry kernel (one wave per SIMD there)."""
+    mode = os.environ.get("DL_ONE_PASS_SCORER", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    if table_dtype == torch.float32 or K * d < 2048 or (K, d) == (16, 128):
+        return True
+    return 2 * n_nodes * K * d * 2 > (512 << 20)
+
+
 def score_pairs_train_supported(pairs: PairList, K: int, d: int, dt: int) -> bool:
     return bool(_lib.load().dl_score_pairs_train_supported(pairs.c_struct(pairs.n_pairs), K, d, dt))
 
