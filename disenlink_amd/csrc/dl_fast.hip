@@ -355,7 +355,8 @@ __device__ __forceinline__ int dpp_move_i(int v) {
 template <int KP>
 __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, int K, const uint8_t* __restrict__ p,
                                                                 const float* __restrict__ a, float* __restrict__ s,
-                                                                int n_reg_blocks) {
+                                                                int n_reg_blocks, const int32_t* __restrict__ exp_rev = nullptr,
+                                                                float* __restrict__ exp_wn = nullptr) {
     if ((int)blockIdx.x >= n_reg_blocks) {
         const int m = ((int)blockIdx.x - n_reg_blocks) * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
         if (m >= g.n_multi) return;
@@ -433,6 +434,19 @@ __global__ __launch_bounds__(BLOCK) void s_rowsum_thread_kernel(dl_csr_plan g, i
         tot[kk] += ok2 ? v2 : 0.0f;
         tot[kk] += ok3 ? v3 : 0.0f;
     }
+#ifdef DL_EXP_ROWSUM_SCATTER      // TIMING EXPERIMENT ONLY: what it would cost the row-sum pass to write the normalised weight of every
+    // entry through the reverse-edge map (one more coalesced read + one scattered 4-byte store per entry; the totals used here
+    // are the head position's only, so the values are not the real ones)
+    if (exp_rev != nullptr) {
+        for (int e = beg + sub; e < end; e += ROWSUM_SUB) {
+            float tt = 1.0f;
+            const int kq = (int)p[e];
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) tt = kq == kk ? tot[kk] : tt;
+            exp_wn[exp_rev[e]] = a[e] / one_if_zero(tt);
+        }
+    }
+#endif
     if (!head || sub != 0 || slot >= 0) return;
     float* dst = s + ((size_t)row + g.row_offset) * K;
 #pragma unroll
@@ -521,7 +535,9 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
             my_a = a[si.beg + lane];
         }
         // the neighbour's normaliser stays in flight while the entries are sorted and the first row gathers go out
-        if (mine) my_s = s[(size_t)my_col * K + my_k];
+#ifndef DL_EXP_NO_SGATHER         // -DDL_EXP_NO_SGATHER: TIMING EXPERIMENT ONLY (wrong results): what the aggregation would gain
+        if (mine) my_s = s[(size_t)my_col * K + my_k];      // if the normalised weight a / s~ arrived with p / a in the per-entry stream
+#endif
         const int cls = my_k % NC;
         int pos = 0, my_off = 0, my_cnt = 0, run = 0, trip = 0;
 #pragma unroll
@@ -1165,7 +1181,7 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
     const WaveSeg ws = load_wave_seg(g);
     const SegInfo si = ws.si;
     const int wave = ws.wave, lane = lane_id();
-    const int r = lane >> 4, i = lane & 15;                         // DPP row (its factors: r, r + 4, ...) and position in it
+    const int i = lane & 15;                                       // position in the DPP row (the row holds the factors r, r + 4, ... of row r)
     float4 az[NJ], ah[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) az[j] = ah[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1703,8 +1719,22 @@ static inline int pow2_at_least(int k) {
     return p;
 }
 
+#ifdef DL_EXP_ROWSUM_SCATTER
+static const int32_t* exp_rev_ptr = nullptr;      // set by route_fwd below (experiment builds only)
+static float* exp_wn_ptr = nullptr;
+#endif
 static void launch_s_rowsum(const dl_csr_plan* g, int K, const uint8_t* p, const float* a, float* s, hipStream_t st) {
     if (g->n_seg <= 0) return;
+#ifdef DL_EXP_ROWSUM_SCATTER
+    {
+        const int reg = (g->n_seg + ROWSUM_POS_PER_BLOCK - 1) / ROWSUM_POS_PER_BLOCK;
+        const dim3 grid((unsigned)reg + wave_blocks(g->n_multi)), block(BLOCK);
+        if (K <= 8 && K > 4) {
+            hipLaunchKernelGGL(s_rowsum_thread_kernel<8>, grid, block, 0, st, *g, K, p, a, s, reg, exp_rev_ptr, exp_wn_ptr);
+            return;
+        }
+    }
+#endif
     const int reg = (g->n_seg + ROWSUM_POS_PER_BLOCK - 1) / ROWSUM_POS_PER_BLOCK;
     const dim3 grid((unsigned)reg + wave_blocks(g->n_multi)), block(BLOCK);
     if (K <= 4) hipLaunchKernelGGL(s_rowsum_thread_kernel<4>, grid, block, 0, st, *g, K, p, a, s, reg);
@@ -1755,7 +1785,14 @@ struct Ops {
                 hipLaunchKernelGGL((route_seg_kernel<K, D, T, false>), dim3(seg_blocks(rp)), dim3(BLOCK), 0, st, *rp, rev,
                                    (const T*)Z, t, p, a);
         }
+#ifdef DL_EXP_ROWSUM_SCATTER
+        exp_rev_ptr = mirror ? rev : nullptr;          // unsharded graphs only (they have the reverse-edge map)
+        if (exp_wn_ptr == nullptr && hipMalloc(&exp_wn_ptr, (size_t)64 << 20) != hipSuccess) exp_rev_ptr = nullptr;   // experiment scratch
+        if ((size_t)g->n_entries * sizeof(float) > ((size_t)64 << 20)) exp_rev_ptr = nullptr;
         (void)s_part;
+#else
+        (void)s_part;
+#endif
         launch_s_rowsum(g, K, p, a, s, st);
         return check_launch("route_fwd(fast)");
     }
