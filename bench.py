@@ -201,7 +201,7 @@ def build_workload(name, device, K, d, nhid, seed=0, m=5, scale=1.0, elem_bytes=
     return sg, split, graph, pairs, model, x, Z
 
 
-def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=30.0, parity=None):
+def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=20.0, parity=None, fwd_bwd_budget_s=30.0):
     """The oracle's dense restatement (same op sequence as model.py:56-76,109-113) timed on the host
     cores: one warm-up, then the median of up to 3 passes within the budget.  `parity` = (pu, pv, label, prob_gpu) of
     the timed GPU step: the warm-up pass's probabilities at those pairs become the line's parity block."""
@@ -231,6 +231,29 @@ def cpu_baseline(Z_cpu, graph_cpu, n_units, beta, t, budget_s=30.0, parity=None)
                sample=f"whole workload, dense [K,N,N] forward (route+aggregate+all-pairs score) of oracle/dense_ref.py, "
                       f"median of {len(times)} after 1 warm-up, {med:.2f} s per pass",
                seconds_per_pass=med)
+    # forward + backward ("forward and forward+backward reported separately"): one pass of the same
+    # dense op sequence under autograd with the weighted BCE of main_disentangled.py:195 on the scored pairs — what the
+    # reference's loss.backward() does to the path (the projection excluded on both sides), timed once (it holds ~10
+    # [K,N,N] tensors; a second pass would double the bench's CPU time)
+    if parity is not None and fwd_bwd_budget_s > 0:
+        try:
+            from disenlink_amd.metrics import pair_bce_weights
+            pu, pv, label = parity[0].long(), parity[1].long(), torch.from_numpy(parity[2])
+            n_pos = int(label.sum())
+            w = torch.where(label > 0, torch.tensor(1.0 / max(n_pos, 1)), torch.tensor(1.0 / (5 * max(label.numel() - n_pos, 1))))
+            Zg = Zk.clone().requires_grad_(True)
+            t0 = time.perf_counter()
+            H, e, _att, _p, _s = dense_ref.route_aggregate(Zg, adj, beta, t)
+            P = dense_ref.score_allpairs(H, e)
+            loss = torch.nn.functional.binary_cross_entropy(P[pu, pv], label, weight=w, reduction="sum")
+            loss.backward()
+            dt = time.perf_counter() - t0
+            del H, e, _att, P, loss
+            out["fwd_bwd"] = dict(value=n_units / dt, unit="edges/s", seconds_per_pass=dt,
+                                  sample="one pass of the same dense forward under autograd + weighted BCE on the scored pairs + "
+                                         "backward to Z (no warm-up of its own)")
+        except MemoryError as ex:                                   # the host cannot hold the autograd tape
+            out["fwd_bwd"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
     return (out, par) if parity is not None else out
 
 
@@ -251,7 +274,7 @@ def parity_block(prob_cpu, label, prob_gpu):
             "what": "timed GPU step (route+aggregate+score on the scored train pairs) vs oracle/dense_ref.py on the same Z"}
 
 
-def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=30.0):
+def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=30.0, label=None):
     """Baseline B: the multi-threaded C restatement of the edge-list form, for graphs whose
     dense [K,N,N] form cannot exist.  Whole workload, median of up to 3 passes after one warm-up."""
     from oracle import c_ref
@@ -271,11 +294,30 @@ def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=
         if time.perf_counter() - t_all > budget_s and times:
             break
     med = float(np.median(times))
-    return dict(value=n_units / med, unit="edges/s", cores=os.cpu_count(), kind="port",
-                sample=f"whole workload, edge-list forward (route+aggregate+score_pairs) of oracle/c/sparse_ref.c with "
-                       f"OpenMP on all host cores (the reference's dense form cannot hold this graph), "
-                       f"median of {len(times)} after 1 warm-up, {med:.2f} s per pass",
-                seconds_per_pass=med)
+    out = dict(value=n_units / med, unit="edges/s", cores=os.cpu_count(), kind="port",
+               sample=f"whole workload, edge-list forward (route+aggregate+score_pairs) of oracle/c/sparse_ref.c with "
+                      f"OpenMP on all host cores (Baseline B of BASELINE.md: the form that also runs where the reference's "
+                      f"dense [K,N,N] cannot exist), median of {len(times)} after 1 warm-up, {med:.2f} s per pass",
+               seconds_per_pass=med)
+    if label is not None:                                           # forward + backward of the same path, edge-list form
+        n_pos = int(label.sum())
+        w = np.where(label > 0, 1.0 / max(n_pos, 1), 1.0 / (5 * max(label.size - n_pos, 1))).astype(np.float32)
+        tb = []
+        for it in range(2):
+            t0 = time.perf_counter()
+            p, a, s = c_ref.route(Zh, rowptr, col, t)
+            H = c_ref.aggregate(Zh, rowptr, col, p, a, s, beta)
+            prob = c_ref.score_pairs(Zh, H, pu, pv, t)
+            g = (w * (prob - label) / np.maximum(prob * (1 - prob), np.float32(1e-12))).astype(np.float32)
+            _dZs, dH = c_ref.score_pairs_bwd(Zh, H, pu, pv, t, prob, g)
+            c_ref.route_aggregate_bwd(Zh, rowptr, col, p, a, s, beta, t, dH)
+            tb.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > 2 * budget_s:
+                break
+        out["fwd_bwd"] = dict(value=n_units / tb[-1], unit="edges/s", seconds_per_pass=tb[-1],
+                              sample="edge-list forward + weighted BCE gradient + scorer / routing / aggregation backward of "
+                                     f"oracle/c/sparse_ref.c, pass {len(tb)} of {len(tb)}")
+    return out
 
 
 WARM_S = [0.3]          # --warm-s / --min-region-s (profiler passes set both to 0: a PMC pass serialises every launch)
@@ -785,6 +827,10 @@ def main():
                      "note": bound_note},
         "edge_scatter": scatter_entry(kernels, E, peak),
         "kernels": kernels,
+        "kernels_note": "avg_us of a phase = HIP events around its launches on the launch stream, in a loop of its own; the "
+                        "event brackets add ~1 us per phase, so the phases sum to phase_sum_over_step x ms_per_step (the "
+                        "timed blocks carry no events)",
+        "phase_sum_over_step": sum(kernels[n]["avg_us"] for n in NAMES) * 1e-6 / step_s,
         "step_bytes_over_time_GBs": sum(mbytes.values()) / step_s / 1e9,
         "kernel_source_hash": kernel_source_hash(),
     }
@@ -816,9 +862,14 @@ def main():
             par_in = (pcpu[0], pcpu[1], label_cpu, prob_timed) if prob_timed is not None else None
             got = cpu_baseline(Zc, gcpu, units, beta, t, parity=par_in)
             result["cpu_baseline"], result["parity"] = got if par_in is not None else (got, None)
+            # Baseline B beside it ("also reported for 1-3"): seconds, not tens of seconds
+            result["cpu_baseline_sparse"] = cpu_baseline_sparse(Zc, gcpu, pcpu, units, beta, t, budget_s=8.0, label=label_cpu)
         else:
-            result["cpu_baseline"] = cpu_baseline_sparse(Zc, gcpu, pcpu, units, beta, t)
+            result["cpu_baseline"] = cpu_baseline_sparse(Zc, gcpu, pcpu, units, beta, t, label=label_cpu)
     print(json.dumps(result), flush=True)
+    if result.get("parity") is not None and not result["parity"]["ok"]:
+        print("bench.py: the timed step's outputs do NOT match the CPU oracle (parity.ok = false)", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -162,6 +162,12 @@ def all_gather_rows(full: torch.Tensor, lo: int, hi: int, group=None, src: torch
     all_gather_into_tensor whose output is `full` itself.  `src`: the local rows, if the caller holds them elsewhere
     (then `full[lo:hi]` need not be filled); otherwise they are taken where they lie — in place over RCCL, through one
     clone where the backend (gloo) does not promise the in-place form."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        # one rank: nothing to exchange — the launch sequence of the sharded step is then the unsharded one (a one-rank
+        # RCCL all-gather still costs ~15 us of launch: 3 of them were 18 % of the squirrel step, profiles/r4w)
+        if src is not None and (src.data_ptr() != full[lo:hi].data_ptr() or src.dtype != full.dtype):
+            full[lo:hi].copy_(src)
+        return
     _count("collectives")
     if _gloo_on_device(full, group):
         local = src if src is not None else full[lo:hi]
@@ -441,8 +447,10 @@ class Shard:
         lo, hi = rank * B, (rank + 1) * B
         ts = torch.as_tensor(part.to_padded(edge_src), device=device)
         td = torch.as_tensor(part.to_padded(edge_dst), device=device)
-        graph = Graph.from_edge_rows(ts, td, n_pad, symmetrise=True, seg_len=seg_len, row_range=(lo, hi),
-                                     row_bytes=row_bytes)
+        # one rank owns every row: the unsharded graph (its routing plan walks each undirected edge once and mirrors the
+        # result through the reverse-edge map — a shard has no reverse entries and routes every directed entry)
+        graph = Graph.from_edge_rows(ts, td, n_pad, symmetrise=True, seg_len=seg_len,
+                                     row_range=None if world == 1 else (lo, hi), row_bytes=row_bytes)
         ppu, ppv = part.to_padded(pu), part.to_padded(pv)             # order-preserving: still sorted by u
         cuts = np.searchsorted(ppu, np.arange(world + 1) * B, side="left")
         cuts[-1] = ppu.size
@@ -451,7 +459,7 @@ class Shard:
         pairs = PairList.build(tpu[q0:q1], tpv[q0:q1], n_pad, row_range=(lo, lo), by_u_range=(lo, hi),
                                row_bytes=row_bytes)
         groups = []
-        if part.n_chunks > 1:
+        if part.n_chunks > 1 and world > 1:                        # (one rank: one scoring launch, nothing arrives in chunks)
             lv = ppv[q0:q1]
             owner = lv // B
             chunk = (lv % B) // part.chunk_rows
@@ -569,8 +577,12 @@ def _gather_and_route(sh: "Shard", backend, Z_loc, t, group, table_dtype):
     routing pass, or — Shard.route_by_peer — the per-peer gather with the routing in arrival order."""
     K, d = Z_loc.shape[1], Z_loc.shape[2]
     dev = Z_loc.device
-    Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
     s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
+    if sh.world == 1 and Z_loc.shape[0] == sh.n_pad:           # one rank: its rows ARE the table (no copy, no collective)
+        Z = Z_loc.detach().to(table_dtype).contiguous()
+        p, a = backend.route_fwd(sh.graph, Z, t, s)
+        return Z, s, p, a
+    Z = torch.empty((sh.n_pad, K, d), dtype=table_dtype, device=dev)
     by_peer = bool(sh.route_by_peer) and backend.honours_partial_route_plans(K, d, table_dtype)
     if by_peer:
         Z[sh.lo:sh.hi] = Z_loc.detach().to(table_dtype)

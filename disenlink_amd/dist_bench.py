@@ -147,6 +147,23 @@ def _timed(fn, reps, red_dev):
     return _median_max_over_ranks(ts, red_dev)
 
 
+def _all_ok(ok: bool, ctrl) -> bool:
+    """Did EVERY rank get through?  (MIN over the control group — gloo, host side.)  A transport that raises on some ranks
+    only would otherwise leave the ranks with different sets of measured modes: they would pick different forms and
+    enter mismatched collectives — a hang instead of an error (advisor, round 4)."""
+    v = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=ctrl)
+    return bool(int(v) == 1)
+
+
+AB_MARGIN = 0.95      # a non-default transport must be >= 5 % faster than the default to be used (2.556 vs 2.606 ms is noise)
+
+
+def _pick(times: dict, default: str) -> str:
+    best = min(times, key=times.get)
+    return best if (best == default or default not in times or times[best] < AB_MARGIN * times[default]) else default
+
+
 def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     """One (workload, scaling, K, d, dtype) block.  One step = all-gather Z, route, all-gather s, aggregate, all-gather H,
     score the local pairs; value = (E_sym + P over all ranks) / max-over-ranks time."""
@@ -178,7 +195,8 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
         Z_loc = model.project(shard.pad_rows(x_loc)).contiguous().to(tab)
     model.table_dtype = tab
 
-    Z = torch.empty((shard.n_pad, K, d), dtype=tab, device=device)
+    # (one rank: its rows are the whole table — the gather below finds them in place and copies nothing)
+    Z = Z_loc if (world == 1 and Z_loc.shape[0] == shard.n_pad) else torch.empty((shard.n_pad, K, d), dtype=tab, device=device)
     s = torch.empty((shard.n_pad, K), dtype=torch.float32, device=device)
     H = torch.empty_like(Z)
     part, B = shard.part, shard.part.block
@@ -223,13 +241,18 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
             continue
         def z_gather(mode=mode):
             dd.gather_table(Z, part, rank, mode, src=Z_loc)
+        err = None
         try:                                        # a transport the backend refuses is left out, not fatal (the plain
-            z_ab[mode] = _timed(z_gather, reps, red_dev) * 1e3      # all-gather is the form every backend has)
+            tm = _timed(z_gather, reps, red_dev) * 1e3              # all-gather is the form every backend has)
         except Exception as e:                      # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        if _all_ok(err is None, ctrl):              # ... on EVERY rank, or on none
+            z_ab[mode] = tm
+        else:
             if mode == "allgather":
-                raise
-            ab_errors[mode] = f"{type(e).__name__}: {e}"[:300]
-    z_mode = min(z_ab, key=z_ab.get)
+                raise RuntimeError(f"the plain all-gather failed on a rank ({err or 'another rank'})")
+            ab_errors[mode] = err or "failed on another rank"
+    z_mode = _pick(z_ab, "allgather") if world > 1 else "allgather"         # (one rank: every form is a no-op)
     p, a = backend.route_fwd(shard.graph, Z, t, s)
     dd.all_gather_rows(s, shard.lo, shard.hi)
     backend.aggregate_fwd(shard.graph, Z, beta, p, a, s, H)
@@ -249,13 +272,18 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     for name, fn in h_forms.items():
         if want_form and name != want_form:
             continue
+        err = None
         try:
-            h_ab[name] = _timed(fn, reps, red_dev) * 1e3
+            tm = _timed(fn, reps, red_dev) * 1e3
         except Exception as e:                      # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        if _all_ok(err is None, ctrl):
+            h_ab[name] = tm
+        else:
             if name == "blocking":
-                raise
-            ab_errors["h_" + name] = f"{type(e).__name__}: {e}"[:300]
-    h_form = min(h_ab, key=h_ab.get)
+                raise RuntimeError(f"the blocking H gather failed on a rank ({err or 'another rank'})")
+            ab_errors["h_" + name] = err or "failed on another rank"
+    h_form = _pick(h_ab, "blocking") if world > 1 else "blocking"
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -392,7 +420,8 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
                       "note": "allgather = one all_gather_into_tensor into the table itself (in place); p2p = one grouped "
                               "batch of W-1 direct sends + W-1 receives landing in place; broadcast = W broadcasts; "
                               "H phase: blocking gather + one scoring launch vs row chunks pushed directly with the "
-                              "scorer under them; max over ranks of the median of %d" % reps},
+                              "scorer under them; max over ranks of the median of %d; a non-default form is used only "
+                              "when it is >= 5 %% faster than the default (allgather / blocking)" % reps},
         "messages_per_step": {**messages, "note": "this rank: collectives (Z, s[, H]) + point-to-point operations of the "
                                                   "chunked H exchange; staging_copies = device copies made only to feed or "
                                                   "unpack a collective (0: every received row lands in its final place)"},
@@ -423,8 +452,13 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     if os.environ.get("DL_BENCH_TRAIN", "1") != "0":
         try:
             out["training_step"] = _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_loc, red_dev)
-        except Exception as e:                      # noqa: BLE001
+        except Exception as e:                      # noqa: BLE001 — a rank that fails INSIDE a collective cannot be rescued
+            # (its peers block there); what this catches is a failure before the first collective of the step or after
+            # the last: recorded, and the run ends here on every rank rather than entering the next block out of step
             out["training_step"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if not _all_ok("error" not in out["training_step"], ctrl):
+            out["training_step"].setdefault("error", "failed on another rank")
+            out["abort_after_this_block"] = True
     del shard, Z_loc, model, x_loc
     torch.cuda.empty_cache()
     return out
@@ -526,12 +560,22 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
     else:
         specs = [dict(name=f"{args.workload}_{args.scaling}", workload=args.workload, scaling=args.scaling, K=args.K,
                       d=args.d, dtype=args.dtype, config="as given on the command line")]
-    results = [run_block(sp, args, rank, world, device, ctrl) for sp in specs]
+    results = []
+    for sp in specs:
+        results.append(run_block(sp, args, rank, world, device, ctrl))
+        if results[-1].get("abort_after_this_block"):
+            break
     head = results[0]
+    head_cfg = dict(head["config"])
+    head_cfg["workload"] = (f"[N={world} record: {head['name']} — {head['scaling']} scaling of ONE fixed problem; its N=1 reference is "
+                            f"n1_same_problem_ms of THIS line (speedup_vs_n1), NOT the `bench.py --gpus 1` record, which is "
+                            f"BASELINE's squirrel headline] ") + head_cfg["workload"]
     line = {"metric": "edges/sec (aggregate+score) at K=8 d=64",
+            "metric_note": f"top-level value = block '{head['name']}' ({head['baseline_config']}); do not ratio it against the "
+                           "N=1 squirrel record — every block carries its own same-problem N=1 time and speedup_vs_n1",
             "value": head["value"], "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
-            "dtype": head["dtype"], "data": "synthetic", "config": head["config"],
+            "dtype": head["dtype"], "data": "synthetic", "config": head_cfg,
             "n1_same_problem_ms": head["n1_same_problem_ms"], "speedup_vs_n1": head["speedup_vs_n1"],
             "parity": head["parity"], "roofline": head["roofline"],
             "cpu_baseline": None,

@@ -84,6 +84,16 @@ def load_dataset(args):
     return datasets.LinkDataset(f"{key}-synthetic", sg.features(), sg.src, sg.dst)
 
 
+def save_results(args, result) -> None:
+    """--save 1: append the runs' summary line to performance/<dataset>_..._nfactor.csv (main_disentangled.py:225-246)."""
+    os.makedirs("performance", exist_ok=True)
+    sub = f"{args.sub_dataset}" if args.dataset in ("twitch-e", "fb100") else ""
+    with open(f"performance/{args.dataset}_{sub}disentangle_nfactor.csv", "a+") as f:
+        f.write(f"{result.mean():.3f} ± {result.std():.3f},{result},beta {args.beta},temperature {args.temperature},"
+                f"nfactor {args.nfactor},nhidden {args.nhidden},nembed {args.nembed},dataset {args.dataset},"
+                f"run {args.run},epochs {args.epochs},lr {args.lr},m {args.m}\n")
+
+
 def main_sharded(args):
     """--gpus N: the same runs with the graph's rows, the feature rows and the pair lists sharded over N ranks
     (train.run_link_prediction_sharded).  Every rank loads the dataset and draws the SAME seeded split (host arrays);
@@ -126,6 +136,8 @@ def main_sharded(args):
         result = np.array(result)
         if rank == 0:
             print("final", result.mean(), result.std(), flush=True)
+            if args.save == 1:
+                save_results(args, result)
         return result
     finally:
         dist.destroy_process_group()
@@ -175,12 +187,7 @@ def main(argv=None):
     result = np.array(result)
     print("final", result.mean(), result.std())
     if args.save == 1:                                              # :225-246
-        os.makedirs("performance", exist_ok=True)
-        sub = f"{args.sub_dataset}" if args.dataset in ("twitch-e", "fb100") else ""
-        with open(f"performance/{args.dataset}_{sub}disentangle_nfactor.csv", "a+") as f:
-            f.write(f"{result.mean():.3f} ± {result.std():.3f},{result},beta {args.beta},temperature {args.temperature},"
-                    f"nfactor {args.nfactor},nhidden {args.nhidden},nembed {args.nembed},dataset {args.dataset},"
-                    f"run {args.run},epochs {args.epochs},lr {args.lr},m {args.m}\n")
+        save_results(args, result)
     return result
 
 

@@ -516,7 +516,11 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None, one_allocation: b
         raise ValueError("inconsistent projection shapes")
     # the (up to) four gradients are carved out of ONE allocation, back to back: the sharded training step all-reduces
     # them as one flat tensor without packing (dist.allreduce_gradients), every piece 16-byte aligned
-    shapes = [tuple(W1.shape), tuple(b1.shape)] + ([tuple(W2.shape), (K, d)] if two else [])
+    # (with a zero-padded feature axis the kernels write dW1 at the padded width into a buffer of its own and the columns
+    # that exist are copied into the first piece — the one copy the trim costs anyway — so the four gradients stay
+    # adjacent at EVERY feature width: snap-patents' F = 269 gave four collectives in round 4)
+    trimmed = F != F_true
+    shapes = [tuple(W1.shape[:2]) + (F_true,), tuple(b1.shape)] + ([tuple(W2.shape), (K, d)] if two else [])
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     if one_allocation and all(n % 4 == 0 for n in sizes):
         flat = _empty((sum(sizes),), torch.float32, x.device)
@@ -526,7 +530,9 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None, one_allocation: b
             off += n
     else:
         parts = [_empty(sh, torch.float32, x.device) for sh in shapes]
-    dW1, db1 = parts[0], parts[1]
+    dW1_out = parts[0]
+    dW1 = _empty(tuple(W1.shape), torch.float32, x.device) if trimmed else dW1_out
+    db1 = parts[1]
     dW2, db2 = (parts[2], parts[3]) if two else (None, None)
     ws = _ws.get(int(lib.dl_project_bwd_workspace_bytes(N, F, K, nhid, d, int(two))), x.device)
     _lib.check(lib.dl_project_bwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
@@ -534,9 +540,9 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None, one_allocation: b
                                   hid.data_ptr() if (two and hid is not None) else None, dW1.data_ptr(), db1.data_ptr(),
                                   dW2.data_ptr() if two else None, db2.data_ptr() if two else None,
                                   ws.data_ptr(), ws.numel(), _stream()), "dl_project_bwd")
-    if F != F_true:
-        dW1 = dW1[..., :F_true].contiguous()
-    return dW1, db1, dW2, db2
+    if trimmed:
+        dW1_out.copy_(dW1[..., :F_true])
+    return dW1_out, db1, dW2, db2
 
 
 def project_supported(d: int) -> bool:
