@@ -83,9 +83,11 @@ class AucPlan:
             # dl_auc_pair_counts: one launch — slices of the smaller class sorted in LDS, the other class located in
             # them by binary searches; exact integer counts (~10 us at 10^4 x 5*10^4 against ~130 us for the sort
             # path below, which only enormous validation sets take)
-            from . import _lib
-            lib = _lib.load()
+            from . import _lib, native
             score = score.contiguous()
+            if native.available():                                 # the same launch from the compiled binding
+                return native.auc_pair_counts(score, self.pos_idx, self.neg_idx)[0].to(torch.float64) / self._denom2
+            lib = _lib.load()
             u2 = torch.empty(1, dtype=torch.int64, device=score.device)
             _lib.check(lib.dl_auc_pair_counts(score.data_ptr(), self.pos_idx.data_ptr(), self.n_pos, self.neg_idx.data_ptr(),
                                               self.n_neg, u2.data_ptr(), torch.cuda.current_stream().cuda_stream),

@@ -196,6 +196,9 @@ class Disentangle(nn.Module):
                 st = self._stacked
                 bufs = ((st[("mlp", "weight")], st[("mlp", "bias")], None, None) if self.single_layer else
                         (st[("mlp1", "weight")], st[("mlp1", "bias")], st[("mlp2", "weight")], st[("mlp2", "bias")]))
+                from . import native
+                if native.project_ok(x, d, self.single_layer):   # the same kernels from a C++ autograd node (no Python in the backward)
+                    return native.project_stacked(x, bufs, flat)
                 return ops.ProjectStacked.apply(x, bufs, K, *flat)
             # parameters were re-pointed by the caller: stack them (one copy per call)
             if self.single_layer:
@@ -285,11 +288,11 @@ class Disentangle(nn.Module):
         dt = ops._lib.DL_F32 if self.table_dtype == torch.float32 else ops._lib.DL_BF16
         one_pass = ops.one_pass_scorer_wanted(self.table_dtype, Z.shape[0], Z.shape[1], Z.shape[2])     # the rule and its numbers: there
         if one_pass and ops.score_pairs_train_supported(pairs, Z.shape[1], Z.shape[2], dt):
-            if self.table_dtype == torch.float32 and Z.dtype == torch.float32 and graph.n_rows == graph.n_nodes:
+            if Z.dtype == torch.float32 and graph.n_rows == graph.n_nodes:
                 from . import native                            # the compiled binding: the same step as ONE C++ autograd node
                 if native.available():
                     H, prob, loss = native.hot_path_pairs_loss(Z, graph, pairs, float(self.beta), float(self.temperature),
-                                                               label, weight)
+                                                               label, weight, self.table_dtype)
                     return H.view(H.shape[0], -1), prob, loss
             H, prob, loss = ops.HotPathPairsLoss.apply(Z, graph, pairs, float(self.beta), float(self.temperature),
                                                        self.table_dtype, label, weight)

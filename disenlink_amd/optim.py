@@ -100,6 +100,15 @@ class StackedAdam:
                 elif p.grad is not None:
                     p.grad.zero_()
 
+    def _native(self) -> bool:
+        ok = self.__dict__.get("_native_ok")
+        if ok is None:
+            from . import native
+            ok = native.available()
+            self._native_ok = ok
+            self._flat_params = [p for k in self.keys for p in self.groups[k]]
+        return ok
+
     def _stacked_grad(self, key) -> torch.Tensor:
         return stacked_grad(self.groups[key], self.model._stacked[key])
 
@@ -108,6 +117,11 @@ class StackedAdam:
         if [self.model._stacked[k].data_ptr() for k in self.keys] != [b.data_ptr() for b in self.bufs]:
             raise RuntimeError("the module's parameter buffers were rebuilt (.to() / load on another device): "
                                "create the optimiser afterwards")
+        if not self.use_torch_kernel and self._native():
+            from . import native                                   # gradient bookkeeping + launch in C++ (no ctypes, no per-parameter Python)
+            native.adam_step(self.bufs, self._flat_params, self.exp_avg, self.exp_avg_sq, self.dl_state, self.lr, self.betas[0],
+                             self.betas[1], self.eps, self.weight_decay)
+            return
         grads = [self._stacked_grad(k) for k in self.keys]
         if not self.use_torch_kernel:
             from . import _lib

@@ -1719,6 +1719,101 @@ def test_one_pass_training_scorer_matches_the_oracle_directly(K, d, dtype, t):
 
 
 @pytest.mark.gpu
+def test_compiled_projection_adam_auc_and_bf16_hot_path_equal_the_python_operators_bit_for_bit(monkeypatch):
+    """Round 5: the rest of the training step behind the compiled binding (csrc/torch/dl_torch.cpp) — the projection over
+    the module's shared buffers (forward, the four stacked gradients), the Adam step, the AUC counts, and the hot path with
+    bf16 tables — against the Python operators over ctypes: the same kernels, so the same bits; and a whole eager training
+    run with DL_NATIVE_OPS=1 against DL_NATIVE_OPS=0."""
+    from disenlink_amd import native, ops
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.metrics import AucPlan
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.optim import StackedAdam, flat_view
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    native._state["loaded"] = None
+    assert native.available()
+    # ---- projection node: Z, and every parameter's gradient as a slice of one flat allocation
+    torch.manual_seed(0)
+    N, F, K, nhid, d = 700, 64, 8, 96, 64
+    x = torch.randn(N, F, device=DEV)
+    gZ = torch.randn(N, K, d, device=DEV)
+    out = {}
+    for which in ("python", "native"):
+        torch.manual_seed(1)
+        m = Disentangle(F, nhid, d, nfactor=K, beta=0.5, t=1).to(DEV)
+        flat = m._stacked_params()
+        st = m._stacked
+        bufs = (st[("mlp1", "weight")], st[("mlp1", "bias")], st[("mlp2", "weight")], st[("mlp2", "bias")])
+        assert native.project_ok(x, d, False)
+        Z = ops.ProjectStacked.apply(x, bufs, K, *flat) if which == "python" else native.project_stacked(x, bufs, flat)
+        Z.backward(gZ)
+        grads = [p.grad for p in flat]
+        assert flat_view([g for g in grads]) is not None             # back to back: one all-reduce, no stacking copy in Adam
+        out[which] = (Z.detach().clone(), [g.clone() for g in grads], m)
+    assert torch.equal(out["python"][0], out["native"][0])
+    for a_, b_ in zip(out["python"][1], out["native"][1]):
+        assert torch.equal(a_, b_)
+    # ---- Adam step on those gradients: native bookkeeping + launch vs the ctypes path
+    after = {}
+    for which in ("python", "native"):
+        m = out[which][2]
+        opt = StackedAdam(m, lr=1e-2, weight_decay=5e-4)
+        opt._native_ok = which == "native"
+        opt._flat_params = [p for k in opt.keys for p in opt.groups[k]]
+        for _ in range(3):
+            opt.step()
+        after[which] = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in after["python"]:
+        assert torch.equal(after["python"][k], after["native"][k]), k
+    # ---- AUC counts
+    lab = (torch.rand(5000, device=DEV) < 0.3).float()
+    sc = torch.rand(5000, device=DEV)
+    sc[::7] = 1.0                                                      # ties
+    plan = AucPlan(lab)
+    a_native = plan.auc(sc)
+    monkeypatch.setenv("DL_NATIVE_OPS", "0")
+    native._state["loaded"] = None
+    try:
+        assert not native.available()
+        a_py = plan.auc(sc)
+        assert float(a_native) == float(a_py) == pytest.approx(metrics_ref.auc_tie_avg(lab.cpu().numpy(), sc.cpu().numpy()), abs=1e-12)
+    finally:
+        monkeypatch.delenv("DL_NATIVE_OPS")
+        native._state["loaded"] = None
+    assert native.available()
+    # ---- the hot path with bf16 tables through both bindings
+    G, pairs, Z0, label, weight, _pu, _pv = _one_pass_case(8, 64, torch.bfloat16, seed=5)
+    res = {}
+    for which in ("python", "native"):
+        Zr = Z0.clone().requires_grad_(True)
+        if which == "python":
+            H, prob, loss = ops.HotPathPairsLoss.apply(Zr, G, pairs, 0.6, 1.0, torch.bfloat16, label, weight)
+        else:
+            H, prob, loss = native.hot_path_pairs_loss(Zr, G, pairs, 0.6, 1.0, label, weight, torch.bfloat16)
+        (loss * 2.0 + (H * H).sum() * 1e-3).backward()
+        res[which] = (H.detach().clone(), prob.detach().clone(), loss.detach().clone(), Zr.grad.clone())
+    for a_, b_, what in zip(res["python"], res["native"], ("H", "prob", "loss", "dZ")):
+        assert torch.equal(a_, b_), what
+    # ---- a whole eager training run either way: the same trajectory bit for bit
+    sg = synthetic_graph("cora", seed=2)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=2)
+    run = prepare_run(split, torch.device(DEV), row_bytes=8 * 64 * 4)
+    xx = torch.from_numpy(sg.features()[:, :1432].copy()).to(DEV)     # F % 4 == 0: the compiled projection node serves it
+    traj = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DL_NATIVE_OPS", mode)
+        native._state["loaded"] = None
+        torch.manual_seed(0)
+        model = Disentangle(xx.shape[1], 64, 64, nfactor=8, beta=0.6, t=1).to(DEV)
+        traj[mode] = run_link_prediction(model, xx, run, epochs=6, lr=1e-3, use_graph=False)
+    monkeypatch.delenv("DL_NATIVE_OPS")
+    native._state["loaded"] = None
+    assert traj["1"].losses == traj["0"].losses and traj["1"].val_aucs == traj["0"].val_aucs
+    assert traj["1"].test_auc == traj["0"].test_auc
+
+
+@pytest.mark.gpu
 def test_compiled_binding_and_python_operator_agree_at_temperature_2_and_with_a_loss_on_prob():
     """native.hot_path_pairs_loss (C++ autograd node) against ops.HotPathPairsLoss at t = 2 — the wave kernel's T1 = false
     instantiation through both bindings — bit for bit, for loss.backward() and with another loss term on `prob` and on
