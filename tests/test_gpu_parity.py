@@ -55,7 +55,10 @@ def test_forward_kernels_match_reference_golden(name, force_generic):
         src = sparse_ref.edge_rows(rowptr)
         _p, _a, alpha, _s = sparse_ref.route(Zh, rowptr, col, m["t"])
         ok = _decisive(alpha)
-        assert ok.mean() > 0.95
+        # every committed fixture routes every edge decisively (top-2 margin > 1e-5: checked on the CPU when the fixtures were
+        # made), so the near-tie masks below select EVERYTHING here — they only say what would have to be left out if a
+        # fixture with a near-tie were ever added, and such a fixture must say so explicitly
+        assert ok.all(), f"{name}: {int((~ok).sum())} near-tie edges in a golden fixture"
         assert (p.cpu().numpy()[ok] == g["p"][src, col][ok]).all()
         np.testing.assert_allclose(a.cpu().numpy()[ok], g["a"][src, col][ok], rtol=1e-5)
         # A near-tie in the routing of one edge (fp32 may break it either way) changes s of that row, h of that row and of
@@ -63,7 +66,7 @@ def test_forward_kernels_match_reference_golden(name, force_generic):
         row_ok = np.bincount(src[~ok], minlength=N) == 0                       # every edge of the row is decisive
         nb_bad = np.bincount(src, weights=(~row_ok[col]).astype(float), minlength=N) > 0
         node_ok = row_ok & ~nb_bad                                             # ... and of every neighbour's row
-        assert node_ok.mean() > 0.6, node_ok.mean()
+        assert node_ok.all(), node_ok.mean()                                   # all nodes, all N^2 scores are compared
         s_h = s.cpu().numpy()
         np.testing.assert_allclose(np.where(s_h == 0, 1, s_h)[row_ok], g["s"][row_ok], rtol=1e-5)
         H = ops.aggregate_fwd(G, Z, m["beta"], p, a, s)
