@@ -74,6 +74,40 @@ __device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
     }
 }
 
+// The W2 operand of layer 2 for one hidden chunk, staged through LDS (round 5).  The planes of W2 lie in global memory as
+// [3][K*D][nhid_p] bf16 with the hidden units in layer 2's k-slot order; a chunk's slice — D rows x 128 hidden x 3 planes —
+// was read straight from there by every wave, one K = 16 group ahead of its use: 16 bytes per lane from 32 different rows
+// per instruction (a quarter of every 128-byte line used), and a global round trip per group that no prefetch depth hid
+// (stamps, tools/r5_proj_stamps.py: 9,000 cycles per chunk for 48 MFMAs = 1,536 cycles of issue).  Now the whole workgroup
+// copies the slice with fully coalesced 16-byte loads (issued at the top of the chunk's last layer-1 step) into the LDS tile
+// buffer that step has just finished reading, and layer 2 takes its A operands from there with ds_read_b128.
+template <int D, int THREADS>
+struct W2Stage {
+    static constexpr int PIECES = 3 * D * 16;                  // 16-byte pieces: 3 planes x D rows x (128 hidden / 8)
+    static constexpr int PER = PIECES / THREADS;
+    static constexpr int PITCH = 128 + 8;                      // LDS row pitch (bf16): 68 dwords -> conflict-free b128 reads
+    static_assert(PIECES % THREADS == 0, "the slice divides over the workgroup");
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v[PER];
+    __device__ __forceinline__ void fetch(const __bf16* __restrict__ w2, size_t plane_stride, size_t row0, int nhid_p, int col0, int tid) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int q = tid + THREADS * j, p = q / (D * 16), r = (q % (D * 16)) / 16, c = (q % 16) * 8;
+            v[j] = *reinterpret_cast<const u32x4*>(w2 + p * plane_stride + (row0 + r) * nhid_p + col0 + c);
+        }
+    }
+    __device__ __forceinline__ void stash(__bf16* lds, int tid) const {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int q = tid + THREADS * j, p = q / (D * 16), r = (q % (D * 16)) / 16, c = (q % 16) * 8;
+            *reinterpret_cast<u32x4*>(lds + (p * D + r) * PITCH + c) = v[j];
+        }
+    }
+};
+#ifndef DL_W2_LDS
+#define DL_W2_LDS 1               // -DDL_W2_LDS=0: the W2 operand straight from global memory (the round-2 form), for A/B runs
+#endif
+
 // Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D].
 // VEC: F % 4 == 0 and nhid % 4 == 0.  1-D grid of xcd_grid(node tiles of 128, K * G hidden-chunk groups).
 // out: Z [N][K][D] with b2 != nullptr (G == 1), or slab [G][N][K][D] of partial sums with b2 == nullptr.
@@ -84,6 +118,22 @@ struct FwdPlanes {
     const __bf16* x; const __bf16* w; size_t w_batch; int ncb;     // tile-major planes of x and of the K matrices W1_k
     const __bf16* w2; size_t w2_ps; int nhid_p;                    // planes [3][K*D][nhid_p] of W2 in layer 2's k-slot order
 };
+
+// -DDL_PROJ_STAMPS=<workgroup index>: DIAGNOSTIC build — waves 0 and 4 of that workgroup (two waves of one SIMD) record
+// s_memtime at the phase boundaries of every pipeline step into dl_proj_stamps (read back by dl_debug_read_stamps; the
+// stamps go nowhere else).  tools/r5_proj_stamps.py prints the timeline.
+#ifdef DL_PROJ_STAMPS
+__device__ unsigned long long dl_proj_stamps[2][512];
+#define DL_STAMP(code)                                                                                  \
+    do {                                                                                                \
+        if (stamp_on && stamp_n < 510) {                                                                \
+            dl_proj_stamps[stamp_w][stamp_n++] = ((unsigned long long)(code) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); \
+            dl_proj_stamps[stamp_w][511] = stamp_n;                                                     \
+        }                                                                                               \
+    } while (0)
+#else
+#define DL_STAMP(code) do {} while (0)
+#endif
 
 template <int D, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restrict__ x, int N, int F, int nhid,
@@ -96,8 +146,13 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                               // [2][TN][LDT]
     float* w1s = xs + 2 * TN * LDT;                // [2][TH][LDT]
-    __bf16* xp = reinterpret_cast<__bf16*>(lds);   // SPLIT: [2][3][TN][SPLIT_PITCH]
-    __bf16* wp = xp + 2 * 3 * TN * SPLIT_PITCH;    //        [2][3][TH][SPLIT_PITCH]
+    // SPLIT: two parity buffers, each [3][TN][SPLIT_PITCH] (x tile) followed by [3][TH][SPLIT_PITCH] (W1 tile): one buffer is
+    // one contiguous block (it also takes the W2 slice of a chunk's layer 2, W2Stage)
+    constexpr int XBUF = 3 * TN * SPLIT_PITCH, PBUF = 3 * (TN + TH) * SPLIT_PITCH;
+    __bf16* pbuf = reinterpret_cast<__bf16*>(lds);
+    constexpr bool W2LDS = SPLIT && DL_W2_LDS && D <= 64 && (size_t)W2Stage<D, NTHR>::PITCH * 3 * D <= (size_t)PBUF;
+    float* bias_s = reinterpret_cast<float*>(pbuf + 2 * PBUF);      // SPLIT: the 128 biases of the current hidden chunk
+    float bias_q = 0.0f;
     const XcdItem item = xcd_item(blockIdx.x, (N + TN - 1) / TN, K * G);
     if (!item.valid) return;
     const int k = item.b % K, grp = item.b / K;
@@ -105,6 +160,12 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
     const int wn = wave >> 1, wh = wave & 1;
+#ifdef DL_PROJ_STAMPS
+    const bool stamp_on = (int)blockIdx.x == DL_PROJ_STAMPS && (wave == 0 || wave == 4) && lane == 0;
+    const int stamp_w = wave >> 2;
+    int stamp_n = 0;
+#endif
+    DL_STAMP(1);
     const float* W1k = W1 + (size_t)k * nhid * F;
     const float* W2k = W2 + (size_t)k * D * nhid;
     const float* b1k = b1 + (size_t)k * nhid;
@@ -128,8 +189,8 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     };
     auto stash = [&](int s) {
         if constexpr (SPLIT) {
-            xq.stash(xp + (s & 1) * 3 * TN * SPLIT_PITCH, tid);
-            wq.stash(wp + (s & 1) * 3 * TH * SPLIT_PITCH, tid);
+            xq.stash(pbuf + (s & 1) * PBUF, tid);
+            wq.stash(pbuf + (s & 1) * PBUF + XBUF, tid);
         } else {
             xt.template stash<LDT>(xs + (s & 1) * TN * LDT, tid);
             wt.template stash<LDT>(w1s + (s & 1) * TH * LDT, tid);
@@ -162,47 +223,74 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
             x0.fetch(P.x + plane_tile<SPLIT_COLS>(item.a, 0, P.ncb), tid);
             w0.fetch(P.w + (size_t)k * P.w_batch + plane_tile<SPLIT_COLS>(hc0, 0, P.ncb), tid);
             fetch(min(1, steps - 1));
-            x0.stash(xp, tid);
-            w0.stash(wp, tid);
+            x0.stash(pbuf, tid);
+            w0.stash(pbuf + XBUF, tid);
         } else {
             fetch(0);
             stash(0);
             if (steps > 1) fetch(1);
         }
     }
+    DL_STAMP(2);
     __syncthreads();
+    DL_STAMP(3);
     for (int s = 0; s < steps; ++s) {
         const int hc = hc0 + s / nfc, fc = s % nfc;
         const bool last = fc == nfc - 1;
         const int hbase = hc * TH + wh * 64;                    // first hidden unit of this wave's tile
+        DL_STAMP(10);
         float4 bias[2][4], wnext[2][4];                         // quad g of tile ht = hidden rows 8g+4*half .. +3
-        if (last) {
+        if constexpr (!SPLIT) {
+            if (last) {
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht)
+                for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bias[ht][g] = load4_raw<VEC>(b1k, hbase + ht * 32 + 8 * g + 4 * half, nhid);
-            if constexpr (!SPLIT) load_w2(wnext, 0, hbase);
+                    for (int g = 0; g < 4; ++g) bias[ht][g] = load4_raw<VEC>(b1k, hbase + ht * 32 + 8 * g + 4 * half, nhid);
+                load_w2(wnext, 0, hbase);
+            }
+        }
+        // SPLIT: nothing is requested from global memory at the top of a step.  s_waitcnt vmcnt counts in issue order, and the
+        // tile of step s+1 — requested a step ago — is written to LDS in the middle of this step: a load issued HERE would be
+        // younger than the tile's, the compiler cannot tell the two apart at the join of the `last` branch (it waits for
+        // vmcnt(0)), and the stash would sit out a whole global round trip (stamps: +2,800 cycles in every chunk's last
+        // step).  The chunk's biases and the W2 slice are requested BEHIND the stash instead (below); the biases — asked
+        // for a step ahead — go to LDS here, at the top of the chunk's last step, where everything younger than them was
+        // requested a step ago too.  (F <= 32, one step per chunk: requested here, staged before their use.)
+        if constexpr (SPLIT) {
+            if (tid < TH) {
+                if (nfc == 1) {
+                    const int h = hc * TH + tid;
+                    bias_q = b1k[h < nhid ? h : 0];
+                    bias_q = h < nhid ? bias_q : 0.0f;
+                } else if (last) {
+                    bias_s[tid] = bias_q;
+                }
+            }
         }
         // SPLIT: the A operand of layer 2 for group grp = (d-tile, hidden tile, K = 16 block): one 16-byte load per plane
         auto load_w2p = [&](bf16x8 (&a)[3], int grp) {
             const int dt = grp >> 2, ht = (grp >> 1) & 1, b = grp & 1;
-            const __bf16* src = P.w2 + ((size_t)k * D + dt * 32 + li) * P.nhid_p + hbase + ht * 32 + 16 * b + 8 * half;
+            if constexpr (W2LDS) {                               // the slice staged in this step's (already read) tile buffer
+                const __bf16* src = pbuf + (s & 1) * PBUF + (dt * 32 + li) * W2Stage<D, NTHR>::PITCH + wh * 64 + ht * 32 + 16 * b + 8 * half;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(src + p * P.w2_ps);
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(src + p * D * W2Stage<D, NTHR>::PITCH);
+            } else {
+                const __bf16* src = P.w2 + ((size_t)k * D + dt * 32 + li) * P.nhid_p + hbase + ht * 32 + 16 * b + 8 * half;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(src + p * P.w2_ps);
+            }
         };
         // one group in flight (issued here for the first, a layer-1 step ahead; three in flight measured no faster)
-        constexpr int W2PF = 1;
+#ifndef DL_W2PF
+#define DL_W2PF 1
+#endif
+        constexpr int W2PF = DL_W2PF;
         bf16x8 w2a[W2PF + 1][3];
-        if constexpr (SPLIT) {
-            if (last) {
-#pragma unroll
-                for (int q = 0; q < W2PF; ++q) load_w2p(w2a[q], q);
-            }
-        }
+        W2Stage<D, NTHR> w2st;
         if constexpr (SPLIT) {
             // lane half h supplies features 8h .. 8h+7 of each 16-wide block: A = W1 rows (two hidden tiles), B = x rows
-            const __bf16* xb = xp + (s & 1) * 3 * TN * SPLIT_PITCH + (wn * 32 + li) * SPLIT_PITCH + half * 8;
-            const __bf16* wb = wp + (s & 1) * 3 * TH * SPLIT_PITCH + (wh * 64 + li) * SPLIT_PITCH + half * 8;
+            const __bf16* xb = pbuf + (s & 1) * PBUF + (wn * 32 + li) * SPLIT_PITCH + half * 8;
+            const __bf16* wb = pbuf + (s & 1) * PBUF + XBUF + (wh * 64 + li) * SPLIT_PITCH + half * 8;
             // both K = 16 blocks of the chunk are read up front: block 1's LDS latency hides behind block 0's MFMAs
             bf16x8 a0[2][3], a1[2][3], b[2][3];
 #pragma unroll
@@ -213,14 +301,34 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                     a0[kb][p] = *reinterpret_cast<const bf16x8*>(wb + p * TH * SPLIT_PITCH + kb * 16);
                     a1[kb][p] = *reinterpret_cast<const bf16x8*>(wb + (p * TH + 32) * SPLIT_PITCH + kb * 16);
                 }
+            DL_STAMP(11);
             mfma_split6(hacc[0], a0[0], b[0]);
             mfma_split6(hacc[1], a1[0], b[0]);
+            DL_STAMP(12);
             if (s + 1 < steps) stash(s + 1);
+            // behind the stash (see the top of the step): the chunk's 128 biases — one float per thread of the first two
+            // waves, a step ahead of their use — and, in the chunk's last step, the W2 operand of layer 2
+            if (nfc >= 2 && fc == nfc - 2 && tid < TH) {
+                const int h = hc * TH + tid;
+                bias_q = b1k[h < nhid ? h : 0];
+                bias_q = h < nhid ? bias_q : 0.0f;
+            }
+            if (last) {
+                if constexpr (W2LDS) {
+                    w2st.fetch(P.w2, P.w2_ps, (size_t)k * D, P.nhid_p, hc * TH, tid);      // coalesced; lands under the rest of the step
+                } else {
+#pragma unroll
+                    for (int q = 0; q < W2PF; ++q) load_w2p(w2a[q], q);
+                }
+            }
             // unconditional (the last steps fetch the last tile again): a fetch under a condition makes the
             // registers a merge of old and new values, and hipcc then waits for the loads right here to copy them
+            DL_STAMP(13);
             fetch(min(s + 2, steps - 1));
+            DL_STAMP(14);
             mfma_split6(hacc[0], a0[1], b[1]);
             mfma_split6(hacc[1], a1[1], b[1]);
+            DL_STAMP(15);
         } else {
         // lane half h owns features h*FC/2 .. h*FC/2 + FC/2-1 of the chunk; MFMA block j takes 2 quads of them
         // per operand row (3 ds_read_b128, 16 MFMAs), block j+1's reads are issued ahead of block j's MFMAs
@@ -258,12 +366,21 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
         }
         }   // !SPLIT
         if (last) {
+            if constexpr (SPLIT) {
+                if (nfc == 1 && tid < TH) bias_s[tid] = bias_q;
+                __syncthreads();        // the biases are staged; every wave has this step's operands in registers: the tile buffer is free
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bias[ht][g] = *reinterpret_cast<const float4*>(bias_s + wh * 64 + ht * 32 + 8 * g + 4 * half);
+            }
             // bias + ReLU on hidT (row = hidden unit, column = node), then layer 2 straight from the registers
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    bias[ht][g] = zero4<VEC>(bias[ht][g], hbase + ht * 32 + 8 * g + 4 * half, nhid);
+                    if constexpr (!SPLIT) bias[ht][g] = zero4<VEC>(bias[ht][g], hbase + ht * 32 + 8 * g + 4 * half, nhid);   // (SPLIT: staged as zeros)
                     hacc[ht][4 * g + 0] = fmaxf(hacc[ht][4 * g + 0] + bias[ht][g].x, 0.0f);
                     hacc[ht][4 * g + 1] = fmaxf(hacc[ht][4 * g + 1] + bias[ht][g].y, 0.0f);
                     hacc[ht][4 * g + 2] = fmaxf(hacc[ht][4 * g + 2] + bias[ht][g].z, 0.0f);
@@ -279,6 +396,7 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                         if (h < nhid && n < N) hid_out[((size_t)k * nhid + h) * ldh + n] = hacc[ht][r];
                     }
             }
+            DL_STAMP(20);
             if constexpr (SPLIT) {
                 // layer 2 on the bf16 matrix path too: the post-ReLU accumulator is split into its three planes in
                 // registers (slot s of block b = register 8b + s), W2 comes pre-split in the matching order
@@ -293,11 +411,20 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                             split3(hacc[ht][8 * b + s8], hi, mid, lo);
                             hp[ht][b][0][s8] = hi; hp[ht][b][1][s8] = mid; hp[ht][b][2][s8] = lo;
                         }
+                if constexpr (W2LDS) {
+                    // the slice was requested at the top of this step (a layer-1 step, the bias / ReLU and the plane split ago)
+                    w2st.stash(pbuf + (s & 1) * PBUF, tid);
+                    __syncthreads();                                 // the staged slice is complete
+#pragma unroll
+                    for (int q = 0; q < W2PF; ++q) load_w2p(w2a[q], q);
+                }
+                DL_STAMP(21);
 #pragma unroll
                 for (int grp = 0; grp < 4 * DT; ++grp) {
                     if (grp + W2PF < 4 * DT) load_w2p(w2a[(grp + W2PF) % (W2PF + 1)], grp + W2PF);
                     mfma_split6(zacc[grp >> 2], w2a[grp % (W2PF + 1)], hp[(grp >> 1) & 1][grp & 1]);
                 }
+                DL_STAMP(22);
             } else {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -321,7 +448,9 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) zero_acc(hacc[ht]);
         }
+        DL_STAMP(16);
         __syncthreads();
+        DL_STAMP(17);
     }
     // The two hidden halves (wh = 0, 1) of a node quarter hold partial Z sums: wave wh = 1 hands its half
     // over through LDS and wave wh = 0 adds (fixed order), adds b2 and stores (registers 4g..4g+3 are 4
@@ -335,6 +464,7 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     }
     __syncthreads();
     const int n = n0 + wn * 32 + li;
+    DL_STAMP(30);
     if (wh == 0 && n < N) {
         float* orow = out + (((size_t)grp * N + n) * K + k) * D;
 #pragma unroll
@@ -350,11 +480,22 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                 *reinterpret_cast<float4*>(orow + dd) = make_float4(o[0] + bb.x, o[1] + bb.y, o[2] + bb.z, o[3] + bb.w);
             }
     }
+    DL_STAMP(31);
 }
+
+#ifdef DL_PROJ_STAMPS
+}  // namespace project
+}  // namespace dl
+extern "C" int dl_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dl::project::dl_proj_stamps), sizeof(unsigned long long) * 2 * 512);
+}
+namespace dl {
+namespace project {
+#endif
 
 constexpr size_t project2_lds(int D, bool split) {
     const size_t red = sizeof(float) * 4 * (D / 32) * 16 * 64;                 // the Z hand-over at the end
-    const size_t stage = split ? sizeof(__bf16) * 2 * 3 * (TN + TH) * SPLIT_PITCH : sizeof(float) * (2 * TN + 2 * TH) * (fwd_fc(D) + 4);
+    const size_t stage = split ? sizeof(__bf16) * 2 * 3 * (TN + TH) * SPLIT_PITCH + sizeof(float) * TH : sizeof(float) * (2 * TN + 2 * TH) * (fwd_fc(D) + 4);
     return stage > red ? stage : red;
 }
 
