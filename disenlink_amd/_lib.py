@@ -61,6 +61,10 @@ EXPORTS = {
     "dl_project_fwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "dl_project_hidden_floats": (_z, [_i, _i, _i]),
     "dl_project_fwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
+    "dl_project_xplanes_bytes": (_z, [_i, _i]),
+    "dl_project_xplanes_build": (_i, [_P, _i, _i, _P, _z, _P]),
+    "dl_project_fwd_xp": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _z, _P, _P]),
+    "dl_project_bwd_xp": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P, _P]),
     "dl_project_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "dl_project_bwd": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_fwd": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _z, _P]),

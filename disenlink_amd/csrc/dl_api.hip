@@ -132,9 +132,26 @@ size_t dl_project_hidden_floats(int N, int K, int nhid) {
     return (size_t)K * nhid * (size_t)((N + 3) & ~3);
 }
 
+size_t dl_project_xplanes_bytes(int N, int F) { return (N > 0 && F > 0) ? project_xplanes_bytes(N, F) : 0; }
+
+int dl_project_xplanes_build(const float* x, int N, int F, void* xplanes, size_t xplanes_bytes, void* stream) {
+    DL_REQUIRE(N >= 0 && F >= 1, "bad size N=%d F=%d", N, F);
+    if (N == 0) return DL_OK;
+    DL_REQUIRE(x && xplanes && xplanes_bytes >= project_xplanes_bytes(N, F) && ((uintptr_t)xplanes & 15) == 0,
+               "x planes buffer: %zu bytes given, %zu needed (dl_project_xplanes_bytes), 16-byte aligned", xplanes_bytes,
+               project_xplanes_bytes(N, F));
+    return project_xplanes_build(x, N, F, xplanes, (hipStream_t)stream);
+}
+
 int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
                    const float* W2, const float* b2, float* Z, float* hid_out, void* ws, size_t ws_bytes,
                    void* stream) {
+    return dl_project_fwd_xp(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, hid_out, ws, ws_bytes, nullptr, stream);
+}
+
+int dl_project_fwd_xp(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                      const float* W2, const float* b2, float* Z, float* hid_out, void* ws, size_t ws_bytes,
+                      const void* xplanes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
     DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
@@ -144,7 +161,9 @@ int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d, const f
     DL_REQUIRE(x && W1 && b1 && Z, "NULL argument");
     DL_REQUIRE((long long)N * K * d < (1LL << 40) && (long long)128 * F < (1LL << 31), "projection sizes out of range");
     DL_REQUIRE(hid_out == nullptr || W2 != nullptr, "hid_out is for the two-layer form only");
-    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, ws, ws_bytes, hid_out, (hipStream_t)stream);
+    DL_REQUIRE(xplanes == nullptr || ((uintptr_t)xplanes & 15) == 0, "x planes must be 16-byte aligned");
+    return project_fwd(x, N, F, K, nhid, d, W1, b1, W2, b2, Z, ws, ws_bytes, hid_out, (hipStream_t)stream,
+                       W2 != nullptr ? xplanes : nullptr);
 }
 
 size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int two_layer) {
@@ -155,6 +174,12 @@ size_t dl_project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, int 
 int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
                    const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
                    void* ws, size_t ws_bytes, void* stream) {
+    return dl_project_bwd_xp(x, N, F, K, nhid, d, W1, b1, W2, dZ, hid, dW1, db1, dW2, db2, ws, ws_bytes, nullptr, stream);
+}
+
+int dl_project_bwd_xp(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
+                      const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
+                      void* ws, size_t ws_bytes, const void* xplanes, void* stream) {
     if (int rc = check_shape(K, d)) return rc;
     DL_REQUIRE(project_supported(d), "projection kernel supports d in {32, 64, 128}, got %d", d);
     DL_REQUIRE(N >= 0 && F >= 1 && nhid >= 1, "bad size N=%d F=%d nhid=%d", N, F, nhid);
@@ -176,7 +201,9 @@ int dl_project_bwd(const float* x, int N, int F, int K, int nhid, int d, const f
     DL_REQUIRE(ws != nullptr && ws_bytes >= need, "workspace too small: %zu < %zu bytes (dl_project_bwd_workspace_bytes)",
                ws_bytes, need);
     DL_REQUIRE(hid == nullptr || two, "hid is for the two-layer form only");
-    return project_bwd(x, N, F, K, two ? nhid : 1, d, W1, b1, W2, dZ, hid, dW1, db1, dW2, db2, ws, (hipStream_t)stream);
+    DL_REQUIRE(xplanes == nullptr || ((uintptr_t)xplanes & 15) == 0, "x planes must be 16-byte aligned");
+    return project_bwd(x, N, F, K, two ? nhid : 1, d, W1, b1, W2, dZ, hid, dW1, db1, dW2, db2, ws, (hipStream_t)stream,
+                       xplanes);
 }
 
 int dl_route_fwd(const dl_graph* g, const void* Z, int K, int d, dl_dtype dtype, float t, uint8_t* p, float* a,

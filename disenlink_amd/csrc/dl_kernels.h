@@ -73,11 +73,16 @@ bool project_supported(int d);
 size_t project_fwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer);
 bool split_products();   // layer-1 / dW1 products from three bf16 planes per operand (off: DL_PROJECT_FP32_MFMA=1)
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st);
+                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st,
+                const void* xplanes = nullptr);
+// persistent bf16 planes of x and x^T (x is constant for a run): built once, handed to project_fwd / project_bwd
+size_t project_xplanes_bytes(int N, int F);
+const void* project_xplanes_xT(const void* xplanes, int N, int F);
+int project_xplanes_build(const float* x, int N, int F, void* xplanes, hipStream_t st);
 // its backward (dl_project_bwd.hip): weight / bias gradients, W2 == nullptr for the single layer
 size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer);
 int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
                 const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
-                void* ws, hipStream_t st);
+                void* ws, hipStream_t st, const void* xplanes = nullptr);
 
 }  // namespace dl

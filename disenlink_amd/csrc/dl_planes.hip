@@ -145,7 +145,7 @@ void split_fwd_operands(const float* x, int N, int F, __bf16* xP, const float* W
                         const float* W2, int d, __bf16* w2P, int nhid_p, hipStream_t st) {
     const RowsJob jx = rows_job(x, N, F, F, 0, xP), jw = rows_job(W1, nhid, F, F, (size_t)nhid * F, wP);
     const W2Job j2 = w2_job(W2, K * d, nhid, w2P, nhid_p);
-    const unsigned bx = rows_blocks(jx), bw = rows_blocks(jw), b2 = w2_blocks(j2);
+    const unsigned bx = x ? rows_blocks(jx) : 0u, bw = rows_blocks(jw), b2 = w2_blocks(j2);   // x == NULL: its planes exist already
     hipLaunchKernelGGL(split_fwd_operands_kernel, dim3(bx + (unsigned)K * bw + b2), dim3(256), 0, st, jx, bx, jw, bw,
                        (unsigned)K, j2);
 }

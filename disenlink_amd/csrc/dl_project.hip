@@ -632,8 +632,33 @@ static void launch2_t(int N, int K, int G, int cpg, hipStream_t st, const float*
                        out, K, G, cpg, hid_out, ldh, P);
 }
 
+// Persistent planes of the (constant) feature matrix: [x planes, 32-column tiles | x^T planes, 16-column tiles], both
+// tile-major and zero-padded like the per-call arrays (dl_tiles.h).  Only single-block problems use them (fwd_block_rows,
+// bwd_block_rows): a blocked run re-splits the block it works on.
+size_t project_xplanes_bytes(int N, int F) {
+    using namespace project;
+    if (N <= 0 || F <= 0) return 0;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return al(sizeof(__bf16) * plane_array_elems(N, F, SPLIT_COLS)) + al(sizeof(__bf16) * plane_array_elems(F, N, PLANE_ROWS));
+}
+static size_t xplanes_xT_offset(int N, int F) {
+    using namespace project;
+    return (sizeof(__bf16) * plane_array_elems(N, F, SPLIT_COLS) + 255) & ~(size_t)255;
+}
+const void* project_xplanes_xT(const void* xplanes, int N, int F) {
+    return xplanes ? static_cast<const char*>(xplanes) + xplanes_xT_offset(N, F) : nullptr;
+}
+int project_xplanes_build(const float* x, int N, int F, void* xplanes, hipStream_t st) {
+    using namespace project;
+    char* base = static_cast<char*>(xplanes);
+    split_rows(x, 1, N, F, F, 0, reinterpret_cast<__bf16*>(base), st);
+    split_transposed(x, N, F, F, reinterpret_cast<__bf16*>(base + xplanes_xT_offset(N, F)), st);
+    return check_launch("project_xplanes_build");
+}
+
 int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
-                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st) {
+                const float* W2, const float* b2, float* Z, void* ws, size_t ws_bytes, float* hid_out, hipStream_t st,
+                const void* xplanes) {
     using namespace project;
     const int ldh = (N + 3) & ~3;
     if (W2 == nullptr) {          // single Linear(F -> d): W1 is [K][d][F], b1 is [K][d]
@@ -655,7 +680,8 @@ int project_fwd(const float* x, int N, int F, int K, int nhid, int d, const floa
         __bf16* wP = reinterpret_cast<__bf16*>(base + L.off_wp);
         __bf16* w2P = reinterpret_cast<__bf16*>(base + L.off_w2p);
         if (L.R >= N) {                                     // one node block: all three operand splits in one launch
-            split_fwd_operands(x, N, F, xP, W1, K, nhid, wP, W2, d, w2P, L.nhid_p, st);
+            if (xplanes) xP = const_cast<__bf16*>(static_cast<const __bf16*>(xplanes));     // x was split once for the run
+            split_fwd_operands(xplanes ? nullptr : x, N, F, xP, W1, K, nhid, wP, W2, d, w2P, L.nhid_p, st);
         } else {
             split_rows(W1, K, nhid, F, F, (size_t)nhid * F, wP, st);
             split_w2(W2, K * d, nhid, w2P, L.nhid_p, st);

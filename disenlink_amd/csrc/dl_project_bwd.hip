@@ -682,7 +682,8 @@ struct SlabBatch {
 // One node block [row0, row0 + N) of the backward; acc: add to the gradients instead of overwriting them.
 static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
                               const float* W2, const float* dZ, const float* hidT, int ldh, int hid_cols, float* dW1,
-                              float* db1, float* dW2, float* db2, void* ws, bool blocked, bool acc, hipStream_t st) {
+                              float* db1, float* dW2, float* db2, void* ws, bool blocked, bool acc, hipStream_t st,
+                              const void* xT_planes = nullptr) {
     using namespace project;
     const bool two = W2 != nullptr;
     const BwdLayout L = bwd_layout(N, F, K, nhid, d, two, blocked, hidT == nullptr);
@@ -729,7 +730,8 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
         static unsigned long long lds_done_p = 0;
         const size_t lds = sizeof(__bf16) * 2 * 2 * 3 * PLANE_ROWS * PPITCH;
         ensure_dynamic_lds(reinterpret_cast<const void*>(&nodes_contract_planes_kernel), lds, lds_done_p);
-        split_transposed(x, N, F, F, xTP, st);
+        if (xT_planes) xTP = const_cast<__bf16*>(static_cast<const __bf16*>(xT_planes));     // split once for the run
+        else split_transposed(x, N, F, F, xTP, st);
         const dim3 grid((unsigned)xcd_grid(L.sB * ceil_div(F, CT), ceil_div(L.Mb, CT) * K));
         const bool direct = L.sB == 1 && !blocked;
         float* out = direct ? dW1 : w1p;
@@ -755,10 +757,15 @@ static void project_bwd_block(const float* x, int N, int F, int K, int nhid, int
 
 int project_bwd(const float* x, int N, int F, int K, int nhid, int d, const float* W1, const float* b1,
                 const float* W2, const float* dZ, const float* hid, float* dW1, float* db1, float* dW2, float* db2,
-                void* ws, hipStream_t st) {
+                void* ws, hipStream_t st, const void* xplanes) {
     const bool two = W2 != nullptr;
     const int R = project::bwd_block_rows(N, K, nhid, two);
     const bool blocked = R < N;
+    if (!blocked && xplanes && two && split_products()) {     // one block: the persistent x^T planes serve it
+        project_bwd_block(x, N, F, K, nhid, d, W1, b1, W2, dZ, hid, (N + 3) & ~3, (N + 3) & ~3, dW1, db1, dW2, db2, ws, false,
+                          false, st, project_xplanes_xT(xplanes, N, F));
+        return check_launch("project_bwd");
+    }
     const int ldh = (N + 3) & ~3;                               // row stride of the kept hidden layer hidT [K][nhid][ldh]
     for (int row0 = 0; row0 < N; row0 += R)
         project_bwd_block(x + (size_t)row0 * F, std::min(R, N - row0), F, K, nhid, d, W1, b1, W2,

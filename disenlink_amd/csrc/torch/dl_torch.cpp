@@ -141,7 +141,7 @@ struct ProjectStackedNode : public torch::autograd::Function<ProjectStackedNode>
     // (params as at::TensorList: a std::vector<Tensor> argument is NOT seen as a list of autograd inputs by Function::apply —
     // the output then carries no grad_fn)
     static Tensor forward(AutogradContext* ctx, at::TensorList params, const Tensor& x_in, const Tensor& W1, const Tensor& b1,
-                          const Tensor& W2, const Tensor& b2, bool keep_hid) {
+                          const Tensor& W2, const Tensor& b2, bool keep_hid, const c10::optional<Tensor>& xplanes) {
         TORCH_CHECK(x_in.is_cuda() && x_in.scalar_type() == at::kFloat && x_in.dim() == 2, "x must be a CUDA fp32 [N,F] tensor");
         TORCH_CHECK(W1.is_contiguous() && b1.is_contiguous() && W2.is_contiguous() && b2.is_contiguous(), "stacked buffers must be dense");
         at::AutoDispatchBelowADInplaceOrView guard;
@@ -153,17 +153,19 @@ struct ProjectStackedNode : public torch::autograd::Function<ProjectStackedNode>
         Tensor hid;
         if (keep_hid) hid = at::empty({(int64_t)dl_project_hidden_floats(N, K, nhid)}, x.options());
         Tensor ws = at::empty({(int64_t)dl_project_fwd_workspace_bytes(N, F, K, nhid, d, 1) + 256}, x.options().dtype(at::kByte));
-        check(dl_project_fwd(x.data_ptr<float>(), N, F, K, nhid, d, W1.data_ptr<float>(), b1.data_ptr<float>(), W2.data_ptr<float>(),
-                             b2.data_ptr<float>(), Z.data_ptr<float>(), keep_hid ? hid.data_ptr<float>() : nullptr, ws.data_ptr(),
-                             (size_t)ws.numel(), stream()), "dl_project_fwd");
-        ctx->save_for_backward({x, W1, b1, W2, keep_hid ? hid : Tensor()});
+        // xplanes: the persistent bf16 planes of x and x^T (dl_project_xplanes_build; ops._XPlanes) — valid for this x only
+        const bool have_xp = xplanes.has_value() && xplanes->defined() && x.data_ptr() == x_in.data_ptr();
+        check(dl_project_fwd_xp(x.data_ptr<float>(), N, F, K, nhid, d, W1.data_ptr<float>(), b1.data_ptr<float>(), W2.data_ptr<float>(),
+                                b2.data_ptr<float>(), Z.data_ptr<float>(), keep_hid ? hid.data_ptr<float>() : nullptr, ws.data_ptr(),
+                                (size_t)ws.numel(), have_xp ? xplanes->data_ptr() : nullptr, stream()), "dl_project_fwd");
+        ctx->save_for_backward({x, W1, b1, W2, keep_hid ? hid : Tensor(), have_xp ? *xplanes : Tensor()});
         ctx->saved_data["K"] = (int64_t)K;
         return Z;
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         const auto saved = ctx->get_saved_variables();
-        const Tensor &x = saved[0], &W1 = saved[1], &b1 = saved[2], &W2 = saved[3], &hid = saved[4];
+        const Tensor &x = saved[0], &W1 = saved[1], &b1 = saved[2], &W2 = saved[3], &hid = saved[4], &xp = saved[5];
         const int64_t K = ctx->saved_data["K"].toInt();
         const int N = (int)x.size(0), F = (int)x.size(1), nhid = (int)W1.size(1), d = (int)W2.size(1);
         at::AutoDispatchBelowADInplaceOrView guard;
@@ -173,22 +175,22 @@ struct ProjectStackedNode : public torch::autograd::Function<ProjectStackedNode>
         Tensor dW1 = flat.narrow(0, 0, n1).view(W1.sizes()), db1 = flat.narrow(0, n1, n2).view(b1.sizes());
         Tensor dW2 = flat.narrow(0, n1 + n2, n3).view(W2.sizes()), db2 = flat.narrow(0, n1 + n2 + n3, n4).view({K, d});
         Tensor ws = at::empty({(int64_t)dl_project_bwd_workspace_bytes(N, F, (int)K, nhid, d, 1) + 256}, x.options().dtype(at::kByte));
-        check(dl_project_bwd(x.data_ptr<float>(), N, F, (int)K, nhid, d, W1.data_ptr<float>(), b1.data_ptr<float>(), W2.data_ptr<float>(),
-                             dZ.data_ptr<float>(), hid.defined() ? hid.data_ptr<float>() : nullptr, dW1.data_ptr<float>(),
-                             db1.data_ptr<float>(), dW2.data_ptr<float>(), db2.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
-                             stream()), "dl_project_bwd");
+        check(dl_project_bwd_xp(x.data_ptr<float>(), N, F, (int)K, nhid, d, W1.data_ptr<float>(), b1.data_ptr<float>(), W2.data_ptr<float>(),
+                                dZ.data_ptr<float>(), hid.defined() ? hid.data_ptr<float>() : nullptr, dW1.data_ptr<float>(),
+                                db1.data_ptr<float>(), dW2.data_ptr<float>(), db2.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
+                                xp.defined() ? xp.data_ptr() : nullptr, stream()), "dl_project_bwd");
         variable_list out;
-        out.reserve(4 * K + 6);
+        out.reserve(4 * K + 7);
         for (const Tensor* g : {&dW1, &db1, &dW2, &db2})
             for (int64_t k = 0; k < K; ++k) out.push_back(g->select(0, k));
-        for (int i = 0; i < 6; ++i) out.push_back(Tensor());                      // x, W1, b1, W2, b2, keep_hid
+        for (int i = 0; i < 7; ++i) out.push_back(Tensor());                      // x, W1, b1, W2, b2, keep_hid, xplanes
         return out;
     }
 };
 
 Tensor project_stacked(const Tensor& x, const Tensor& W1, const Tensor& b1, const Tensor& W2, const Tensor& b2,
-                       at::TensorList params, bool keep_hid) {
-    return ProjectStackedNode::apply(params, x, W1, b1, W2, b2, keep_hid);
+                       at::TensorList params, bool keep_hid, const c10::optional<Tensor>& xplanes) {
+    return ProjectStackedNode::apply(params, x, W1, b1, W2, b2, keep_hid, xplanes);
 }
 
 // ---------------------------------------------------------------------------- Adam over the shared buffers (main_disentangled.py:150, 199)
@@ -249,7 +251,7 @@ Tensor auc_pair_counts(const Tensor& score, const Tensor& pos_idx, const Tensor&
 TORCH_LIBRARY(disenlink_native, m) {
     m.def("hot_path_pairs_loss(Tensor Z, int graph_ptr, int inc_ptr, int n_edges, float beta, float t, Tensor label, "
           "Tensor weight, Tensor ws_graph, Tensor ws_pairs, Tensor ws_bce, int table_bf16) -> (Tensor, Tensor, Tensor)");
-    m.def("project_stacked(Tensor x, Tensor W1, Tensor b1, Tensor W2, Tensor b2, Tensor[] params, bool keep_hid) -> Tensor");
+    m.def("project_stacked(Tensor x, Tensor W1, Tensor b1, Tensor W2, Tensor b2, Tensor[] params, bool keep_hid, Tensor? xplanes) -> Tensor");
     m.def("adam_step(Tensor[] bufs, Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, Tensor state, float lr, float beta1, "
           "float beta2, float eps, float weight_decay) -> ()");
     m.def("auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor");

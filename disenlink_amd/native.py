@@ -87,7 +87,7 @@ def project_stacked(x: torch.Tensor, bufs, params) -> torch.Tensor:
     W1, b1, W2, b2 = bufs
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     keep = need_grad and ops.keep_hidden(x.shape[0], x.shape[1], W1.shape[0], W1.shape[1])
-    return torch.ops.disenlink_native.project_stacked(x, W1, b1, W2, b2, params, keep)
+    return torch.ops.disenlink_native.project_stacked(x, W1, b1, W2, b2, params, keep, ops.xplanes_for(x))
 
 
 def adam_step(bufs, params, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay) -> None:

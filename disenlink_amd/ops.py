@@ -377,6 +377,53 @@ def padded_features(x: torch.Tensor) -> torch.Tensor:
     return x if Fp == F else _xpad.get(x, Fp)
 
 
+class _XPlanes:
+    """Persistent bf16 planes of a feature matrix and of its transpose (dl_project_xplanes_build), one entry per feature
+    TENSOR (object identity + version counter, like _PaddedFeatures): model.py:106 evaluates the MLPs on the same x every
+    epoch, and the projection kernels otherwise split x (forward) and x^T (backward) into their three bf16 planes on every
+    call.  An entry is made the SECOND time a tensor is seen (a one-off call splits inside its own workspace, as before),
+    only for graphs the kernels process as one node block, and dies with its tensor."""
+    MAX_ROWS = 2 << 17              # fwd_block_rows: larger graphs are processed in node blocks that re-split themselves
+    MAX_BYTES = 1 << 30
+
+    def __init__(self):
+        self._by_id: dict = {}
+
+    def get(self, x: torch.Tensor, force: bool = False):
+        if os.environ.get("DL_X_PLANES", "1") == "0" or x.shape[0] > self.MAX_ROWS or not x.is_cuda:
+            return None
+        key = id(x)
+        hit = self._by_id.get(key)
+        if hit is not None and (hit[0]() is not x or hit[1] != x._version):
+            hit = None
+        if hit is None:
+            ref = weakref.ref(x, lambda _r, k=key, d=self._by_id: d.pop(k, None) if d.get(k, (None,))[0] is _r else None)
+            hit = (ref, x._version, None)
+            self._by_id[key] = hit
+            if not force:
+                return None                                         # first sight: remember the tensor, build next time
+        if hit[2] is None:
+            lib = _lib.load()
+            N, F = x.shape
+            nbytes = int(lib.dl_project_xplanes_bytes(N, F))
+            if nbytes == 0 or nbytes > self.MAX_BYTES:
+                return None
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.dl_project_xplanes_build(x.data_ptr(), N, F, buf.data_ptr(), nbytes, _stream()), "dl_project_xplanes_build")
+            hit = (hit[0], hit[1], buf)
+            self._by_id[key] = hit
+        return hit[2]
+
+
+_xplanes = _XPlanes()
+
+
+def xplanes_for(x: torch.Tensor, force: bool = False):
+    """The persistent planes of the tensor the projection kernels read for x (its zero-padded copy when F % 4 != 0), or
+    None (first sight of the tensor, a blocked graph, DL_X_PLANES=0).  force=True builds them now (before a graph capture)."""
+    return _xplanes.get(padded_features(_f32c(x)), force)
+
+
 def _pad_features(x, W1):
     """Rows of F floats with F % 4 != 0 have no common 16-byte alignment, which would force the kernels onto
     scalar loads.  Zero-pad the feature axis of x (once per tensor: the features are constant data) and of W1
@@ -469,9 +516,10 @@ def project_fwd(x, W1, b1, W2=None, b2=None, pad: bool = True, keep_hid: bool = 
     if keep_hid and W2 is not None:
         hid = _empty(int(lib.dl_project_hidden_floats(N, K, nhid)), torch.float32, x.device)
     ws = _ws.get(int(lib.dl_project_fwd_workspace_bytes(N, F, K, nhid, d, int(W2 is not None))), x.device)
-    _lib.check(lib.dl_project_fwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(), w2p, b2p,
-                                  Z.data_ptr(), hid.data_ptr() if hid is not None else None, ws.data_ptr(), ws.numel(),
-                                  _stream()), "dl_project_fwd")
+    xp = _xplanes.get(x) if W2 is not None else None           # x's planes, split once for the run (second call on)
+    _lib.check(lib.dl_project_fwd_xp(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(), w2p, b2p,
+                                     Z.data_ptr(), hid.data_ptr() if hid is not None else None, ws.data_ptr(), ws.numel(),
+                                     xp.data_ptr() if xp is not None else None, _stream()), "dl_project_fwd")
     return (Z, hid) if keep_hid else Z
 
 
@@ -535,11 +583,13 @@ def project_bwd(x, W1, b1, W2, dZ, pad: bool = True, hid=None, one_allocation: b
     db1 = parts[1]
     dW2, db2 = (parts[2], parts[3]) if two else (None, None)
     ws = _ws.get(int(lib.dl_project_bwd_workspace_bytes(N, F, K, nhid, d, int(two))), x.device)
-    _lib.check(lib.dl_project_bwd(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
-                                  W2.data_ptr() if two else None, dZ.data_ptr(),
-                                  hid.data_ptr() if (two and hid is not None) else None, dW1.data_ptr(), db1.data_ptr(),
-                                  dW2.data_ptr() if two else None, db2.data_ptr() if two else None,
-                                  ws.data_ptr(), ws.numel(), _stream()), "dl_project_bwd")
+    xp = _xplanes.get(x) if two else None
+    _lib.check(lib.dl_project_bwd_xp(x.data_ptr(), N, F, K, nhid, d, W1.data_ptr(), b1.data_ptr(),
+                                     W2.data_ptr() if two else None, dZ.data_ptr(),
+                                     hid.data_ptr() if (two and hid is not None) else None, dW1.data_ptr(), db1.data_ptr(),
+                                     dW2.data_ptr() if two else None, db2.data_ptr() if two else None,
+                                     ws.data_ptr(), ws.numel(), xp.data_ptr() if xp is not None else None, _stream()),
+               "dl_project_bwd")
     if trimmed:
         dW1_out.copy_(dW1[..., :F_true])
     return dW1_out, db1, dW2, db2

@@ -151,8 +151,9 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     # reads and writes: the next allocation of that size would be corrupted, or an index set would turn to garbage).
     # ... and so is the zero-padded copy of x the projection kernels read when F % 4 != 0 (ops.padded_features): it is
     # cached per source tensor, and held here as well so that nothing but the end of this run can free it
-    from .ops import padded_features
-    return graph.replay, out, (graph, opt, val_plan, epoch, label_all, weight_all, x, padded_features(x))
+    # ... and the persistent bf16 planes of x and x^T the projection reads (ops._XPlanes: built by the second warm-up epoch)
+    from .ops import padded_features, xplanes_for
+    return graph.replay, out, (graph, opt, val_plan, epoch, label_all, weight_all, x, padded_features(x), xplanes_for(x))
 
 
 def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 2000, lr: float = 1e-4,

@@ -187,6 +187,23 @@ int dl_project_fwd(const float* x, int N, int F, int K, int nhid, int d,
                    const float* W1, const float* b1, const float* W2, const float* b2,
                    float* Z, float* hid_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Persistent operand planes of the feature matrix (round 5).  model.py:106 evaluates the K MLPs on the SAME x every epoch
+ * (main_disentangled.py:194): dl_project_fwd / dl_project_bwd split x (and x^T) into the three bf16 planes of the matrix
+ * path inside ws on every call.  A caller that keeps x for a run builds them ONCE into a buffer of its own
+ * (dl_project_xplanes_bytes; 16-byte aligned; tile-major planes of x, then of x^T) and passes it to the _xp forms, which
+ * then skip those splits — same products, same bits.  The buffer is valid for exactly the (x contents, N, F) it was built
+ * from; xplanes == NULL behaves like the plain entry points.  Two-layer form on the bf16 matrix path only (the single
+ * layer and DL_PROJECT_FP32_MFMA=1 ignore it); graphs processed in node blocks re-split per block and ignore it too. */
+size_t dl_project_xplanes_bytes(int N, int F);
+int dl_project_xplanes_build(const float* x, int N, int F, void* xplanes, size_t xplanes_bytes, void* stream);
+int dl_project_fwd_xp(const float* x, int N, int F, int K, int nhid, int d,
+                      const float* W1, const float* b1, const float* W2, const float* b2,
+                      float* Z, float* hid_out, void* ws, size_t ws_bytes, const void* xplanes, void* stream);
+int dl_project_bwd_xp(const float* x, int N, int F, int K, int nhid, int d,
+                      const float* W1, const float* b1, const float* W2, const float* dZ, const float* hid,
+                      float* dW1, float* db1, float* dW2, float* db2,
+                      void* ws, size_t ws_bytes, const void* xplanes, void* stream);
+
 /* Backward of the projection: replaces autograd of model.py:13-15 / 24-27 under loss.backward()
  * (main_disentangled.py:198).  dZ fp32 [N][K][d] in; weight and bias gradients out, shaped like the weights
  * (dW1 like W1, db1 like b1, dW2 like W2, db2 like b2; single layer: W2 = dW2 = db2 = NULL, nhid = 1).

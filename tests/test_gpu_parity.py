@@ -1338,6 +1338,44 @@ def test_projection_kernels_serve_any_factor_width_up_to_128(d, nhid):
         ops.project_fwd(x, torch.randn(K, 130, Fdim, device=DEV), torch.randn(K, 130, device=DEV))    # d > 128: not served
 
 
+@pytest.mark.parametrize("F", [128, 269])
+def test_persistent_x_planes_give_the_same_bits_and_follow_the_tensor(F, monkeypatch):
+    """ops._XPlanes: the bf16 planes of x and x^T built once per feature TENSOR (second sight on) and handed to
+    dl_project_fwd_xp / dl_project_bwd_xp — the same products, so Z and every gradient are the same bits as with the
+    per-call split (DL_X_PLANES=0); an in-place change of x (version counter) or another tensor gets planes of its own."""
+    from disenlink_amd import ops
+    torch.manual_seed(5)
+    N, K, nhid, d = 777, 4, 96, 64
+    x = torch.randn(N, F, device=DEV)
+    W1, b1 = torch.randn(K, nhid, F, device=DEV) * 0.1, torch.randn(K, nhid, device=DEV) * 0.1
+    W2, b2 = torch.randn(K, d, nhid, device=DEV) * 0.1, torch.randn(K, d, device=DEV) * 0.1
+    dZ = torch.randn(N, K, d, device=DEV)
+
+    def run():
+        Z, hid = ops.project_fwd(x, W1, b1, W2, b2, keep_hid=True)
+        return (Z,) + tuple(ops.project_bwd(x, W1, b1, W2, dZ, hid=hid)) + tuple(ops.project_bwd(x, W1, b1, W2, dZ))
+    monkeypatch.setenv("DL_X_PLANES", "0")
+    want = run()
+    monkeypatch.delenv("DL_X_PLANES")
+    assert ops.xplanes_for(x) is None                                   # first sight: nothing built
+    first = run()                                                       # (project_fwd saw it once more: the bwd calls build / use them)
+    planes = ops.xplanes_for(x)
+    assert planes is not None and planes.numel() == ops._lib.load().dl_project_xplanes_bytes(N, (F + 3) // 4 * 4)
+    second = run()
+    for a_, b_, c_ in zip(want, first, second):
+        assert torch.equal(a_, b_) and torch.equal(a_, c_)
+    assert ops.xplanes_for(x).data_ptr() == planes.data_ptr()          # reused, not rebuilt
+    x.mul_(2.0)                                                         # in place: the version counter moves, the planes are stale
+    monkeypatch.setenv("DL_X_PLANES", "0")
+    want2 = run()
+    monkeypatch.delenv("DL_X_PLANES")
+    for _ in range(2):
+        got2 = run()
+    for a_, b_ in zip(want2, got2):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(want2[0], want[0])
+
+
 @pytest.mark.parametrize("F", [269, 128])
 def test_projection_gradients_lie_back_to_back_at_every_feature_width(F):
     """ops.project_bwd carves its four stacked gradients out of ONE allocation so that the sharded training step all-reduces
