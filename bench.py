@@ -73,7 +73,7 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-TRAIN_PHASE_KERNELS = {"scorer": ("score_train_wave_kernel", "score_bwd_seg_kernel", "score_bwd_coef_seg_kernel"),
+TRAIN_PHASE_KERNELS = {"scorer": ("score_train_wave_kernel", "score_train_wide_kernel", "score_bwd_seg_kernel", "score_bwd_coef_seg_kernel"),
                        "bwd_phase1": ("bwd_phase1_seg_kernel",), "bwd_phase2": ("bwd_phase2_seg_kernel",),
                        "route": ("route_seg_kernel", "s_rowsum_thread_kernel"), "aggregate": ("aggregate_cls_kernel",)}
 

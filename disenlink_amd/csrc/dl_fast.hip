@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score
 // and the two coefficients of every (entry, chunk) are formed in the lane that holds them and handed to the row by
 // row_newbcast moves: 226 vector instructions per step against 271 above.
 // Entries are accumulated in ascending order by every lane: the sums depend on the row alone (shard-independent).
-// Same-box A/B (tools/r4_train_ab.sh): real squirrel 442 -> 387 us, chameleon 96 -> 78.
+// Same-box A/B (profiles/r4g_train_ab.txt): real squirrel 442 -> 387 us, chameleon 96 -> 78.
 // Tried and dropped: a second register set with the next step's rows requested before the current step is computed
 // (two waves per SIMD; hipcc renamed the sets in the two-step unrolled loop, kept three of them live and spilled 28-50
 // registers: 630-980 us); the per-value xor / rotation all-reduces instead of the transposed reduction (+35 instructions

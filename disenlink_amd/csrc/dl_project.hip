@@ -78,7 +78,7 @@ __device__ __forceinline__ float4 zero4(const float4& q, int base, int n) {
 // [3][K*D][nhid_p] bf16 with the hidden units in layer 2's k-slot order; a chunk's slice — D rows x 128 hidden x 3 planes —
 // was read straight from there by every wave, one K = 16 group ahead of its use: 16 bytes per lane from 32 different rows
 // per instruction (a quarter of every 128-byte line used), and a global round trip per group that no prefetch depth hid
-// (stamps, tools/r5_proj_stamps.py: 9,000 cycles per chunk for 48 MFMAs = 1,536 cycles of issue).  Now the whole workgroup
+// (stamps, tools/proj_stamps.py: 9,000 cycles per chunk for 48 MFMAs = 1,536 cycles of issue).  Now the whole workgroup
 // copies the slice with fully coalesced 16-byte loads (issued at the top of the chunk's last layer-1 step) into the LDS tile
 // buffer that step has just finished reading, and layer 2 takes its A operands from there with ds_read_b128.
 template <int D, int THREADS>
@@ -121,7 +121,7 @@ struct FwdPlanes {
 
 // -DDL_PROJ_STAMPS=<workgroup index>: DIAGNOSTIC build — waves 0 and 4 of that workgroup (two waves of one SIMD) record
 // s_memtime at the phase boundaries of every pipeline step into dl_proj_stamps (read back by dl_debug_read_stamps; the
-// stamps go nowhere else).  tools/r5_proj_stamps.py prints the timeline.
+// stamps go nowhere else).  tools/proj_stamps.py prints the timeline.
 #ifdef DL_PROJ_STAMPS
 __device__ unsigned long long dl_proj_stamps[2][512];
 #define DL_STAMP(code)                                                                                  \

@@ -1,4 +1,4 @@
-"""cProfile of the eager training loop on a small graph (host time per epoch): python tools/r4_epoch_hostprof.py [dataset]"""
+"""cProfile of the eager training loop on a small graph (host time per epoch): python tools/epoch_hostprof.py [dataset]"""
 import cProfile, os, pstats, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

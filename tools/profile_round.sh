@@ -17,6 +17,7 @@ bash tools/prof_stats.sh ${tag}_hbm_bound bench.py --sections hbm_bound --no-cpu
 bash tools/prof_stats.sh ${tag}_chameleon bench.py --workload chameleon --sections headline --steps 20 --warmup 5 --no-cpu-baseline || exit 1
 bash tools/prof_stats.sh ${tag}_penn94_K16_d128_bf16 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 10 --warmup 3 --no-cpu-baseline || exit 1
 bash tools/prof_stats.sh ${tag}_training bench.py --sections fwd_bwd,scorer_train --steps 20 --warmup 5 --no-cpu-baseline --warm-s 0 --min-region-s 0 || exit 1
+bash tools/prof_stats.sh ${tag}_penn94_training bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections fwd_bwd --steps 10 --warmup 3 --no-cpu-baseline --warm-s 0 --min-region-s 0 || exit 1
 bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32 --sections headline --steps 5 --warmup 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32_train --sections fwd_bwd --steps 5 --warmup 2 || exit 1
 # L2-side request counters (what `moved_bytes` is checked against): headline, training step, hbm_bound
@@ -24,6 +25,9 @@ bash tools/pmc_l2_run.sh $tag squirrel_realx1_K8_d64_f32 --sections headline --s
 bash tools/pmc_l2_run.sh $tag squirrel_realx1_K8_d64_f32_train --sections fwd_bwd --steps 5 --warmup 2 || exit 1
 bash tools/pmc_l2_run.sh $tag snap_patentsx0.25_K8_d64_f32 --sections hbm_bound --hbm-steps 2 --repeats 2 || exit 1
 bash tools/pmc_l2_run.sh $tag chameleonx1_K8_d64_f32 --workload chameleon --sections headline --steps 5 --warmup 2 || exit 1
+bash tools/pmc_l2_run.sh $tag penn94x1_K16_d128_bf16 --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 3 --warmup 1 --repeats 2 || exit 1
+bash tools/pmc_l2_run.sh $tag penn94x1_K16_d128_bf16_train --workload penn94 --K 16 --d 128 --dtype bf16 --sections fwd_bwd --steps 3 --warmup 1 || exit 1
+bash tools/pmc_traffic_run.sh $tag penn94x1_K16_d128_bf16_train --workload penn94 --K 16 --d 128 --dtype bf16 --sections fwd_bwd --steps 3 --warmup 1 || exit 1
 bash tools/pmc_traffic_run.sh $tag snap_patentsx0.25_K8_d64_f32 --sections hbm_bound --hbm-steps 2 --repeats 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag chameleonx1_K8_d64_f32 --workload chameleon --sections headline --steps 5 --warmup 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag penn94x1_K16_d128_bf16 --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 3 --warmup 1 --repeats 2 || exit 1
@@ -32,7 +36,7 @@ cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic_latest.json
 cp gpurun_out/${tag}_pmc_l2.json profiles/pmc_l2_latest.json
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err || { tail -n 5 gpurun_out/${tag}_bench.err; exit 1; }
 python3 bench.py --workload chameleon --sections headline,cpu --steps 20 --warmup 5 > gpurun_out/${tag}_chameleon_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
-python3 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_penn94_K16_d128_bf16_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
+python3 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline,fwd_bwd --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_penn94_K16_d128_bf16_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
 cp profiles/pmc_traffic_latest.json gpurun_out/${tag}_pmc_traffic_latest.json
 cp profiles/pmc_l2_latest.json gpurun_out/${tag}_pmc_l2_latest.json
 echo "profile_round $tag done"

@@ -1,6 +1,6 @@
 """Timeline of one workgroup of project2_fwd_kernel from a DIAGNOSTIC build (tools/build_variant.py stamps dl_project.hip
 "-DDL_PROJ_STAMPS=300"): s_memtime at the phase boundaries of waves 0 and 4 (two waves of one SIMD).
-usage: DL_LIB_PATH=variants/libdisenlink_hip_stamps.so python tools/r5_proj_stamps.py [N F K nhid d]"""
+usage: DL_LIB_PATH=variants/libdisenlink_hip_stamps.so python tools/proj_stamps.py [N F K nhid d]"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
