@@ -184,12 +184,18 @@ class Disentangle(nn.Module):
 
     # ------------------------------------------------------------------ projection (model.py:106)
     def project(self, x: torch.Tensor) -> torch.Tensor:
-        """Z [N,K,d] = K independent MLPs of x.  On the GPU (d <= 128, see ``projection``): the fused MFMA
-        kernels of libdisenlink_hip.so.  Otherwise (CPU tests of the host logic, odd d, projection="library"): one
-        wide library GEMM + one K-batched GEMM — plain torch plumbing, the reference's own ops."""
+        """Z [N,K,d] = K independent MLPs of x.  On the GPU: the fused MFMA kernels of libdisenlink_hip.so (d <= 128).
+        The library-GEMM form (one wide GEMM + one K-batched GEMM: the reference's own ops) runs ONLY when asked for —
+        ``Disentangle(projection="library")``, kept for timing comparisons — or for CPU tensors, which no product path
+        serves (the CPU tests of the host logic and of the sharding choreography use it with the oracle as the backend);
+        a CUDA tensor whose shape the kernels do not serve raises instead of falling back."""
         fs = self.factors
         K, d = self.nfactor, self.nebed
-        use_kernel = x.is_cuda and x.dtype == torch.float32 and self.projection != "library" and ops.project_supported(d)
+        if x.is_cuda and self.projection != "library" and not (x.dtype == torch.float32 and ops.project_supported(d)):
+            raise ops._lib.DisenlinkHipError(
+                f"the projection kernels serve fp32 features and factor widths d <= 128 (got {x.dtype}, d = {d}); "
+                "there is no eager fallback on the GPU — construct the module with projection=\"library\" to use the library GEMMs")
+        use_kernel = x.is_cuda and self.projection != "library"
         if use_kernel:
             flat = self._stacked_params()
             if flat is not None:                                # zero-copy: the kernel reads the shared buffers
