@@ -584,7 +584,15 @@ def test_compiled_torch_binding_builds_loads_and_registers_its_operator():
     op = torch.ops.disenlink_native.hot_path_pairs_loss
     assert str(op.default._schema) == (
         "disenlink_native::hot_path_pairs_loss(Tensor Z, int graph_ptr, int inc_ptr, int n_edges, float beta, float t, "
-        "Tensor label, Tensor weight, Tensor ws_graph, Tensor ws_pairs, Tensor ws_bce) -> (Tensor, Tensor, Tensor)")
+        "Tensor label, Tensor weight, Tensor ws_graph, Tensor ws_pairs, Tensor ws_bce, int table_bf16) -> (Tensor, Tensor, Tensor)")
+    # round 5: the rest of the training step — projection node, Adam step, AUC counts
+    schemas = {"project_stacked": "disenlink_native::project_stacked(Tensor x, Tensor W1, Tensor b1, Tensor W2, Tensor b2, "
+                                  "Tensor[] params, bool keep_hid, Tensor? xplanes) -> Tensor",
+               "adam_step": "disenlink_native::adam_step(Tensor[] bufs, Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, "
+                            "Tensor state, float lr, float beta1, float beta2, float eps, float weight_decay) -> ()",
+               "auc_pair_counts": "disenlink_native::auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor"}
+    for name, want in schemas.items():
+        assert str(getattr(torch.ops.disenlink_native, name).default._schema) == want, name
     assert torch.ops.disenlink_native.abi_version() == _lib.load().dl_version().decode()
     with pytest.raises(RuntimeError, match="CUDA fp32"):
-        op(torch.zeros(3, 2, 8), 0, 0, 0, 0.5, 1.0, torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1))
+        op(torch.zeros(3, 2, 8), 0, 0, 0, 0.5, 1.0, torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), 0)
