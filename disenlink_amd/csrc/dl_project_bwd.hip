@@ -48,6 +48,21 @@ constexpr int bwd_ht(int D) { return D <= 64 ? 2 : 1; }
 // reads along the node axis is written (zeros past N and past nhid).
 struct DhidPlanes { __bf16* base; size_t batch; int ncb; };       // factor k at base + k * batch; ncb 16-node chunks per row block
 
+// -DDL_PROJA_STAMPS=<workgroup index>: DIAGNOSTIC build (like DL_PROJ_STAMPS in dl_project.hip): s_memtime at the phase
+// boundaries of every node tile, waves 0 and 4 of one workgroup; read back by dl_debug_read_stamps_a.
+#ifdef DL_PROJA_STAMPS
+__device__ unsigned long long dl_proja_stamps[2][512];
+#define DLA_STAMP(code)                                                                                 \
+    do {                                                                                                \
+        if (stamp_on && stamp_n < 510) {                                                                \
+            dl_proja_stamps[stamp_w][stamp_n++] = ((unsigned long long)(code) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); \
+            dl_proja_stamps[stamp_w][511] = stamp_n;                                                    \
+        }                                                                                               \
+    } while (0)
+#else
+#define DLA_STAMP(code) do {} while (0)
+#endif
+
 template <int D, bool VEC, bool RECOMPUTE, bool PLANES>
 __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     const float* __restrict__ x, int N, int F, int nhid, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -78,11 +93,31 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     const int nfc = RECOMPUTE ? (F + BFC - 1) / BFC : 1;
     const int steps = my_tiles * nfc;
     const int hw0 = hc * HB + wh * 32 * HT;        // first hidden unit of this wave
+#ifdef DL_PROJA_STAMPS
+    const bool stamp_on = (int)blockIdx.x == DL_PROJA_STAMPS && (wave == 0 || wave == 4) && lane == 0;
+    const int stamp_w = wave >> 2;
+    int stamp_n = 0;
+#endif
+    DLA_STAMP(1);
 
-    for (int i = tid; i < HB * D; i += BTHR) {     // W2^T chunk: w2t[h][dd] = W2_k[dd][hc*HB + h]
-        const int dd = i / HB, h = i - dd * HB;
-        const int hh = hc * HB + h;
-        w2t[h * LDZ + dd] = hh < nhid ? W2k[(size_t)dd * nhid + hh] : 0.0f;
+    {   // W2^T chunk: w2t[h][dd] = W2_k[dd][hc*HB + h].  All loads first, then the LDS stores: written as one loop the
+        // compiler waited for every load before its store — 16 global round trips in a row, 16,000 cycles of a workgroup's
+        // 183,000 (stamps, tools/proja_stamps.py).
+        constexpr int NW = HB * D / BTHR;
+        static_assert(HB * D % BTHR == 0, "the W2^T chunk divides over the workgroup");
+        float wv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + j * BTHR, dd = i / HB, h = i - dd * HB;
+            const int hh = hc * HB + h;
+            wv[j] = W2k[(size_t)dd * nhid + (hh < nhid ? hh : 0)];
+            wv[j] = hh < nhid ? wv[j] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + j * BTHR, dd = i / HB, h = i - dd * HB;
+            w2t[h * LDZ + dd] = wv[j];
+        }
     }
     float b1v[HT];
 #pragma unroll
@@ -184,9 +219,12 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
         }
         }   // RECOMPUTE
         if (last) {
+            DLA_STAMP(10);
             // every wave is past the previous tile's use of dzs (barrier at the end of that step)
             zt.template stash<LDZ>(dzs, tid);
+            DLA_STAMP(11);
             __syncthreads();
+            DLA_STAMP(12);
             float hid[HT][16];
             unsigned relu_bits[HT];                             // bit r: hid[ht][r] > 0 (the mask of the dhid epilogue)
 #pragma unroll
@@ -214,6 +252,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
             }
             // kept form: the next tile's dZ rows and hidden quads are fetched behind this tile's MFMAs (unconditional —
             // the last tile is fetched twice — see project2_fwd_kernel)
+            DLA_STAMP(13);
             const int n0n = (tile0 + min(tl + 1, my_tiles - 1)) * TILE_N;
             if constexpr (!RECOMPUTE) zt.fetch(dZk + (size_t)n0n * K * D, K * D, N - n0n, D, tid);
             // dW2[dd][hidden] += dZ[node][dd] . hid[node][hidden]: the k-pair of register r is the node pair
@@ -228,6 +267,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
                     for (int ht = 0; ht < HT; ++ht) DL_MFMA(w2acc[dt][ht], zv[r], hid[ht][r]);
             }
+            DLA_STAMP(14);
             if constexpr (!RECOMPUTE) load_hq(n0n);             // hid has been consumed by the MFMAs above
             // dhid[node][hidden] = dZ[node][dd] . W2^T[hidden][dd], masked by the ReLU
 #pragma unroll
@@ -249,6 +289,7 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
                 for (int ht = 0; ht < HT; ++ht) DL_MFMA(hacc[ht], zq.w, vq[ht].w);
             }
+            DLA_STAMP(15);
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht) {
                 const int h = hw0 + ht * 32 + li;
@@ -300,8 +341,10 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
                 b1acc[ht] += colsum;
                 zero_acc(hacc[ht]);
             }
+            DLA_STAMP(16);
         }
         __syncthreads();
+        DLA_STAMP(17);
     }
     // cross-wave reduction (fixed order over the 4 node quarters) of the dW2 / db1 partials of this range
     constexpr int RW = DT * HT * 16 + HT;                       // floats per lane and wave
@@ -630,6 +673,14 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
 }
 
 }  // namespace project
+
+#ifdef DL_PROJA_STAMPS
+}  // namespace dl
+extern "C" int dl_debug_read_stamps_a(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dl::project::dl_proja_stamps), sizeof(unsigned long long) * 2 * 512);
+}
+namespace dl {
+#endif
 
 size_t project_bwd_workspace_bytes(int N, int F, int K, int nhid, int d, bool two_layer) {
     if (N <= 0) return 0;

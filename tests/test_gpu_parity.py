@@ -1760,6 +1760,30 @@ def test_one_pass_training_scorer_matches_the_oracle_directly(K, d, dtype, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K,d,dtype", [(8, 64, torch.float32), (16, 128, torch.bfloat16), (16, 128, torch.float32), (4, 32, torch.float32)])
+def test_one_pass_training_scorer_is_independent_of_the_row_sharding(K, d, dtype):
+    """dl_score_pairs_train over the incidence rows of a row SHARD (what a rank of the sharded training step runs) gives
+    that shard's rows of dZ / dH and the scores of the pairs touching it bit for bit as the unsharded call: every kernel
+    family sums a node's entries in an order that depends on the row alone (ascending entries per lane; units summed in
+    segment order, or — the wide kernel — as the tree (s0 + s1) + (s2 + s3) of the row's own segments)."""
+    from disenlink_amd import ops
+    from disenlink_amd.graph import PairList
+    G, pairs, Z, label, weight, pu, pv = _one_pass_case(K, d, dtype, seed=31 + K)
+    N = Z.shape[0]
+    Zt = Z if dtype == torch.float32 else Z.to(dtype)
+    H = ops.aggregate_fwd(G, Zt, 0.6, *ops.route_fwd(G, Zt, 1.0))
+    prob, dZ, dH = ops.score_pairs_train(Zt, H, pairs, 1.0, label, weight)
+    tpu, tpv = torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV)
+    wb = 4 if dtype == torch.float32 else 2
+    for lo, hi in ((0, 3), (3, 4), (4, 301), (301, N)):                # node 3 (several segments' worth of pairs) alone in a shard
+        inc = PairList.build(tpu, tpv, N, row_range=(lo, hi), build_by_u=False, row_bytes=K * d * wb)
+        prob_s, dZ_s, dH_s = ops.score_pairs_train(Zt, H, inc, 1.0, label, weight)
+        assert torch.equal(dZ_s[lo:hi], dZ[lo:hi]) and torch.equal(dH_s[lo:hi], dH[lo:hi]), (lo, hi)
+        touch = torch.from_numpy(((pu >= lo) & (pu < hi)) | ((pv >= lo) & (pv < hi))).to(DEV)
+        assert torch.equal(prob_s[touch], prob[touch]), (lo, hi)
+
+
+@pytest.mark.gpu
 def test_compiled_projection_adam_auc_and_bf16_hot_path_equal_the_python_operators_bit_for_bit(monkeypatch):
     """Round 5: the rest of the training step behind the compiled binding (csrc/torch/dl_torch.cpp) — the projection over
     the module's shared buffers (forward, the four stacked gradients), the Adam step, the AUC counts, and the hot path with
