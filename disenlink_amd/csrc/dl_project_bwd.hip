@@ -48,6 +48,10 @@ constexpr int bwd_ht(int D) { return D <= 64 ? 2 : 1; }
 // reads along the node axis is written (zeros past N and past nhid).
 struct DhidPlanes { __bf16* base; size_t batch; int ncb; };       // factor k at base + k * batch; ncb 16-node chunks per row block
 
+#ifndef DL_BWD_A_BF16
+#define DL_BWD_A_BF16 1           // -DDL_BWD_A_BF16=0: kernel A's two products on fp32 MFMA (the round-2 form), for A/B runs
+#endif
+
 // -DDL_PROJA_STAMPS=<workgroup index>: DIAGNOSTIC build (like DL_PROJ_STAMPS in dl_project.hip): s_memtime at the phase
 // boundaries of every node tile, waves 0 and 4 of one workgroup; read back by dl_debug_read_stamps_a.
 #ifdef DL_PROJA_STAMPS
@@ -76,6 +80,16 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     float* w1s = xs + 2 * TILE_N * LDB;            // [2][HB][LDB]
     float* dzs = w1s + 2 * HB * LDB;               // [TILE_N][LDZ]   dZ_k rows of the current node tile
     float* w2t = dzs + TILE_N * LDZ;               // [HB][LDZ]       W2_k[:, chunk]^T, staged once
+    // BF (round 5; kept hidden layer, d <= 64): both products of a node tile — dW2 += dZ^T . hid and dhid = dZ . W2^T — on
+    // the bf16 matrix path from three bf16 planes per operand (dl_tiles.h: six exact products per term, fp32-grade) instead
+    // of fp32 MFMA: 96 MFMAs of 32 cycles per wave and tile instead of 128 of 64 (stamps, tools/proja_stamps.py: fp32 MFMA
+    // issue was 58 % of a tile).  dZ tile and W2^T chunk live in LDS as planes [3][rows][ZP]; the A operand of the node
+    // contraction (dZ^T: lane = dd, k-slots = 8 nodes) comes out of the [node][dd] image by the transposed LDS read
+    // ds_read_b64_tr_b16; its B operand is the hidden layer in registers, split in place (slot s of block b = register 8b + s).
+    constexpr bool BF = DL_BWD_A_BF16 && PLANES && !RECOMPUTE && D <= 64;
+    constexpr int ZP = D + 8;                      // plane row pitch (bf16): 16-byte rows reads conflict-free, 8-byte aligned
+    __bf16* dzp = reinterpret_cast<__bf16*>(lds);  // BF: [3][TILE_N][ZP]
+    __bf16* w2p = dzp + 3 * TILE_N * ZP;           //     [3][HB][ZP]      W2_k[:, chunk]^T as planes
     const int n_tiles = (N + TILE_N - 1) / TILE_N;
     const int nhc = (nhid + HB - 1) / HB;
     // a = node range (shares the x tiles), b = (hidden chunk, factor) (shares the W1 chunk): see xcd_item
@@ -116,7 +130,15 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int i = tid + j * BTHR, dd = i / HB, h = i - dd * HB;
-            w2t[h * LDZ + dd] = wv[j];
+            if constexpr (BF) {
+                __bf16 hi, mid, lo;
+                split3(wv[j], hi, mid, lo);
+                w2p[(0 * HB + h) * ZP + dd] = hi;
+                w2p[(1 * HB + h) * ZP + dd] = mid;
+                w2p[(2 * HB + h) * ZP + dd] = lo;
+            } else {
+                w2t[h * LDZ + dd] = wv[j];
+            }
         }
     }
     float b1v[HT];
@@ -221,7 +243,26 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
         if (last) {
             DLA_STAMP(10);
             // every wave is past the previous tile's use of dzs (barrier at the end of that step)
-            zt.template stash<LDZ>(dzs, tid);
+            if constexpr (BF) {                                 // the dZ tile as three bf16 planes [node][dd]
+                const bool full = zt.rows_valid >= TILE_N && zt.cols_valid >= D;
+#pragma unroll
+                for (int j = 0; j < zt.NV / 4; ++j) {
+                    const int i = tid + BTHR * j, r = i / (D / 4), c = 4 * (i % (D / 4));
+                    const unsigned m = (full || (r < zt.rows_valid && c < zt.cols_valid)) ? 0xFFFFFFFFu : 0u;
+                    bf16x4 p0, p1, p2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        __bf16 hi, mid, lo;
+                        split3(mask_bits(zt.v[4 * j + e], m), hi, mid, lo);
+                        p0[e] = hi; p1[e] = mid; p2[e] = lo;
+                    }
+                    *reinterpret_cast<bf16x4*>(dzp + (0 * TILE_N + r) * ZP + c) = p0;
+                    *reinterpret_cast<bf16x4*>(dzp + (1 * TILE_N + r) * ZP + c) = p1;
+                    *reinterpret_cast<bf16x4*>(dzp + (2 * TILE_N + r) * ZP + c) = p2;
+                }
+            } else {
+                zt.template stash<LDZ>(dzs, tid);
+            }
             DLA_STAMP(11);
             __syncthreads();
             DLA_STAMP(12);
@@ -257,6 +298,43 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
             if constexpr (!RECOMPUTE) zt.fetch(dZk + (size_t)n0n * K * D, K * D, N - n0n, D, tid);
             // dW2[dd][hidden] += dZ[node][dd] . hid[node][hidden]: the k-pair of register r is the node pair
             // {acc_row(r,0), acc_row(r,1)} of this quarter
+            if constexpr (BF) {
+                // B operand: the hidden layer split in place — registers 8b .. 8b+7 of lane half t are the nodes
+                // 16b + 8(s>>2) + 4t + (s&3), s = 0..7, of this node quarter: the 8 k-slots of K = 16 block b
+                bf16x8 hidp[HT][2][3];
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int s8 = 0; s8 < 8; ++s8) {
+                            __bf16 hi, mid, lo;
+                            split3(hid[ht][8 * b + s8], hi, mid, lo);
+                            hidp[ht][b][0][s8] = hi; hidp[ht][b][1][s8] = mid; hidp[ht][b][2][s8] = lo;
+                        }
+                // A operand: dZ^T[dd = dt*32 + li][those 8 nodes] by two transposed reads per plane (4 node rows x 16 dd
+                // columns per group of 16 lanes: lane 4q+p gives the address of row q, columns 4p..4p+3, and receives
+                // column (lane & 15) of the 4 rows).  Every lane is active here (the read needs EXEC all ones).
+                const int i16 = lane & 15, trq = i16 >> 2, trp = i16 & 3, cb = (li >> 4) * 16;
+                typedef short v4s __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        bf16x8 za[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const __bf16* a0 = dzp + (p * TILE_N + wn * 32 + 16 * b + 4 * half + trq) * ZP + dt * 32 + cb + 4 * trp;
+                            const v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)a0);
+                            const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a0 + 8 * ZP));
+                            typedef short v8s __attribute__((ext_vector_type(8)));
+                            const v8s both = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                            za[p] = __builtin_bit_cast(bf16x8, both);
+                        }
+#pragma unroll
+                        for (int ht = 0; ht < HT; ++ht) mfma_split6(w2acc[dt][ht], za, hidp[ht][b]);
+                    }
+            } else {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 float zv[16];
@@ -267,15 +345,31 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
 #pragma unroll
                     for (int ht = 0; ht < HT; ++ht) DL_MFMA(w2acc[dt][ht], zv[r], hid[ht][r]);
             }
+            }
             DLA_STAMP(14);
             if constexpr (!RECOMPUTE) load_hq(n0n);             // hid has been consumed by the MFMAs above
             // dhid[node][hidden] = dZ[node][dd] . W2^T[hidden][dd], masked by the ReLU
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht) zero_acc(hacc[ht]);
+            if constexpr (BF) {
+#pragma unroll
+                for (int b = 0; b < D / 16; ++b) {              // A = dZ rows of this node quarter, B = W2^T rows, planes from LDS
+                    bf16x8 za[3], vb[HT][3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        za[p] = *reinterpret_cast<const bf16x8*>(dzp + (p * TILE_N + wn * 32 + li) * ZP + 16 * b + 8 * half);
+#pragma unroll
+                        for (int ht = 0; ht < HT; ++ht)
+                            vb[ht][p] = *reinterpret_cast<const bf16x8*>(w2p + (p * HB + wh * 32 * HT + ht * 32 + li) * ZP + 16 * b + 8 * half);
+                    }
+#pragma unroll
+                    for (int ht = 0; ht < HT; ++ht) mfma_split6(hacc[ht], za, vb[ht]);
+                }
+            }
             const float* za = dzs + (wn * 32 + li) * LDZ + half * (D / 2);
             const float* va = w2t + (wh * 32 * HT + li) * LDZ + half * (D / 2);
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) {
+            for (int q = 0; q < (BF ? 0 : D / 8); ++q) {
                 const float4 zq = *reinterpret_cast<const float4*>(za + 4 * q);
                 float4 vq[HT];
 #pragma unroll
