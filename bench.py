@@ -756,12 +756,17 @@ def main():
                 "f32 results; products from three bf16 planes per operand (six exact bf16 MFMA products per term)",
                 "peak": FP32_MFMA_PEAK_TFLOPS, "bf16_peak": BF16_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s (fp32-equivalent against the fp32 matrix peak; bf16_pipe_* = issued bf16 MFMA flops, "
-                        "6 per fp32 flop, against the dense bf16 peak — an upper bound: kernel A of the backward and the "
-                        "recompute form's layer 1 still run fp32 MFMA)",
+                        "6 per fp32 flop, against the dense bf16 peak — an upper bound: the recompute form's kernel A (layer 1 "
+                        "again, dW2, dhid) still runs fp32 MFMA)",
                 "shape": {"N": N, "F": Fx, "K": K, "nhid": nh, "d": d},
                 "fwd": both(fl_f, t_f), "bwd": both(fl_b, t_b),
                 "fwd_keeping_hidden": {"avg_us": t_fk * 1e6},
-                "bwd_from_kept_hidden": both(fl_bk, t_bk)}
+                "bwd_from_kept_hidden": both(fl_bk, t_bk),
+                # what an epoch of the training loop runs at this shape (ops.keep_hidden: the forward keeps the hidden layer,
+                # the backward starts from it; round 5: kernel A of that backward on the bf16 matrix path too, d <= 64)
+                "training_loop": {"form": "kept hidden layer" if ops.keep_hidden(N, Fx, K, nh) else "recompute",
+                                  "fwd_us": (t_fk if ops.keep_hidden(N, Fx, K, nh) else t_f) * 1e6,
+                                  "bwd_us": (t_bk if ops.keep_hidden(N, Fx, K, nh) else t_b) * 1e6}}
 
     # extra: the dense [N,N] scorer of the drop-in forward (model.py:109-113 as written): Gram products on MFMA
     dense = None

@@ -51,6 +51,16 @@ struct DhidPlanes { __bf16* base; size_t batch; int ncb; };       // factor k at
 #ifndef DL_BWD_A_BF16
 #define DL_BWD_A_BF16 1           // -DDL_BWD_A_BF16=0: kernel A's two products on fp32 MFMA (the round-2 form), for A/B runs
 #endif
+#ifndef DL_BWD_A_BF16_MAXD
+#define DL_BWD_A_BF16_MAXD 128    // largest factor width that takes the bf16 path (its planes must fit the kernel's LDS)
+#endif
+// LDS bytes of kernel A (also used by its launcher below)
+constexpr size_t project2_bwd_lds_bytes(int D) {
+    const size_t ht = D <= 64 ? 2 : 1;
+    const size_t stage = 2 * 128 * (32 + 4) + 2 * 64 * ht * (32 + 4) + 128 * (size_t)(D + 4) + 64 * ht * (size_t)(D + 4);
+    const size_t red = 8 * (size_t)((D / 32) * ht * 16 + ht) * 64;
+    return sizeof(float) * (stage > red ? stage : red);
+}
 
 // -DDL_PROJA_STAMPS=<workgroup index>: DIAGNOSTIC build (like DL_PROJ_STAMPS in dl_project.hip): s_memtime at the phase
 // boundaries of every node tile, waves 0 and 4 of one workgroup; read back by dl_debug_read_stamps_a.
@@ -86,7 +96,8 @@ __global__ __launch_bounds__(BTHR) void project2_bwd_hidden_kernel(
     // issue was 58 % of a tile).  dZ tile and W2^T chunk live in LDS as planes [3][rows][ZP]; the A operand of the node
     // contraction (dZ^T: lane = dd, k-slots = 8 nodes) comes out of the [node][dd] image by the transposed LDS read
     // ds_read_b64_tr_b16; its B operand is the hidden layer in registers, split in place (slot s of block b = register 8b + s).
-    constexpr bool BF = DL_BWD_A_BF16 && PLANES && !RECOMPUTE && D <= 64;
+    constexpr bool BF = DL_BWD_A_BF16 && PLANES && !RECOMPUTE && D <= DL_BWD_A_BF16_MAXD;
+    static_assert(!BF || sizeof(__bf16) * 3 * (TILE_N + HB) * (D + 8) <= project2_bwd_lds_bytes(D), "planes of the dZ tile and the W2^T chunk fit the kernel's LDS");
     constexpr int ZP = D + 8;                      // plane row pitch (bf16): 16-byte rows reads conflict-free, 8-byte aligned
     __bf16* dzp = reinterpret_cast<__bf16*>(lds);  // BF: [3][TILE_N][ZP]
     __bf16* w2p = dzp + 3 * TILE_N * ZP;           //     [3][HB][ZP]      W2_k[:, chunk]^T as planes
