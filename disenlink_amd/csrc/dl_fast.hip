@@ -883,6 +883,9 @@ __global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl
         my_col = g.col[si.beg + lane];
         my_pair = pair_id[si.beg + lane];
     }
+#ifdef DL_EXP_SKIP_GATHER
+    Chunk<VEC> exp_h[KBP], exp_z[KBP];
+#endif
     for (int base = si.beg; base < si.end; base += EPW) {
         const int it = base + grp;
         const bool live = it < si.end;
@@ -893,6 +896,27 @@ __global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl
 #pragma unroll
         for (int b0 = 0; b0 < K; b0 += KB) {
             float pq[KBP], ps[KBP];
+#ifdef DL_EXP_SKIP_GATHER     // TIMING EXPERIMENT ONLY (wrong results): 2 of every 5 iterations re-use the rows gathered before — would
+            // the kernel speed up in proportion if fewer rows had to be gathered (rows shared between the pairs of a u block)?
+            Chunk<VEC> hx[KBP], zx[KBP];
+            if (K > 8 || ((base - si.beg) / EPW) % 5 < 3 || base == si.beg) {
+#pragma unroll
+                for (int k = 0; k < KBP; ++k) {
+                    const int kk = (k < KB && b0 + k < K) ? b0 + k : 0;
+                    exp_h[k] = Tab<T>::load(H + v * ROW + kk * D + c * VEC);
+                    exp_z[k] = Tab<T>::load(Z + v * ROW + kk * D + c * VEC);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KBP; ++k) { hx[k] = exp_h[k]; zx[k] = exp_z[k]; }
+#pragma unroll
+            for (int k = 0; k < KBP; ++k) {
+                const bool in = k < KB && b0 + k < K;
+                const int kk = in ? b0 + k : 0;
+                pq[k] = in ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), hx[k]) : 0.0f;
+                ps[k] = in ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), zx[k]) : 0.0f;
+            }
+#else
 #pragma unroll
             for (int k = 0; k < KBP; ++k) {
                 const bool in = k < KB && b0 + k < K;
@@ -900,6 +924,7 @@ __global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl
                 pq[k] = in ? dot(load_f32<VEC>(&urow[wave][ROW + kk * D + c * VEC]), Tab<T>::load(H + v * ROW + kk * D + c * VEC)) : 0.0f;
                 ps[k] = in ? dot(load_f32<VEC>(&urow[wave][kk * D + c * VEC]), Tab<T>::load(Z + v * ROW + kk * D + c * VEC)) : 0.0f;
             }
+#endif
             TransposedReduce<KBP, G / 2>::run(pq, c);
             TransposedReduce<KBP, G / 2>::run(ps, c);
 #pragma unroll
