@@ -104,6 +104,11 @@ struct W2Stage {
         }
     }
 };
+#ifndef DL_PROJ_STAGGER
+#define DL_PROJ_STAGGER 0         // 1: waves 4..7 of the forward stage before their first MFMA block — measured SLOWER (same box: 90.7 ->
+                                  // 95.4 us at the bench shape, 675 -> 748 at F = 2,088, 845 -> 868 at d = 128): the staging under a wave-uniform
+                                  // branch costs more than the overlap buys; kept for the record
+#endif
 #ifndef DL_W2_LDS
 #define DL_W2_LDS 1               // -DDL_W2_LDS=0: the W2 operand straight from global memory (the round-2 form), for A/B runs
 #endif
@@ -301,31 +306,46 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
                     a0[kb][p] = *reinterpret_cast<const bf16x8*>(wb + p * TH * SPLIT_PITCH + kb * 16);
                     a1[kb][p] = *reinterpret_cast<const bf16x8*>(wb + (p * TH + 32) * SPLIT_PITCH + kb * 16);
                 }
+            // the step's staging work: tile s+1 to LDS, then the requests that must come behind that stash
+            auto stage_work = [&]() {
+                if (s + 1 < steps) stash(s + 1);
+                // behind the stash (see the top of the step): the chunk's 128 biases — one float per thread of the first two
+                // waves, a step ahead of their use — and, in the chunk's last step, the W2 operand of layer 2
+                if (nfc >= 2 && fc == nfc - 2 && tid < TH) {
+                    const int h = hc * TH + tid;
+                    bias_q = b1k[h < nhid ? h : 0];
+                    bias_q = h < nhid ? bias_q : 0.0f;
+                }
+                if (last) {
+                    if constexpr (W2LDS) {
+                        w2st.fetch(P.w2, P.w2_ps, (size_t)k * D, P.nhid_p, hc * TH, tid);  // coalesced; lands under the rest of the step
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < W2PF; ++q) load_w2p(w2a[q], q);
+                    }
+                }
+                // unconditional (the last steps fetch the last tile again): a fetch under a condition makes the
+                // registers a merge of old and new values, and hipcc then waits for the loads right here to copy them
+                DL_STAMP(13);
+                fetch(min(s + 2, steps - 1));
+                DL_STAMP(14);
+            };
+#if DL_PROJ_STAGGER
+            // The two waves of a SIMD (w and w + 4) run the same program between the same barriers: in lockstep both stage
+            // at the same time and the matrix pipe idles meanwhile.  Waves 4..7 stage BEFORE their first MFMA block, waves
+            // 0..3 behind it: one wave's MFMAs run beside its SIMD partner's LDS stores and global requests.
+            const bool early = __builtin_amdgcn_readfirstlane(wave) >= 4;
+            if (early) stage_work();
+#endif
             DL_STAMP(11);
             mfma_split6(hacc[0], a0[0], b[0]);
             mfma_split6(hacc[1], a1[0], b[0]);
             DL_STAMP(12);
-            if (s + 1 < steps) stash(s + 1);
-            // behind the stash (see the top of the step): the chunk's 128 biases — one float per thread of the first two
-            // waves, a step ahead of their use — and, in the chunk's last step, the W2 operand of layer 2
-            if (nfc >= 2 && fc == nfc - 2 && tid < TH) {
-                const int h = hc * TH + tid;
-                bias_q = b1k[h < nhid ? h : 0];
-                bias_q = h < nhid ? bias_q : 0.0f;
-            }
-            if (last) {
-                if constexpr (W2LDS) {
-                    w2st.fetch(P.w2, P.w2_ps, (size_t)k * D, P.nhid_p, hc * TH, tid);      // coalesced; lands under the rest of the step
-                } else {
-#pragma unroll
-                    for (int q = 0; q < W2PF; ++q) load_w2p(w2a[q], q);
-                }
-            }
-            // unconditional (the last steps fetch the last tile again): a fetch under a condition makes the
-            // registers a merge of old and new values, and hipcc then waits for the loads right here to copy them
-            DL_STAMP(13);
-            fetch(min(s + 2, steps - 1));
-            DL_STAMP(14);
+#if DL_PROJ_STAGGER
+            if (!early) stage_work();
+#else
+            stage_work();
+#endif
             mfma_split6(hacc[0], a0[1], b[1]);
             mfma_split6(hacc[1], a1[1], b[1]);
             DL_STAMP(15);
