@@ -78,6 +78,8 @@ CASES = [
     ("k3_d8_hub", 80, 8, 3,  8,   4, 0.9, 2, 1.0, 0.05, (1,), (2,), 3, 1),
     ("k5_d64",   56, 20, 5, 64,  24, 0.8, 1, 0.3, 0.10, (), (0,), None, 5),
     ("k8_d64",   72, 32, 8, 64,  48, 0.5, 1, 0.25, 0.09, (4,), (8, 9), 6, 5),
+    # round 5: the factor shape of BASELINE configs[4] (Penn94: K = 16, d = 128) — the wide kernels against the reference itself
+    ("k16_d128", 44, 24, 16, 128, 128, 0.6, 1, 0.3, 0.12, (5,), (7,), 2, 5),
 ]
 
 
@@ -154,6 +156,7 @@ TRAJ = [
     # round 5: the benchmark's factor shape (K=8, d=64) at temperature 2 — the `/ t` of model.py:56 inside the one-pass
     # training scorer (its T1 = false instantiation) pinned by a training trajectory of the reference
     ("traj_k8_d64_t2", 140, 16, 8, 64, 32, 0.6, 2, 0.5, 0.05, 5, 8, 5e-3),
+    ("traj_k16_d128", 100, 16, 16, 128, 128, 0.6, 1, 0.3, 0.06, 5, 6, 5e-3),
 ]
 
 
@@ -283,6 +286,12 @@ def main():
     import model as model_mod  # the reference's model.py
     torch.set_num_threads(1)
     only_traj = "--trajectories-only" in sys.argv or "--adam-only" in sys.argv   # the case_* / auc_* files are already committed
+    only_case = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only-case=")]      # --only-case=k16_d128: one case
+    if only_case:
+        for idx, spec in enumerate(CASES):
+            if spec[0] in only_case:
+                run_case(model_mod, spec, seed=100 + idx)
+        return
     if not only_traj:
         for idx, spec in enumerate(CASES):
             run_case(model_mod, spec, seed=100 + idx)

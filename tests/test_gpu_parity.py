@@ -1910,11 +1910,14 @@ def test_compiled_binding_and_python_operator_agree_at_temperature_2_and_with_a_
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("native_ops", ["1", "0"])
-def test_pair_list_training_with_the_one_pass_scorer_follows_the_reference_trajectory_at_t2(native_ops, monkeypatch):
+@pytest.mark.parametrize("fixture,shape", [("traj_k8_d64_t2", (8, 64, 2)), ("traj_k16_d128", (16, 128, 1))])
+def test_pair_list_training_with_the_one_pass_scorer_follows_the_reference_trajectory_at_t2(fixture, shape, native_ops,
+                                                                                            monkeypatch):
     """tests/golden/traj_k8_d64_t2.npz — the REFERENCE model trained 8 epochs at K = 8, d = 64, temperature 2 under the
     reference's schedule — followed by the pair-list training loop (forward_pairs_loss: route, aggregate, the one-pass
     training scorer's wave kernel with T1 = false, Adam, AUC), through the compiled binding and through the Python
-    operators: per-epoch loss and validation AUC, test AUC with the best weights."""
+    operators: per-epoch loss and validation AUC, test AUC with the best weights.  traj_k16_d128.npz: the same at the
+    factor shape of BASELINE configs[4] (K = 16, d = 128: score_train_wide_kernel and the d = 128 projection kernels)."""
     import sys, os
     from conftest import load_trajectory
     from disenlink_amd import native
@@ -1926,9 +1929,9 @@ def test_pair_list_training_with_the_one_pass_scorer_follows_the_reference_traje
     monkeypatch.setenv("DL_ONE_PASS_SCORER", "1")
     native._state["loaded"] = None                                    # re-read DL_NATIVE_OPS
     try:
-        g = load_trajectory("traj_k8_d64_t2")
+        g = load_trajectory(fixture)
         m = g["meta"]
-        assert (m["K"], m["d"], m["t"]) == (8, 64, 2)
+        assert (m["K"], m["d"], m["t"]) == shape
         model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
         model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")})
         model = model.to(DEV)
