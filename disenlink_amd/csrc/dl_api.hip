@@ -310,6 +310,30 @@ int dl_auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, co
     return auc_pair_counts(score, pos_idx, n_pos, neg_idx, n_neg, u2, (hipStream_t)stream);
 }
 
+int dl_auc_pair_counts_add(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
+                           unsigned long long* u2, void* stream) {
+    DL_REQUIRE(n_pos >= 0 && n_neg >= 0, "negative size");
+    DL_REQUIRE(u2 != nullptr, "u2 is NULL");
+    DL_REQUIRE(auc_counts_supported(n_pos, n_neg), "n_pos * n_neg too large for the slice-and-search form (%d x %d)",
+               n_pos, n_neg);
+    if (n_pos > 0 && n_neg > 0) DL_REQUIRE(score && pos_idx && neg_idx, "NULL argument");
+    return auc_pair_counts(score, pos_idx, n_pos, neg_idx, n_neg, u2, (hipStream_t)stream, /*clear=*/false);
+}
+
+size_t dl_epoch_state_bytes(void) { return epoch_state_bytes(); }
+
+int dl_epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
+                    unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs,
+                    long long patience, void* stream) {
+    DL_REQUIRE(n_bufs >= 0 && n_bufs <= DL_ADAM_MAX_BUFS, "n_bufs=%d outside 0..%d", n_bufs, DL_ADAM_MAX_BUFS);
+    DL_REQUIRE(loss && u2 && state, "loss / u2 / state is NULL");
+    DL_REQUIRE(max_epochs >= 0 && (max_epochs == 0 || hist != nullptr), "hist is NULL");
+    DL_REQUIRE(patience >= 0, "negative patience");
+    if (n_bufs > 0) DL_REQUIRE(params && best && numel, "NULL argument");
+    for (int i = 0; i < n_bufs; ++i) DL_REQUIRE(numel[i] == 0 || (params[i] && best[i]), "buffer %d: NULL pointer", i);
+    return epoch_finish(n_bufs, params, best, numel, loss, u2, denom2, state, hist, max_epochs, patience, (hipStream_t)stream);
+}
+
 int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g, void* ws,
                 size_t ws_bytes, void* stream) {
     DL_REQUIRE(n_pairs >= 0, "negative size");

@@ -59,8 +59,12 @@ int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, 
 // tie-averaged AUC counts (dl_metrics.hip)
 bool auc_counts_supported(int n_pos, int n_neg);           // the smaller class fits the LDS
 int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
-                    unsigned long long* u2, hipStream_t st);
+                    unsigned long long* u2, hipStream_t st, bool clear = true);
 
+size_t epoch_state_bytes();
+int epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
+                 unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs, long long patience,
+                 hipStream_t st);
 int adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
               const size_t* numel, float* state, double lr, double beta1, double beta2, double eps, double weight_decay,
               hipStream_t st);

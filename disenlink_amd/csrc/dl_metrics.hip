@@ -83,8 +83,10 @@ bool auc_counts_supported(int n_pos, int n_neg) {
 }
 
 int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
-                    unsigned long long* u2, hipStream_t st) {
-    if (hipMemsetAsync(u2, 0, sizeof(unsigned long long), st) != hipSuccess) return check_launch("auc_pair_counts(memset)");
+                    unsigned long long* u2, hipStream_t st, bool clear) {
+    // clear = false: the counts are ADDED to *u2 (the caller keeps it at zero between evaluations: dl_epoch_finish reads
+    // and clears it in its own launch — no memset node in the epoch)
+    if (clear && hipMemsetAsync(u2, 0, sizeof(unsigned long long), st) != hipSuccess) return check_launch("auc_pair_counts(memset)");
     if (n_pos == 0 || n_neg == 0) return DL_OK;
     const bool small_is_pos = n_pos <= n_neg;
     const int n_small = small_is_pos ? n_pos : n_neg, n_large = small_is_pos ? n_neg : n_pos;
@@ -177,6 +179,107 @@ int adam_step(int n_bufs, float* const* params, const float* const* grads, float
         hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)((run + 255) / 256)), dim3(256), 0, st, b, (const float*)state,
                            (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     return check_launch("adam_step");
+}
+
+}  // namespace dl
+
+// ---------------------------------------------------------------------------- end of an epoch (main_disentangled.py:199-214)
+// The reference reads the loss and the validation AUC on the host every epoch, compares the AUC with the best one so far,
+// deep-copies the state_dict when it improved and counts the epochs since (patience).  Done that way the GPU idles from
+// the read-back until the host has launched the next epoch's first kernel (74 us of a 940 us epoch on the squirrel-shaped
+// graph, profiles/r5z_epoch_sequence.txt) and torch's scalar glue adds five launches.  Here the bookkeeping lives on the
+// device, in ONE launch at the end of the epoch:
+//   auc = u2 / denom2 (double, correctly rounded: the same value the host formed);  improved = !stopped && auc > best_auc
+//   improved: the parameter buffers are copied to the best-weights buffers (state AFTER the step, like :209), stale = 0;
+//   else stale += 1;  stale > patience: stopped = 1 — from then on the launch changes nothing (the host, which reads the
+//   history one epoch behind, may have queued an epoch or two more: they must not touch the best weights);
+//   hist[epoch] = (loss, auc);  *u2 = 0 for the next evaluation.
+// Every workgroup takes its decision from the state as the previous launch left it; the LAST workgroup to finish (a
+// counter in the state) writes the new state, so no workgroup can read a half-updated one.
+namespace dl {
+
+struct SnapBufs {
+    const float* src[DL_ADAM_MAX_BUFS];
+    float* dst[DL_ADAM_MAX_BUFS];
+    unsigned long long n4_end[DL_ADAM_MAX_BUFS];
+    unsigned long long n[DL_ADAM_MAX_BUFS];
+    int count;
+};
+
+struct EpochState {                 // dl_epoch_state_bytes() = sizeof; zero-initialised by the caller
+    double best_auc;
+    long long stale, epoch, stopped, best_epoch;
+    unsigned int blocks_done, pad;
+};
+static_assert(sizeof(EpochState) == 48, "layout documented in include/disenlink_hip.h");
+
+__global__ __launch_bounds__(256) void epoch_finish_kernel(SnapBufs b, const float* __restrict__ loss, unsigned long long* u2,
+                                                           double denom2, EpochState* st, double* __restrict__ hist,
+                                                           long long max_epochs, long long patience) {
+    const unsigned long long cnt = *reinterpret_cast<volatile unsigned long long*>(u2);
+    const double auc = denom2 > 0.0 ? (double)cnt / denom2 : (double)NAN;
+    const bool stopped = *reinterpret_cast<volatile long long*>(&st->stopped) != 0;
+    const bool improved = !stopped && auc > *reinterpret_cast<volatile double*>(&st->best_auc);
+    if (improved) {
+        const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+        int i = 0;
+        while (i < b.count && q >= b.n4_end[i]) ++i;
+        if (i < b.count) {
+            const unsigned long long e0 = (q - (i ? b.n4_end[i - 1] : 0ull)) * 4;
+            const float* __restrict__ s = b.src[i];
+            float* __restrict__ d = b.dst[i];
+            if (e0 + 4 <= b.n[i] && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+                *reinterpret_cast<float4*>(d + e0) = *reinterpret_cast<const float4*>(s + e0);
+            } else {
+                for (unsigned long long e = e0; e < e0 + 4 && e < b.n[i]; ++e) d[e] = s[e];
+            }
+        }
+    }
+    __syncthreads();                                            // every read of the old state by this workgroup is done
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&st->blocks_done, 1u) == gridDim.x - 1) { // the last one: nobody reads the state any more
+            __threadfence();
+            st->blocks_done = 0;
+            if (!stopped) {
+                const long long e = st->epoch;
+                if (e < max_epochs) {
+                    hist[2 * e] = (double)loss[0];
+                    hist[2 * e + 1] = auc;
+                }
+                if (improved) {
+                    st->best_auc = auc;
+                    st->stale = 0;
+                    st->best_epoch = e;
+                } else {
+                    st->stale += 1;
+                }
+                if (st->stale > patience) st->stopped = 1;
+                st->epoch = e + 1;
+            }
+            *u2 = 0;
+        }
+    }
+}
+
+size_t epoch_state_bytes() { return sizeof(EpochState); }
+
+int epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
+                 unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs, long long patience,
+                 hipStream_t st) {
+    SnapBufs b;
+    unsigned long long run = 0;
+    for (int i = 0; i < n_bufs; ++i) {
+        b.src[i] = params[i]; b.dst[i] = best[i];
+        b.n[i] = numel[i];
+        run += (numel[i] + 3) / 4;
+        b.n4_end[i] = run;
+    }
+    b.count = n_bufs;
+    const unsigned blocks = (unsigned)std::max<unsigned long long>(1, (run + 255) / 256);
+    hipLaunchKernelGGL(epoch_finish_kernel, dim3(blocks), dim3(256), 0, st, b, loss, u2, denom2,
+                       reinterpret_cast<EpochState*>(state), hist, max_epochs, patience);
+    return check_launch("epoch_finish");
 }
 
 }  // namespace dl

@@ -104,13 +104,15 @@ def _loss_vectors(run, device):
     return label, weight
 
 
-def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
+def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all, es_factory=None):
     """Capture one full epoch (forward, fused loss, backward, Adam step, validation AUC) into a HIP graph:
     every launch of the epoch — ours and torch's — is replayed with one host call, which removes the
     launch-bound host time of small graphs.  Returns (replay, out) with out = [loss, auc] on the device."""
     opt = _make_adam(model, True, lr, weight_decay, capturable=True)
     out = torch.zeros(2, dtype=torch.float64, device=x.device)
     val_plan = AucPlan(run.label_val)
+    seed = torch.ones((), dtype=torch.float32, device=x.device)
+    es = es_factory(val_plan) if es_factory is not None else None   # early_stop.DeviceEarlyStop or None
 
     def epoch():
         prob, loss = _scores_and_loss(model, x, run, label_all, weight_all)
@@ -118,10 +120,13 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
         # replays find them at the same addresses (torch's whole-network capture recipe).  Keeping pre-allocated
         # gradients instead (zero_grad(set_to_none=False)) cost 4K fills and 4K accumulating adds per epoch.
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(seed)
         opt.step()
-        out[0] = loss.detach().double()
-        out[1] = val_plan.auc(prob[b:])
+        if es is not None:
+            es.finish(loss, prob[b:])                               # device-side bookkeeping (early_stop.py): no `out`
+        else:
+            out[0] = loss.detach().double()
+            out[1] = val_plan.auc(prob[b:])
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -145,6 +150,8 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
         for v in st.values():
             if torch.is_tensor(v):
                 v.zero_()
+    if es is not None:
+        es.reset()                                                  # ... and the warm-up / capture epochs' bookkeeping
     # A captured graph replays raw addresses: every tensor its kernels touch that was NOT allocated during the capture
     # must outlive the graph.  The optimiser (moments, step counters) and the AUC index sets are created here, so they
     # are handed back for the caller to hold for as long as it replays (dropping them frees memory the graph still
@@ -153,7 +160,8 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all):
     # cached per source tensor, and held here as well so that nothing but the end of this run can free it
     # ... and the persistent bf16 planes of x and x^T the projection reads (ops._XPlanes: built by the second warm-up epoch)
     from .ops import padded_features, xplanes_for
-    return graph.replay, out, (graph, opt, val_plan, epoch, label_all, weight_all, x, padded_features(x), xplanes_for(x))
+    return graph.replay, (es if es is not None else out), (graph, opt, val_plan, epoch, label_all, weight_all, x,
+                                                           padded_features(x), xplanes_for(x), seed, es)
 
 
 def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 2000, lr: float = 1e-4,
@@ -176,6 +184,28 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
     fused = x.is_cuda                                               # fused loss+gradient kernel on the GPU path
     if fused:
         label_all, weight_all = _loss_vectors(run, x.device)
+    from .early_stop import DeviceEarlyStop, drive
+    if fused and DeviceEarlyStop.usable(model, x, val_plan):
+        # early stopping and the best-weights snapshot on the device, the history read one epoch behind the launches:
+        # the GPU never waits for the host between epochs (early_stop.py)
+        es = DeviceEarlyStop(model, val_plan, epochs, patience)
+        seed = torch.ones((), dtype=torch.float32, device=x.device)  # d loss / d loss, made once instead of a fill per epoch
+
+        def launch_epoch(_epoch):
+            model.train()
+            prob, loss = _scores_and_loss(model, x, run, label_all, weight_all)
+            opt.zero_grad()
+            loss.backward(seed)
+            opt.step()
+            model.eval()
+            es.finish(loss, prob[b:])                               # AUC from the pre-step forward (:202-204), weights after the step (:209)
+
+        res.best_val_auc = drive(es, epochs, patience, launch_epoch, res, log)
+        es.restore()
+        with torch.no_grad():
+            _emb, prob = model.forward_pairs(x, run.graph, run.test_pairs)
+        res.test_auc = float(auc_tie_avg(run.label_test, prob, check=False))
+        return res
     for epoch in range(epochs):
         model.train()
         if fused:
@@ -215,10 +245,22 @@ def _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log) -> RunR
             raise ValueError("AUC undefined with one class")
     b = run.n_pos + run.n_neg
     label_all, weight_all = _loss_vectors(run, x.device)
-    replay, out, keep_alive = _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all)
+    from .early_stop import DeviceEarlyStop, drive
+    factory = lambda plan: DeviceEarlyStop(model, plan, epochs, patience) if DeviceEarlyStop.usable(model, x, plan) else None
+    replay, out, keep_alive = _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all, factory)
+    res = RunResult(float("nan"), 0.0, 0)
+    if isinstance(out, DeviceEarlyStop):
+        es = out
+        res.best_val_auc = drive(es, epochs, patience, lambda _epoch: replay(), res, log)
+        torch.cuda.synchronize()
+        del replay, keep_alive                                      # only now may the graph's external tensors go
+        es.restore()
+        with torch.no_grad():
+            _emb, prob = model.forward_pairs(x, run.graph, run.test_pairs)
+        res.test_auc = float(auc_tie_avg(run.label_test, prob, check=False))
+        return res
     snapshot = getattr(model, "snapshot_state", None) or (lambda: deepcopy(model.state_dict()))
     best_auc, stale, weights = 0.0, 0, snapshot()
-    res = RunResult(float("nan"), 0.0, 0)
     for epoch in range(epochs):
         replay()
         loss_v, auc = out.tolist()                                  # the one sync of the epoch

@@ -288,6 +288,26 @@ int dl_score_allpairs_bwd(const void* Z, const void* H, int N, int K, int d, dl_
 int dl_auc_pair_counts_supported(int n_pos, int n_neg);
 int dl_auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
                        unsigned long long* u2, void* stream);
+/* The same, ADDING the counts to *u2 instead of overwriting it (no memset in front of the launch): for a caller that keeps
+ * *u2 at zero between evaluations — dl_epoch_finish reads and clears it. */
+int dl_auc_pair_counts_add(const float* score, const int64_t* pos_idx, int n_pos, const int64_t* neg_idx, int n_neg,
+                           unsigned long long* u2, void* stream);
+
+/* End-of-epoch bookkeeping of the training loop ON THE DEVICE (main_disentangled.py:199-214: loss and validation AUC of
+ * the epoch, `if auc > best_auc: best_auc = auc; weights = deepcopy(state_dict); stale = 0 else stale += 1`, patience), in
+ * one launch, so that the host need not read anything back before it launches the next epoch:
+ *   auc = *u2 / denom2 in double (u2 = the counts of dl_auc_pair_counts[_add], denom2 = 2 n_pos n_neg; NaN if denom2 <= 0);
+ *   if !stopped && auc > best_auc: best[i][:] = params[i][:] for the n_bufs <= DL_ADAM_MAX_BUFS buffers (numel[i] floats
+ *   each: the weights AFTER the step, like :209), best_auc = auc, stale = 0, best_epoch = epoch;  else stale += 1;
+ *   hist[2 epoch] = loss[0], hist[2 epoch + 1] = auc (epoch < max_epochs);  epoch += 1;  stale > patience: stopped = 1;
+ *   *u2 = 0.  Once stopped the call changes nothing but *u2 = 0 (epochs the host queued before it saw the stop).
+ * state: dl_epoch_state_bytes() bytes owned by the caller, zero-initialised once (best_auc = 0 as at :189):
+ *   { double best_auc; int64 stale, epoch, stopped, best_epoch; uint32 internal[2]; }
+ * params / best / numel: HOST arrays like dl_adam_step's; loss, u2, hist, state: device memory. */
+size_t dl_epoch_state_bytes(void);
+int dl_epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
+                    unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs,
+                    long long patience, void* stream);
 
 /* Pair-list loss of main_disentangled.py:195 and its gradient in one pass:
  *   loss[0] = sum_q w[q] * BCE(prob[q], y[q])       (log clamped at -100, like F.binary_cross_entropy)

@@ -2156,3 +2156,95 @@ def test_compiled_torch_binding_equals_the_python_operators_bit_for_bit():
         for a_, b_, what in zip(out[("python", with_emb)], out[("native", with_emb)], ("H", "prob", "loss", "dZ")):
             assert torch.equal(a_, b_), (what, with_emb, float((a_ - b_).abs().max()))
     assert float(out[("native", False)][3].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_device_early_stop_follows_the_reference_bookkeeping():
+    """dl_epoch_finish (early_stop.DeviceEarlyStop) against the loop of main_disentangled.py:199-214 restated on the host:
+    a scripted sequence of validation score vectors (improving, equal, worse, NaN-free ties) and loss values — per epoch the
+    AUC must equal AucPlan.auc's, the best weights must be the parameter values AFTER the step of the last improving epoch,
+    patience must stop the bookkeeping at the same epoch, and launches queued after the stop must change nothing."""
+    from disenlink_amd.early_stop import DeviceEarlyStop
+    from disenlink_amd.metrics import AucPlan
+    from disenlink_amd.model import Disentangle
+    torch.manual_seed(3)
+    model = Disentangle(7, 5, 8, nfactor=3, beta=0.5, t=1).to(DEV)          # odd sizes: the tail elements of the copy
+    rng = np.random.default_rng(11)
+    n_val = 3000
+    label = torch.from_numpy((rng.random(n_val) < 0.3).astype(np.float32)).to(DEV)
+    plan = AucPlan(label)
+    patience, epochs = 3, 40
+    es = DeviceEarlyStop(model, plan, epochs, patience)
+    bufs = list(model._stacked.values())
+    # the quality of the scores goes up, stalls (ties with the best: NOT an improvement), goes up, then down for good
+    quality = [0.1, 0.3, 0.3, 0.2, 0.5, 0.5, 0.4, 0.45, 0.1, 0.1, 0.1, 0.1, 0.9, 0.95]
+    base = torch.from_numpy(rng.standard_normal(n_val).astype(np.float32)).to(DEV)
+    noise = {q: torch.from_numpy(np.round(rng.standard_normal(n_val), 1).astype(np.float32)).to(DEV) for q in set(quality)}
+    best_auc, stale, want_weights, stop_at, hist = 0.0, 0, [b.clone() for b in bufs], None, []
+    for e, q in enumerate(quality):
+        score = (q * (label * 2 - 1) + noise[q] + 0 * base).contiguous()     # same q -> the same vector -> the same AUC
+        loss = torch.tensor(1.0 / (e + 1), dtype=torch.float32, device=DEV)
+        with torch.no_grad():
+            for b in bufs:
+                b.add_(1.0)                                                # "the step"
+        es.finish(loss, score)
+        es.post(e) if stop_at is None else None
+        if stop_at is None:
+            auc = float(plan.auc(score))
+            hist.append((float(loss), auc))
+            if auc > best_auc:
+                best_auc, stale, want_weights = auc, 0, [b.clone() for b in bufs]
+            else:
+                stale += 1
+            if stale > patience:
+                stop_at = e
+    assert stop_at == 8, stop_at                                        # best at epoch 4; 5 (a tie), 6, 7, 8 are the four stale ones
+    for e, (lv, av) in enumerate(hist):
+        got = es.read(e) if e >= len(hist) - es.RING else None          # the ring keeps the last RING epochs
+        if got is not None:
+            assert got == (lv, av), (e, got, lv, av)
+    got_hist = es.hist[:len(hist)].cpu().numpy()
+    np.testing.assert_array_equal(got_hist, np.array(hist, dtype=np.float64))
+    assert torch.count_nonzero(es.hist[len(hist):]) == 0                # nothing recorded after the stop
+    st = es.state.cpu()
+    assert st[:1].view(torch.float64).item() == best_auc and int(st[3]) == 1 and int(st[2]) == stop_at + 1 and int(st[4]) == 4
+    assert int(es.u2.item()) == 0
+    for b, w in zip(es.best, want_weights):
+        assert torch.equal(b, w)
+    es.restore()
+    for b, w in zip(bufs, want_weights):
+        assert torch.equal(b, w)
+    es.reset()
+    assert int(es.state.abs().sum()) == 0 and all(torch.equal(b, s) for b, s in zip(es.best, bufs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("patience", [2, 4])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_training_with_device_side_early_stopping_equals_the_host_side_loop(use_graph, patience, monkeypatch):
+    """run_link_prediction with the end-of-epoch bookkeeping on the device (history read one epoch behind) against the same
+    run with DL_DEVICE_EARLY_STOP=0 (the host reads loss and AUC back every epoch, as the reference does): the same losses,
+    validation AUCs, stopping epoch, best AUC and test AUC — bit for bit, with a patience small enough to stop the run."""
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sg = synthetic_graph("chameleon", seed=7)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=7)
+    run = prepare_run(split, torch.device(DEV), row_bytes=8 * 64 * 4)
+    x = torch.from_numpy(sg.features()).to(DEV)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DL_DEVICE_EARLY_STOP", mode)
+        torch.manual_seed(0)
+        model = Disentangle(sg.n_feat, 64, 64, nfactor=8, beta=0.6, t=1).to(DEV)
+        # at this step size the validation AUC peaks at the third epoch, dips and comes back: the run stops on patience
+        # after 6 / 8 epochs, the best weights are those of epoch 2
+        out[mode] = (run_link_prediction(model, x, run, epochs=60, lr=3e-3, patience=patience, use_graph=use_graph),
+                     {k: v.clone() for k, v in model.state_dict().items()})
+    r1, r0 = out["1"][0], out["0"][0]
+    assert r1.epochs_run == r0.epochs_run and r1.epochs_run == {2: 6, 4: 8}[patience], (r1.epochs_run, r0.epochs_run)
+    assert r1.losses == r0.losses and r1.val_aucs == r0.val_aucs
+    assert r1.best_val_auc == r0.best_val_auc and r1.test_auc == r0.test_auc
+    for k in out["1"][1]:
+        assert torch.equal(out["1"][1][k], out["0"][1][k]), k                 # the best weights were loaded back
