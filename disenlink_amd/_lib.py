@@ -77,10 +77,11 @@ EXPORTS = {
     "dl_auc_pair_counts": (_i, [_P, _P, _i, _P, _i, _P, _P]),
     "dl_auc_pair_counts_add": (_i, [_P, _P, _i, _P, _i, _P, _P]),
     "dl_epoch_state_bytes": (C.c_size_t, []),
-    "dl_epoch_finish": (_i, [_i, _P, _P, _P, _P, _P, C.c_double, _P, _P, C.c_longlong, C.c_longlong, _P]),
+    "dl_epoch_finish": (_i, [_i, _P, _P, _P, _P, _P, C.c_double, _P, _P, C.c_longlong, C.c_longlong, _P, _i, _P]),
     "dl_score_pairs_train_supported": (_i, [_P, _i, _i, _i]),
     "dl_score_pairs_train": (_i, [_P, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_adam_step": (_i, [_i, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+    "dl_adam_step_at": (_i, [_i, _P, _P, _P, _P, _P, _P, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "dl_pair_bce": (_i, [_P, _P, _P, _i, _P, _P, _P, _z, _P]),
     "dl_score_pairs_bwd": (_i, [_P, _P, _i, _i, _i, _f, _I, _P, _P, _P, _P, _P, _P, _z, _P]),
     "dl_route_aggregate_bwd_phase1": (_i, [_G, _P, _i, _i, _i, _f, _P, _P, _P, _P, _P, _P, _P, _P, _z, _P]),

@@ -324,14 +324,16 @@ size_t dl_epoch_state_bytes(void) { return epoch_state_bytes(); }
 
 int dl_epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
                     unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs,
-                    long long patience, void* stream) {
+                    long long patience, double* host_ring, int ring, void* stream) {
     DL_REQUIRE(n_bufs >= 0 && n_bufs <= DL_ADAM_MAX_BUFS, "n_bufs=%d outside 0..%d", n_bufs, DL_ADAM_MAX_BUFS);
     DL_REQUIRE(loss && u2 && state, "loss / u2 / state is NULL");
     DL_REQUIRE(max_epochs >= 0 && (max_epochs == 0 || hist != nullptr), "hist is NULL");
     DL_REQUIRE(patience >= 0, "negative patience");
     if (n_bufs > 0) DL_REQUIRE(params && best && numel, "NULL argument");
     for (int i = 0; i < n_bufs; ++i) DL_REQUIRE(numel[i] == 0 || (params[i] && best[i]), "buffer %d: NULL pointer", i);
-    return epoch_finish(n_bufs, params, best, numel, loss, u2, denom2, state, hist, max_epochs, patience, (hipStream_t)stream);
+    DL_REQUIRE(host_ring == nullptr || ring >= 1, "ring=%d", ring);
+    return epoch_finish(n_bufs, params, best, numel, loss, u2, denom2, state, hist, max_epochs, patience, host_ring, ring,
+                        (hipStream_t)stream);
 }
 
 int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, float* loss, float* g, void* ws,
@@ -355,6 +357,19 @@ int dl_adam_step(int n_bufs, float* const* params, const float* const* grads, fl
         DL_REQUIRE(numel[i] == 0 || (params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i]), "buffer %d: NULL pointer", i);
     return adam_step(n_bufs, params, grads, exp_avg, exp_avg_sq, numel, state, lr, beta1, beta2, eps, weight_decay,
                      (hipStream_t)stream);
+}
+
+int dl_adam_step_at(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const size_t* numel, float* state, long long step, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, void* stream) {
+    DL_REQUIRE(n_bufs >= 0 && n_bufs <= DL_ADAM_MAX_BUFS, "n_bufs=%d outside 0..%d", n_bufs, DL_ADAM_MAX_BUFS);
+    DL_REQUIRE(step >= 1 && step < (1ll << 24), "step=%lld outside 1..2^24-1", step);
+    DL_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "bad Adam hyper-parameters");
+    if (n_bufs > 0) DL_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "NULL argument");
+    for (int i = 0; i < n_bufs; ++i)
+        DL_REQUIRE(numel[i] == 0 || (params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i]), "buffer %d: NULL pointer", i);
+    return adam_step(n_bufs, params, grads, exp_avg, exp_avg_sq, numel, state, lr, beta1, beta2, eps, weight_decay,
+                     (hipStream_t)stream, step);
 }
 
 int dl_score_pairs_bwd(const void* Z, const void* H, int K, int d, dl_dtype dtype, float t,

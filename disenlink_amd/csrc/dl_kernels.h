@@ -64,10 +64,10 @@ int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const
 size_t epoch_state_bytes();
 int epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
                  unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs, long long patience,
-                 hipStream_t st);
+                 double* host_ring, int ring, hipStream_t st);
 int adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
               const size_t* numel, float* state, double lr, double beta1, double beta2, double eps, double weight_decay,
-              hipStream_t st);
+              hipStream_t st, long long host_step = 0);
 
 int pair_bce(const float* prob, const float* y, const float* w, int n, float* loss, float* g, float* partial,
              hipStream_t st);

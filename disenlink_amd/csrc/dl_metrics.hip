@@ -133,14 +133,28 @@ __global__ void adam_advance_kernel(float* __restrict__ state, double lr, double
 }
 
 // w1 = 1 - beta1, w2 = 1 - beta2 (formed in double on the host, like torch's kernel arguments)
-__global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, const float* __restrict__ state, float w1, float beta2,
-                                                          float w2, float eps, float weight_decay) {
+// HOST_STEP (dl_adam_step_at): the caller counts the steps — an eager loop knows the number — so there is no one-thread
+// launch in front: thread 0 of every workgroup forms the two bias corrections from `step` with the SAME device
+// expressions as adam_advance_kernel (the same bits) and hands them over through LDS; workgroup 0 leaves them in `state`.
+template <bool HOST_STEP>
+__global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, float* __restrict__ state, float w1, float beta2,
+                                                          float w2, float eps, float weight_decay, float step, double lr,
+                                                          double beta1d, double beta2d) {
+    __shared__ float corr[2];
+    if constexpr (HOST_STEP) {
+        if (threadIdx.x == 0) {
+            corr[0] = (float)(lr / (1.0 - pow(beta1d, (double)step)));
+            corr[1] = (float)sqrt(1.0 - pow(beta2d, (double)step));
+            if (blockIdx.x == 0 && state != nullptr) { state[0] = step; state[1] = corr[0]; state[2] = corr[1]; }
+        }
+        __syncthreads();
+    }
     const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     int i = 0;
     while (i < b.count && q >= b.n4_end[i]) ++i;
     if (i >= b.count) return;
     const unsigned long long e0 = (q - (i ? b.n4_end[i - 1] : 0ull)) * 4;
-    const float step_size = state[1], bc2s = state[2];
+    const float step_size = HOST_STEP ? corr[0] : state[1], bc2s = HOST_STEP ? corr[1] : state[2];
     float* __restrict__ p = b.p[i];
     const float* __restrict__ g = b.g[i];
     float* __restrict__ m = b.m[i];
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamBufs b, const floa
 
 int adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
               const size_t* numel, float* state, double lr, double beta1, double beta2, double eps, double weight_decay,
-              hipStream_t st) {
+              hipStream_t st, long long host_step) {
     AdamBufs b;
     unsigned long long run = 0;
     for (int i = 0; i < n_bufs; ++i) {
@@ -174,10 +188,16 @@ int adam_step(int n_bufs, float* const* params, const float* const* grads, float
         b.n4_end[i] = run;
     }
     b.count = n_bufs;
+    const dim3 grid((unsigned)std::max<unsigned long long>(1, (run + 255) / 256));
+    if (host_step > 0) {                                        // the caller counts: one launch
+        hipLaunchKernelGGL(adam_update_kernel<true>, grid, dim3(256), 0, st, b, state, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)host_step, lr, beta1, beta2);
+        return check_launch("adam_step_at");
+    }
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, state, lr, beta1, beta2);
     if (run > 0)
-        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)((run + 255) / 256)), dim3(256), 0, st, b, (const float*)state,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
+        hipLaunchKernelGGL(adam_update_kernel<false>, grid, dim3(256), 0, st, b, state, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, 0.0f, lr, beta1, beta2);
     return check_launch("adam_step");
 }
 
@@ -215,16 +235,19 @@ static_assert(sizeof(EpochState) == 48, "layout documented in include/disenlink_
 
 __global__ __launch_bounds__(256) void epoch_finish_kernel(SnapBufs b, const float* __restrict__ loss, unsigned long long* u2,
                                                            double denom2, EpochState* st, double* __restrict__ hist,
-                                                           long long max_epochs, long long patience) {
+                                                           long long max_epochs, long long patience, double* host_ring,
+                                                           int ring) {
     const unsigned long long cnt = *reinterpret_cast<volatile unsigned long long*>(u2);
     const double auc = denom2 > 0.0 ? (double)cnt / denom2 : (double)NAN;
     const bool stopped = *reinterpret_cast<volatile long long*>(&st->stopped) != 0;
     const bool improved = !stopped && auc > *reinterpret_cast<volatile double*>(&st->best_auc);
     if (improved) {
-        const unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-        int i = 0;
-        while (i < b.count && q >= b.n4_end[i]) ++i;
-        if (i < b.count) {
+        // grid-stride over the float4 slots of all buffers: FEW workgroups (the end-of-kernel counter below is one atomic
+        // per workgroup on one address — 768 of them cost 15 us, more than the 3 MB copy itself)
+        const unsigned long long total = b.count ? b.n4_end[b.count - 1] : 0ull;
+        for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (unsigned long long)gridDim.x * 256) {
+            int i = 0;
+            while (q >= b.n4_end[i]) ++i;
             const unsigned long long e0 = (q - (i ? b.n4_end[i - 1] : 0ull)) * 4;
             const float* __restrict__ s = b.src[i];
             float* __restrict__ d = b.dst[i];
@@ -247,6 +270,13 @@ __global__ __launch_bounds__(256) void epoch_finish_kernel(SnapBufs b, const flo
                     hist[2 * e] = (double)loss[0];
                     hist[2 * e + 1] = auc;
                 }
+                if (host_ring != nullptr) {                     // pinned host memory: the host reads it after an event, no copy
+                    volatile double* slot = host_ring + 4 * (e % ring);
+                    slot[0] = (double)loss[0];
+                    slot[1] = auc;
+                    slot[2] = (double)(e + 1);                  // which epoch the slot holds (+1: 0 = never written)
+                    __threadfence_system();
+                }
                 if (improved) {
                     st->best_auc = auc;
                     st->stale = 0;
@@ -266,7 +296,7 @@ size_t epoch_state_bytes() { return sizeof(EpochState); }
 
 int epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
                  unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs, long long patience,
-                 hipStream_t st) {
+                 double* host_ring, int ring, hipStream_t st) {
     SnapBufs b;
     unsigned long long run = 0;
     for (int i = 0; i < n_bufs; ++i) {
@@ -276,9 +306,9 @@ int epoch_finish(int n_bufs, const float* const* params, float* const* best, con
         b.n4_end[i] = run;
     }
     b.count = n_bufs;
-    const unsigned blocks = (unsigned)std::max<unsigned long long>(1, (run + 255) / 256);
+    const unsigned blocks = (unsigned)std::min<unsigned long long>(64, std::max<unsigned long long>(1, (run + 255) / 256));
     hipLaunchKernelGGL(epoch_finish_kernel, dim3(blocks), dim3(256), 0, st, b, loss, u2, denom2,
-                       reinterpret_cast<EpochState*>(state), hist, max_epochs, patience);
+                       reinterpret_cast<EpochState*>(state), hist, max_epochs, patience, host_ring, ring);
     return check_launch("epoch_finish");
 }
 

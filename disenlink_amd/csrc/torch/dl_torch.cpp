@@ -196,8 +196,9 @@ Tensor project_stacked(const Tensor& x, const Tensor& W1, const Tensor& b1, cons
 // ---------------------------------------------------------------------------- Adam over the shared buffers (main_disentangled.py:150, 199)
 // optim.StackedAdam.step without Python between the gradient bookkeeping and the launch: the K gradients of a group are the
 // slices of one stacked tensor when the projection's backward made them (checked by address); otherwise they are stacked.
+// host_step > 0: the caller counts the steps (dl_adam_step_at: one launch instead of two); 0: the counter in `state` (graph capture).
 void adam_step(at::TensorList bufs, at::TensorList params, at::TensorList exp_avg, at::TensorList exp_avg_sq, const Tensor& state,
-               double lr, double beta1, double beta2, double eps, double weight_decay) {
+               double lr, double beta1, double beta2, double eps, double weight_decay, int64_t host_step) {
     const int n = (int)bufs.size();
     TORCH_CHECK(n >= 1 && n <= DL_ADAM_MAX_BUFS && (int)exp_avg.size() == n && (int)exp_avg_sq.size() == n, "adam_step: buffer lists");
     TORCH_CHECK(params.size() % n == 0, "adam_step: params must hold the same number of parameters per buffer");
@@ -232,7 +233,11 @@ void adam_step(at::TensorList bufs, at::TensorList params, at::TensorList exp_av
         vp[b] = exp_avg_sq[b].data_ptr<float>();
         numel[b] = (size_t)bufs[b].numel();
     }
-    check(dl_adam_step(n, pp, gp, mp, vp, numel, state.data_ptr<float>(), lr, beta1, beta2, eps, weight_decay, stream()), "dl_adam_step");
+    if (host_step > 0)
+        check(dl_adam_step_at(n, pp, gp, mp, vp, numel, state.data_ptr<float>(), (long long)host_step, lr, beta1, beta2, eps, weight_decay,
+                              stream()), "dl_adam_step_at");
+    else
+        check(dl_adam_step(n, pp, gp, mp, vp, numel, state.data_ptr<float>(), lr, beta1, beta2, eps, weight_decay, stream()), "dl_adam_step");
 }
 
 // ---------------------------------------------------------------------------- tie-averaged AUC counts (main_disentangled.py:202-204)
@@ -253,7 +258,7 @@ TORCH_LIBRARY(disenlink_native, m) {
           "Tensor weight, Tensor ws_graph, Tensor ws_pairs, Tensor ws_bce, int table_bf16) -> (Tensor, Tensor, Tensor)");
     m.def("project_stacked(Tensor x, Tensor W1, Tensor b1, Tensor W2, Tensor b2, Tensor[] params, bool keep_hid, Tensor? xplanes) -> Tensor");
     m.def("adam_step(Tensor[] bufs, Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, Tensor state, float lr, float beta1, "
-          "float beta2, float eps, float weight_decay) -> ()");
+          "float beta2, float eps, float weight_decay, int host_step=0) -> ()");
     m.def("auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor");
     m.def("abi_version() -> str");
 }

@@ -43,7 +43,8 @@ class DeviceEarlyStop:
         self.hist = torch.zeros(max(self.max_epochs, 1), 2, dtype=torch.float64, device=dev)
         self.u2 = torch.zeros(1, dtype=torch.int64, device=dev)     # kept at zero between evaluations by dl_epoch_finish
         self.denom2 = 2.0 * float(val_plan.n_pos) * float(val_plan.n_neg)
-        self.ring = torch.zeros(self.RING, 2, dtype=torch.float64).pin_memory()
+        # pinned host memory the kernel writes (loss, auc, epoch + 1) into directly: no copy launch per epoch
+        self.ring = torch.zeros(self.RING, 4, dtype=torch.float64).pin_memory()
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
 
     @staticmethod
@@ -58,9 +59,11 @@ class DeviceEarlyStop:
 
     def reset(self):
         """Forget everything (after graph warm-up / capture epochs, which run the launch like any other epoch)."""
+        torch.cuda.synchronize()
         self.state.zero_()
         self.hist.zero_()
         self.u2.zero_()
+        self.ring.zero_()
         for b, src in zip(self.best, self.bufs):
             b.copy_(src)
 
@@ -80,18 +83,19 @@ class DeviceEarlyStop:
                                                    p.n_neg, self.u2.data_ptr(), st), "dl_auc_pair_counts_add")
         self.check(self.lib.dl_epoch_finish(len(self.bufs), self._p, self._b, self._numel, loss.data_ptr(), self.u2.data_ptr(),
                                             self.denom2, self.state.data_ptr(), self.hist.data_ptr(), self.max_epochs,
-                                            self.patience, st), "dl_epoch_finish")
+                                            self.patience, self.ring.data_ptr(), self.RING, st), "dl_epoch_finish")
 
     def post(self, epoch: int):
-        """Queue the read-back of hist[epoch] behind the epoch's launches (not part of a captured graph)."""
-        slot = epoch % self.RING
-        self.ring[slot].copy_(self.hist[epoch], non_blocking=True)
-        self.events[slot].record()
+        """Mark the end of the epoch's launches (an event; not part of a captured graph)."""
+        self.events[epoch % self.RING].record()
 
     def read(self, epoch: int):
+        """(loss, auc) of `epoch`, once its launches are done: from the pinned slot the kernel wrote."""
         slot = epoch % self.RING
         self.events[slot].synchronize()
-        loss_v, auc = self.ring[slot].tolist()
+        loss_v, auc, tag, _ = self.ring[slot].tolist()
+        if int(tag) != epoch + 1:                                   # cannot happen while LAG < RING and the run has not stopped
+            raise RuntimeError(f"DeviceEarlyStop: slot {slot} holds epoch {int(tag) - 1}, expected {epoch}")
         return loss_v, auc
 
     def restore(self):

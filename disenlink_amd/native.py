@@ -90,11 +90,11 @@ def project_stacked(x: torch.Tensor, bufs, params) -> torch.Tensor:
     return torch.ops.disenlink_native.project_stacked(x, W1, b1, W2, b2, params, keep, ops.xplanes_for(x))
 
 
-def adam_step(bufs, params, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay) -> None:
-    """optim.StackedAdam's update (dl_adam_step) with the gradient bookkeeping in C++; params = the parameters of every
-    buffer, buffer by buffer (K each)."""
+def adam_step(bufs, params, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, host_step: int = 0) -> None:
+    """optim.StackedAdam's update (dl_adam_step; dl_adam_step_at when the caller counts the steps: host_step >= 1) with the
+    gradient bookkeeping in C++; params = the parameters of every buffer, buffer by buffer (K each)."""
     torch.ops.disenlink_native.adam_step(bufs, params, exp_avg, exp_avg_sq, state, float(lr), float(beta1), float(beta2),
-                                         float(eps), float(weight_decay))
+                                         float(eps), float(weight_decay), int(host_step))
 
 
 def auc_pair_counts(score: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor) -> torch.Tensor:

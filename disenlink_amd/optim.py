@@ -15,6 +15,10 @@ from __future__ import annotations
 import torch
 
 
+import os as _os
+_HOST_STEP = _os.environ.get("DL_ADAM_HOST_STEP", "1") != "0"      # 0: always the device-side step counter (A/B runs)
+
+
 def stacked_grad(ps, buf) -> torch.Tensor:
     """The K gradients of one parameter group as ONE [K, ...] tensor shaped like the group's shared buffer.  The
     projection's backward hands out the K slices of a stacked gradient (ops.ProjectStacked): when the K .grad tensors
@@ -117,19 +121,30 @@ class StackedAdam:
         if [self.model._stacked[k].data_ptr() for k in self.keys] != [b.data_ptr() for b in self.bufs]:
             raise RuntimeError("the module's parameter buffers were rebuilt (.to() / load on another device): "
                                "create the optimiser afterwards")
+        # an eager loop counts its steps on the host (dl_adam_step_at: no counter launch in front of the update); a loop that
+        # is captured and replayed cannot — its counter lives in dl_state (dl_adam_step)
+        host_step = 0
+        if not self.use_torch_kernel and not self.capturable and _HOST_STEP:
+            self._host_step = host_step = self.__dict__.get("_host_step", 0) + 1
         if not self.use_torch_kernel and self._native():
             from . import native                                   # gradient bookkeeping + launch in C++ (no ctypes, no per-parameter Python)
             native.adam_step(self.bufs, self._flat_params, self.exp_avg, self.exp_avg_sq, self.dl_state, self.lr, self.betas[0],
-                             self.betas[1], self.eps, self.weight_decay)
+                             self.betas[1], self.eps, self.weight_decay, host_step)
             return
         grads = [self._stacked_grad(k) for k in self.keys]
         if not self.use_torch_kernel:
             from . import _lib
             self._grads_alive = grads                              # the launch is asynchronous
-            _lib.check(_lib.load().dl_adam_step(len(self.bufs), self._p, self._ptrs([g.contiguous() for g in grads]), self._m,
-                                                self._v, self._numel, self.dl_state.data_ptr(), self.lr, self.betas[0],
-                                                self.betas[1], self.eps, self.weight_decay,
-                                                torch.cuda.current_stream().cuda_stream), "dl_adam_step")
+            gp = self._ptrs([g.contiguous() for g in grads])
+            st = torch.cuda.current_stream().cuda_stream
+            if host_step:
+                _lib.check(_lib.load().dl_adam_step_at(len(self.bufs), self._p, gp, self._m, self._v, self._numel,
+                                                       self.dl_state.data_ptr(), host_step, self.lr, self.betas[0], self.betas[1],
+                                                       self.eps, self.weight_decay, st), "dl_adam_step_at")
+            else:
+                _lib.check(_lib.load().dl_adam_step(len(self.bufs), self._p, gp, self._m, self._v, self._numel,
+                                                    self.dl_state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                    self.weight_decay, st), "dl_adam_step")
             return
         torch._foreach_add_(self.steps, 1)
         torch._fused_adam_(self.bufs, grads, self.exp_avg, self.exp_avg_sq, [], self.steps, lr=self.lr,

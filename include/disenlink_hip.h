@@ -301,13 +301,15 @@ int dl_auc_pair_counts_add(const float* score, const int64_t* pos_idx, int n_pos
  *   each: the weights AFTER the step, like :209), best_auc = auc, stale = 0, best_epoch = epoch;  else stale += 1;
  *   hist[2 epoch] = loss[0], hist[2 epoch + 1] = auc (epoch < max_epochs);  epoch += 1;  stale > patience: stopped = 1;
  *   *u2 = 0.  Once stopped the call changes nothing but *u2 = 0 (epochs the host queued before it saw the stop).
+ * host_ring (or NULL): PINNED, device-accessible host memory of ring x 4 doubles — slot (epoch mod ring) receives
+ *   { loss, auc, epoch + 1, unused } as well, for a host that reads the history behind an event without a copy.
  * state: dl_epoch_state_bytes() bytes owned by the caller, zero-initialised once (best_auc = 0 as at :189):
  *   { double best_auc; int64 stale, epoch, stopped, best_epoch; uint32 internal[2]; }
  * params / best / numel: HOST arrays like dl_adam_step's; loss, u2, hist, state: device memory. */
 size_t dl_epoch_state_bytes(void);
 int dl_epoch_finish(int n_bufs, const float* const* params, float* const* best, const size_t* numel, const float* loss,
                     unsigned long long* u2, double denom2, void* state, double* hist, long long max_epochs,
-                    long long patience, void* stream);
+                    long long patience, double* host_ring, int ring, void* stream);
 
 /* Pair-list loss of main_disentangled.py:195 and its gradient in one pass:
  *   loss[0] = sum_q w[q] * BCE(prob[q], y[q])       (log clamped at -100, like F.binary_cross_entropy)
@@ -331,6 +333,12 @@ int dl_pair_bce(const float* prob, const float* y, const float* w, int n_pairs, 
 int dl_adam_step(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const size_t* numel, float* state,
                  double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+/* The same update with the step number counted by the CALLER (step = 1 for the first update): no counter launch in front
+ * of the update — for loops that are not replayed from a graph.  The bias corrections are formed on the device with the
+ * expressions dl_adam_step uses (the same bits for the same step); state (or NULL) receives {step, step size, sqrt(1 - beta2^step)}. */
+int dl_adam_step_at(int n_bufs, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const size_t* numel, float* state, long long step,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 /* Backward of dl_score_pairs_fwd (autograd of model.py:109-113 + sigmoid, as triggered at
  * main_disentangled.py:198).  g_prob = dLoss/dprob per pair.  Writes dZ and dH for the plan's rows:

@@ -2248,3 +2248,40 @@ def test_training_with_device_side_early_stopping_equals_the_host_side_loop(use_
     assert r1.best_val_auc == r0.best_val_auc and r1.test_auc == r0.test_auc
     for k in out["1"][1]:
         assert torch.equal(out["1"][1][k], out["0"][1][k]), k                 # the best weights were loaded back
+
+
+@pytest.mark.gpu
+def test_adam_step_counted_by_the_caller_gives_the_bits_of_the_device_counter():
+    """dl_adam_step_at (the eager loop counts the steps: one launch) against dl_adam_step (a one-thread launch advances the
+    counter in `state`, for graph replays): the same parameters, moments and state floats after every one of 7 steps over
+    buffers of odd sizes."""
+    import ctypes as C
+    from disenlink_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    sizes = [1037, 64, 4099, 3]
+    mk = lambda: [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    p0, grads = mk(), [mk() for _ in range(7)]
+    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    numel = (C.c_size_t * len(sizes))(*sizes)
+    out = {}
+    for mode in ("device", "host"):
+        p = [t.clone() for t in p0]
+        m, v = [torch.zeros_like(t) for t in p], [torch.zeros_like(t) for t in p]
+        state = torch.zeros(3, dtype=torch.float32, device=DEV)
+        trace = []
+        for step, gs in enumerate(grads, start=1):
+            if mode == "device":
+                _lib.check(lib.dl_adam_step(len(p), ptrs(p), ptrs(gs), ptrs(m), ptrs(v), numel, state.data_ptr(), 1e-3, 0.9, 0.999,
+                                            1e-8, 5e-4, torch.cuda.current_stream().cuda_stream), "dl_adam_step")
+            else:
+                _lib.check(lib.dl_adam_step_at(len(p), ptrs(p), ptrs(gs), ptrs(m), ptrs(v), numel, state.data_ptr(), step, 1e-3, 0.9,
+                                               0.999, 1e-8, 5e-4, torch.cuda.current_stream().cuda_stream), "dl_adam_step_at")
+            trace.append([t.clone() for t in p + m + v] + [state.clone()])
+        out[mode] = trace
+    for step, (a, b) in enumerate(zip(out["device"], out["host"]), start=1):
+        for i, (x_, y_) in enumerate(zip(a, b)):
+            assert torch.equal(x_, y_), (step, i)
+    assert float(out["host"][-1][-1][0]) == 7.0
+    assert lib.dl_adam_step_at(1, ptrs(p0[:1]), ptrs(p0[:1]), ptrs(p0[:1]), ptrs(p0[:1]), numel, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0,
+                               None) != 0                                   # step 0: rejected

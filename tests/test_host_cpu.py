@@ -589,7 +589,7 @@ def test_compiled_torch_binding_builds_loads_and_registers_its_operator():
     schemas = {"project_stacked": "disenlink_native::project_stacked(Tensor x, Tensor W1, Tensor b1, Tensor W2, Tensor b2, "
                                   "Tensor[] params, bool keep_hid, Tensor? xplanes) -> Tensor",
                "adam_step": "disenlink_native::adam_step(Tensor[] bufs, Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, "
-                            "Tensor state, float lr, float beta1, float beta2, float eps, float weight_decay) -> ()",
+                            "Tensor state, float lr, float beta1, float beta2, float eps, float weight_decay, int host_step=0) -> ()",
                "auc_pair_counts": "disenlink_native::auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor"}
     for name, want in schemas.items():
         assert str(getattr(torch.ops.disenlink_native, name).default._schema) == want, name
