@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void epoch_finish_kernel(SnapBufs b, const flo
                                                            int ring) {
     const unsigned long long cnt = *reinterpret_cast<volatile unsigned long long*>(u2);
     const double auc = denom2 > 0.0 ? (double)cnt / denom2 : (double)NAN;
-    const bool stopped = *reinterpret_cast<volatile long long*>(&st->stopped) != 0;
+    // (epochs past max_epochs — the tail of a replayed graph that holds several epochs — count as stopped too)
+    const bool stopped = *reinterpret_cast<volatile long long*>(&st->stopped) != 0 ||
+                         *reinterpret_cast<volatile long long*>(&st->epoch) >= max_epochs;
     const bool improved = !stopped && auc > *reinterpret_cast<volatile double*>(&st->best_auc);
     if (improved) {
         // grid-stride over the float4 slots of all buffers: FEW workgroups (the end-of-kernel counter below is one atomic
@@ -266,10 +268,8 @@ __global__ __launch_bounds__(256) void epoch_finish_kernel(SnapBufs b, const flo
             st->blocks_done = 0;
             if (!stopped) {
                 const long long e = st->epoch;
-                if (e < max_epochs) {
-                    hist[2 * e] = (double)loss[0];
-                    hist[2 * e + 1] = auc;
-                }
+                hist[2 * e] = (double)loss[0];
+                hist[2 * e + 1] = auc;
                 if (host_ring != nullptr) {                     // pinned host memory: the host reads it after an event, no copy
                     volatile double* slot = host_ring + 4 * (e % ring);
                     slot[0] = (double)loss[0];

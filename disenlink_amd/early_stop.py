@@ -20,10 +20,12 @@ import torch
 
 
 class DeviceEarlyStop:
-    LAG = 1                                                         # epochs the host's read-back trails the launches
-    RING = 4
+    LAG = 1                                                         # launches the host's read-back trails
+    EVENTS = 4
 
-    def __init__(self, model, val_plan, max_epochs: int, patience: int):
+    def __init__(self, model, val_plan, max_epochs: int, patience: int, epochs_per_launch: int = 1):
+        self.per = max(1, int(epochs_per_launch))                   # a replayed graph may hold several epochs
+        self.RING = 4 * self.per
         from . import _lib
         self.lib = _lib.load()
         self.check = _lib.check
@@ -45,7 +47,7 @@ class DeviceEarlyStop:
         self.denom2 = 2.0 * float(val_plan.n_pos) * float(val_plan.n_neg)
         # pinned host memory the kernel writes (loss, auc, epoch + 1) into directly: no copy launch per epoch
         self.ring = torch.zeros(self.RING, 4, dtype=torch.float64).pin_memory()
-        self.events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.events = [torch.cuda.Event() for _ in range(self.EVENTS)]
 
     @staticmethod
     def usable(model, x, val_plan) -> bool:
@@ -85,14 +87,14 @@ class DeviceEarlyStop:
                                             self.denom2, self.state.data_ptr(), self.hist.data_ptr(), self.max_epochs,
                                             self.patience, self.ring.data_ptr(), self.RING, st), "dl_epoch_finish")
 
-    def post(self, epoch: int):
-        """Mark the end of the epoch's launches (an event; not part of a captured graph)."""
-        self.events[epoch % self.RING].record()
+    def post(self, launch: int):
+        """Mark the end of launch number `launch` (an event; not part of a captured graph)."""
+        self.events[launch % self.EVENTS].record()
 
-    def read(self, epoch: int):
-        """(loss, auc) of `epoch`, once its launches are done: from the pinned slot the kernel wrote."""
+    def read(self, epoch: int, launch: int | None = None):
+        """(loss, auc) of `epoch`, once the launch that holds it is done: from the pinned slot the kernel wrote."""
         slot = epoch % self.RING
-        self.events[slot].synchronize()
+        self.events[(epoch // self.per if launch is None else launch) % self.EVENTS].synchronize()
         loss_v, auc, tag, _ = self.ring[slot].tolist()
         if int(tag) != epoch + 1:                                   # cannot happen while LAG < RING and the run has not stopped
             raise RuntimeError(f"DeviceEarlyStop: slot {slot} holds epoch {int(tag) - 1}, expected {epoch}")
@@ -105,11 +107,12 @@ class DeviceEarlyStop:
                 b.copy_(src)
 
 
-def drive(es: DeviceEarlyStop, epochs: int, patience: int, launch_epoch, res, log=None):
-    """The epoch loop over `launch_epoch(epoch)` (which queues one epoch INCLUDING es.finish): launches run LAG epochs
-    ahead of the host's reading of the history; `res` (train.RunResult) receives losses / val_aucs / epochs_run exactly as
-    the reference's loop would fill them.  Returns best_auc."""
+def drive(es: DeviceEarlyStop, epochs: int, patience: int, launch, res, log=None):
+    """The epoch loop over `launch()` (which queues es.per epochs, each INCLUDING es.finish): launches run LAG ahead of the
+    host's reading of the history; `res` (train.RunResult) receives losses / val_aucs / epochs_run exactly as the
+    reference's loop would fill them.  Returns best_auc."""
     best_auc, stale, stopped = 0.0, 0, False
+    per = es.per
 
     def take(e):
         nonlocal best_auc, stale, stopped
@@ -127,16 +130,14 @@ def drive(es: DeviceEarlyStop, epochs: int, patience: int, launch_epoch, res, lo
             log(f"epoch: {e} loss: {loss_v} val_auc: {best_auc}")
 
     done = launched = 0
-    for epoch in range(epochs):
-        launch_epoch(epoch)
-        es.post(epoch)
-        launched = epoch + 1
-        if launched - done > es.LAG:
+    while launched < epochs and not stopped:
+        launch()
+        es.post(launched // per)
+        launched += per                                             # (the device ignores epochs past `epochs`)
+        while launched - done > es.LAG * per and not stopped:
             take(done)
             done += 1
-            if stopped:
-                break
-    while not stopped and done < launched:
+    while not stopped and done < min(launched, epochs):
         take(done)
         done += 1
     return best_auc

@@ -50,6 +50,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--table-dtype", choices=["f32", "bf16"], default="f32")
     p.add_argument("--no-graph", action="store_true",
                    help="launch every epoch from Python instead of replaying it from a captured HIP graph")
+    p.add_argument("--graph", action="store_true",
+                   help="replay every epoch from a captured HIP graph.  Default: replayed when the compiled binding "
+                        "(libdisenlink_torch.so) is absent, eager when it is present — with it and the end-of-epoch "
+                        "bookkeeping on the device the eager loop is gapless and 3-10 %% faster than the replay")
     p.add_argument("--quiet", action="store_true")
     p.add_argument("--gpus", type=int, default=1,
                    help="row-shard every run over this many GPUs of the node (one process per GPU, RCCL): started "
@@ -143,6 +147,18 @@ def main_sharded(args):
         dist.destroy_process_group()
 
 
+def _use_graph(args) -> bool:
+    """--graph / --no-graph, else by what is faster: the replayed epoch saves host time per launch, which only matters when
+    the launches go through the Python operators (chameleon 0.38 vs 0.76 ms); through the compiled binding, with early
+    stopping on the device (early_stop.py), the host runs ahead of the GPU and the eager loop has neither the replay's
+    per-node dispatch cost nor a gap between epochs (squirrel 0.837 vs 0.860 ms, chameleon 0.313 vs 0.331, cora-sized 0.665 vs
+    0.707: profiles/r5z_*)."""
+    if args.graph or args.no_graph:
+        return bool(args.graph)
+    from . import native
+    return not native.available()
+
+
 def main(argv=None):
     args = build_parser().parse_known_args(argv)[0]                 # unknown tokens ignored, like :50
     if args.layer != 1:
@@ -180,7 +196,7 @@ def main(argv=None):
         model = Disentangle(x.shape[1], args.nhidden, args.nembed, nfactor=args.nfactor, beta=args.beta,
                             t=args.temperature, table_dtype=tdt).to(device)
         res = run_link_prediction(model, x, prepared, epochs=args.epochs, lr=args.lr,
-                                  log=None if args.quiet else print, use_graph=not args.no_graph)
+                                  log=None if args.quiet else print, use_graph=_use_graph(args))
         if not args.quiet:
             print("test auc:", res.test_auc)
         result.append(res.test_auc)

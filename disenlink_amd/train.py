@@ -142,6 +142,8 @@ def _graphed_epoch(model, x, run, lr, weight_decay, b, label_all, weight_all, es
                 if torch.is_tensor(v):
                     v.zero_()
     torch.cuda.current_stream().wait_stream(side)
+    # (several epochs per graph, or two graph instances replayed in turn, do not make the replayed loop faster:
+    # profiles/r5z_graph_epochs_execs_sweep.txt — its 25-40 us per epoch over the eager loop are per-node dispatch cost)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         epoch()
@@ -191,7 +193,7 @@ def run_link_prediction(model, x: torch.Tensor, run: PreparedRun, epochs: int = 
         es = DeviceEarlyStop(model, val_plan, epochs, patience)
         seed = torch.ones((), dtype=torch.float32, device=x.device)  # d loss / d loss, made once instead of a fill per epoch
 
-        def launch_epoch(_epoch):
+        def launch_epoch():
             model.train()
             prob, loss = _scores_and_loss(model, x, run, label_all, weight_all)
             opt.zero_grad()
@@ -251,7 +253,7 @@ def _run_graphed(model, x, run, epochs, lr, patience, weight_decay, log) -> RunR
     res = RunResult(float("nan"), 0.0, 0)
     if isinstance(out, DeviceEarlyStop):
         es = out
-        res.best_val_auc = drive(es, epochs, patience, lambda _epoch: replay(), res, log)
+        res.best_val_auc = drive(es, epochs, patience, replay, res, log)
         torch.cuda.synchronize()
         del replay, keep_alive                                      # only now may the graph's external tensors go
         es.restore()

@@ -299,8 +299,9 @@ int dl_auc_pair_counts_add(const float* score, const int64_t* pos_idx, int n_pos
  *   auc = *u2 / denom2 in double (u2 = the counts of dl_auc_pair_counts[_add], denom2 = 2 n_pos n_neg; NaN if denom2 <= 0);
  *   if !stopped && auc > best_auc: best[i][:] = params[i][:] for the n_bufs <= DL_ADAM_MAX_BUFS buffers (numel[i] floats
  *   each: the weights AFTER the step, like :209), best_auc = auc, stale = 0, best_epoch = epoch;  else stale += 1;
- *   hist[2 epoch] = loss[0], hist[2 epoch + 1] = auc (epoch < max_epochs);  epoch += 1;  stale > patience: stopped = 1;
- *   *u2 = 0.  Once stopped the call changes nothing but *u2 = 0 (epochs the host queued before it saw the stop).
+ *   hist[2 epoch] = loss[0], hist[2 epoch + 1] = auc;  epoch += 1;  stale > patience: stopped = 1;  *u2 = 0.
+ * Once stopped, or once max_epochs epochs are recorded, the call changes nothing but *u2 = 0 (epochs the host queued
+ * before it saw the stop; the tail of a replayed graph that holds several epochs).
  * host_ring (or NULL): PINNED, device-accessible host memory of ring x 4 doubles — slot (epoch mod ring) receives
  *   { loss, auc, epoch + 1, unused } as well, for a host that reads the history behind an event without a copy.
  * state: dl_epoch_state_bytes() bytes owned by the caller, zero-initialised once (best_auc = 0 as at :189):

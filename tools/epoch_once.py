@@ -12,5 +12,5 @@ run = prepare_run(split, dev)
 x = torch.from_numpy(sg.features()).to(dev)
 torch.manual_seed(0)
 model = Disentangle(sg.n_feat, 512, 64, nfactor=8, beta=0.5, t=1).to(dev)
-run_link_prediction(model, x, run, epochs=40, lr=1e-4)
+run_link_prediction(model, x, run, epochs=40, lr=1e-4, use_graph=os.environ.get("DL_EPOCH_GRAPH", "0") == "1")
 torch.cuda.synchronize()
