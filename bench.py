@@ -484,6 +484,41 @@ def launch_check(rank: int, world: int) -> int:
     return 0
 
 
+def training_epoch_section(device, K, d, nhidden, epochs=150):
+    """One epoch of the training loop end to end (main_disentangled.py:191-214 through train.run_link_prediction: projection,
+    route, aggregate, one-pass scorer, loss, backward, Adam, validation AUC, early-stopping bookkeeping) on the
+    squirrel-shaped synthetic graph with a seeded link split (m = 5) — wall time per epoch, eager and replayed from a HIP
+    graph.  An extra of the line, not the headline metric."""
+    from disenlink_amd import native
+    from disenlink_amd.data import synthetic_graph
+    from disenlink_amd.model import Disentangle
+    from disenlink_amd.splits import make_link_split
+    from disenlink_amd.train import prepare_run, run_link_prediction
+    sg = synthetic_graph("squirrel", seed=0)
+    split = make_link_split(sg.src, sg.dst, sg.n_nodes, m=5, seed=0)
+    run = prepare_run(split, device, row_bytes=K * d * 4)
+    x = torch.from_numpy(sg.features()).to(device)
+    out = {"workload": f"squirrel-shaped synthetic graph, link split m=5: {run.n_pos + run.n_neg} train + "
+                       f"{run.label_val.numel()} validation pairs, K={K} d={d} nhid={nhidden}",
+           "epochs": epochs, "compiled_binding": bool(native.available()),
+           "bookkeeping": "device (dl_epoch_finish; history read one epoch behind)"
+           if os.environ.get("DL_DEVICE_EARLY_STOP", "1") != "0" else "host (read back every epoch)"}
+    for key, use_graph in (("eager_ms", False), ("replayed_ms", True)):
+        best = None
+        for _rep in range(2):
+            torch.manual_seed(0)
+            model = Disentangle(sg.n_feat, nhidden, d, nfactor=K, beta=0.5, t=1).to(device)
+            run_link_prediction(model, x, run, epochs=3, lr=1e-4, use_graph=use_graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = run_link_prediction(model, x, run, epochs=epochs, lr=1e-4, use_graph=use_graph)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / max(res.epochs_run, 1) * 1e3     # (incl. the graph capture when replayed)
+            best = dt if best is None else min(best, dt)
+        out[key] = best
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,7 +541,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the gathered Z/H tables (arithmetic is fp32 either way)")
     ap.add_argument("--sections", default="all",
-                    help="comma list of: headline, hbm_bound, fwd_bwd, scorer_train, projection, dense, cpu (default all)")
+                    help="comma list of: headline, hbm_bound, fwd_bwd, scorer_train, projection, dense, epoch, cpu (default all)")
     ap.add_argument("--hbm-scale", type=float, default=0.25, help="scale of the snap_patents graph of the hbm_bound block")
     ap.add_argument("--hbm-steps", type=int, default=5)
     ap.add_argument("--warm-s", type=float, default=0.3, help="warm up by time for at least this long (0: --warmup steps only)")
@@ -857,6 +892,8 @@ def main():
     Zc = Z.float().cpu() if gcpu is not None else None
     pcpu = (pairs.pu.cpu(), pairs.pv.cpu()) if gcpu is not None else None
     label_cpu = pairs.bench_label
+    if want("epoch") and args.dtype == "f32" and (args.K, args.d) == (8, 64):
+        result["training_epoch"] = training_epoch_section(device, args.K, args.d, args.nhidden)
     if want("hbm_bound"):
         del graph, pairs, Z, model, x
         torch.cuda.empty_cache()
