@@ -794,9 +794,12 @@ def main():
                         "6 per fp32 flop, against the dense bf16 peak — an upper bound: the recompute form's kernel A (layer 1 "
                         "again, dW2, dhid) still runs fp32 MFMA)",
                 "shape": {"N": N, "F": Fx, "K": K, "nhid": nh, "d": d},
-                "fwd": both(fl_f, t_f), "bwd": both(fl_b, t_b),
+                "fwd": both(fl_f, t_f),
+                # `bwd`: the RECOMPUTE form (layer 1 again; what graphs too large to keep the hidden layer take);
+                # `bwd_from_kept_hidden`: the form the training loop runs whenever the hidden layer fits (ops.keep_hidden)
+                "bwd": dict(both(fl_b, t_b), form="recompute (hidden layer not kept: graphs beyond ops.keep_hidden)"),
                 "fwd_keeping_hidden": {"avg_us": t_fk * 1e6},
-                "bwd_from_kept_hidden": both(fl_bk, t_bk),
+                "bwd_from_kept_hidden": dict(both(fl_bk, t_bk), form="kept hidden layer"),
                 # what an epoch of the training loop runs at this shape (ops.keep_hidden: the forward keeps the hidden layer,
                 # the backward starts from it; round 5: kernel A of that backward on the bf16 matrix path too, d <= 64)
                 "training_loop": {"form": "kept hidden layer" if ops.keep_hidden(N, Fx, K, nh) else "recompute",
