@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/bench_lines.sh <tag>  ->  gpurun_out/<tag>_*bench_line.json
+# The three bench lines of a round (default command, chameleon, Penn94-shaped K=16 d=128 bf16) with the PMC summaries already
+# under profiles/ — the tail of tools/profile_round.sh, for when only bench.py changed since the counter passes.
+set -u
+tag=$1
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err || { tail -n 5 gpurun_out/${tag}_bench.err; exit 1; }
+python3 bench.py --workload chameleon --sections headline,cpu --steps 20 --warmup 5 > gpurun_out/${tag}_chameleon_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
+python3 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline,fwd_bwd --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_penn94_K16_d128_bf16_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
+echo "bench_lines $tag done"
