@@ -197,24 +197,32 @@ class ChunkedRowGather:
         self.works, self._host, self._done = [], [], set()
 
     def start(self):
+        for c in range(self.part.n_chunks):
+            self.start_chunk(c)
+        return self
+
+    def start_chunk(self, c: int):
+        """Enqueue the exchange of chunk c alone (chunks must be started in order 0, 1, ...): for a producer that fills
+        the own block chunk by chunk — the exchange of chunk c then runs under the production of chunk c + 1."""
+        assert c == len(self.works), "chunks are started in order"
         B, Bc, W = self.part.block, self.part.chunk_rows, self.part.world
         full, me = self.full, self.rank
+        if W == 1:
+            self.works.append([])
+            self._host.append(None)
+            return self
         host_path = _gloo_on_device(full, self.group)
         peers = [(me + k) % W for k in range(1, W)]                # every rank starts with its right-hand neighbour
-        for c in range(self.part.n_chunks):
-            rows = lambda q: slice(q * B + c * Bc, q * B + (c + 1) * Bc)
-            if W == 1:
-                self.works.append([])
-                continue
-            send = full[rows(me)].cpu() if host_path else full[rows(me)]
-            recv = {q: (torch.empty(send.shape, dtype=send.dtype) if host_path else full[rows(q)]) for q in peers}
-            ops = []
-            for q in peers:
-                ops.append(dist.P2POp(dist.isend, send, _global_rank(self.group, q), self.group, tag=c))
-                ops.append(dist.P2POp(dist.irecv, recv[q], _global_rank(self.group, q), self.group, tag=c))
-            _count("p2p_ops", len(ops))
-            self.works.append(dist.batch_isend_irecv(ops))
-            self._host.append((send, recv) if host_path else None)
+        rows = lambda q: slice(q * B + c * Bc, q * B + (c + 1) * Bc)
+        send = full[rows(me)].cpu() if host_path else full[rows(me)]
+        recv = {q: (torch.empty(send.shape, dtype=send.dtype) if host_path else full[rows(q)]) for q in peers}
+        ops = []
+        for q in peers:
+            ops.append(dist.P2POp(dist.isend, send, _global_rank(self.group, q), self.group, tag=c))
+            ops.append(dist.P2POp(dist.irecv, recv[q], _global_rank(self.group, q), self.group, tag=c))
+        _count("p2p_ops", len(ops))
+        self.works.append(dist.batch_isend_irecv(ops))
+        self._host.append((send, recv) if host_path else None)
         return self
 
     def wait(self, c: int):
@@ -572,12 +580,18 @@ def score_local_pairs(backend, shard: Shard, Z, H, t, gather: "ChunkedRowGather 
     return prob
 
 
-def _gather_and_route(sh: "Shard", backend, Z_loc, t, group, table_dtype):
+def _gather_and_route(sh: "Shard", backend, Z_loc, t, group, table_dtype, pre=None):
     """The gathered Z table, this rank's rows of s (raw sums) and (p, a) of its entries: one blocking all-gather and one
-    routing pass, or — Shard.route_by_peer — the per-peer gather with the routing in arrival order."""
+    routing pass, or — Shard.route_by_peer — the per-peer gather with the routing in arrival order.  pre = (Z, gather)
+    from project_and_gather: the table with the own block in place and its chunked exchange already in flight."""
     K, d = Z_loc.shape[1], Z_loc.shape[2]
     dev = Z_loc.device
     s = torch.empty((sh.n_pad, K), dtype=torch.float32, device=dev)
+    if pre is not None:
+        Z, gather = pre
+        gather.wait_all()
+        p, a = backend.route_fwd(sh.graph, Z, t, s)
+        return Z, s, p, a
     if sh.world == 1 and Z_loc.shape[0] == sh.n_pad:           # one rank: its rows ARE the table (no copy, no collective)
         Z = Z_loc.detach().to(table_dtype).contiguous()
         p, a = backend.route_fwd(sh.graph, Z, t, s)
@@ -598,13 +612,13 @@ class ShardedHotPath(torch.autograd.Function):
     """Z_loc [rows,K,d] -> (H_loc [rows,K,d], prob_loc [local pairs]) with the collectives inside."""
 
     @staticmethod
-    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype=torch.float32):
+    def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype=torch.float32, pre=None):
         """table_dtype: storage type of the gathered Z / H tables (torch.bfloat16 halves the bytes of both all-gathers —
         the step is bound by them on large graphs; arithmetic and every gradient stay fp32)."""
         sh = shard
         K, d = Z_loc.shape[1], Z_loc.shape[2]
         dev = Z_loc.device
-        Z, s, p, a = _gather_and_route(sh, backend, Z_loc, t, group, table_dtype)
+        Z, s, p, a = _gather_and_route(sh, backend, Z_loc, t, group, table_dtype, pre)
         all_gather_rows(s, sh.lo, sh.hi, group)
         H = torch.empty_like(Z)
         backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
@@ -641,7 +655,7 @@ class ShardedHotPath(torch.autograd.Function):
         if gH_loc is not None:
             dH[sh.lo:sh.hi] += gH_loc
         _route_aggregate_bwd_sharded(be, sh, Z, beta, t, ctx.p, a, s, dH, dZ, group)
-        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None
+        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None, None
 
 
 def gather_grad_rows(dH: torch.Tensor, sh: "Shard", group, wire_dtype) -> None:
@@ -683,7 +697,7 @@ class ShardedHotPathLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Z_loc, shard: Shard, backend, beta: float, t: float, group, table_dtype, label, weight,
-                scorer: str = "one_pass"):
+                scorer: str = "one_pass", pre=None):
         """scorer = "one_pass": dl_score_pairs_train over the rank's incidence rows; "terms": the rank scores every pair
         that touches its nodes with the forward scorer (keeping the per-factor terms), forms the BCE gradient of those
         pairs itself and runs the coefficient-gather backward (Shard.touching) — for shapes whose one-pass kernel is slow
@@ -692,7 +706,7 @@ class ShardedHotPathLoss(torch.autograd.Function):
         sh = shard
         K, d = Z_loc.shape[1], Z_loc.shape[2]
         dev = Z_loc.device
-        Z, s, p, a = _gather_and_route(sh, backend, Z_loc, t, group, table_dtype)
+        Z, s, p, a = _gather_and_route(sh, backend, Z_loc, t, group, table_dtype, pre)
         all_gather_rows(s, sh.lo, sh.hi, group)
         H = torch.empty_like(Z)
         backend.aggregate_fwd(sh.graph, Z, beta, p, a, s, H)
@@ -730,7 +744,34 @@ class ShardedHotPathLoss(torch.autograd.Function):
         if gH_loc is not None:
             dH[sh.lo:sh.hi] += gH_loc
         _route_aggregate_bwd_sharded(be, sh, Z, ctx.beta, ctx.t, ctx.p, a, s, dH, dZ, ctx.group)
-        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None, None, None, None
+        return dZ[sh.lo:sh.hi].clone(), None, None, None, None, None, None, None, None, None, None
+
+
+def project_and_gather(model, x_pad: torch.Tensor, shard: Shard, group, table_dtype):
+    """(Z_loc, pre): the projection of this rank's rows (model.py:106; autograd input of the sharded hot path) and — when
+    the partition has row chunks (Partition.n_chunks > 1), there is more than one rank and DL_Z_OVERLAP != 0 — the Z
+    table with this rank's block in place and its exchange IN FLIGHT: chunk c of the local rows is projected, stored to its
+    place in the table and handed to the direct exchange (ChunkedRowGather.start_chunk) while chunk c + 1 is projected, so
+    only the last chunk's transfer is exposed.  The K MLPs act row by row, so the chunks'
+    outputs are the rows of the whole projection; the weight gradients become a sum over the chunks' backward passes (a
+    different summation order from the single launch: equal to rounding, not bit for bit).  pre = None otherwise (the hot
+    path then gathers Z itself, in one collective)."""
+    part = shard.part
+    if shard.world == 1 or part.n_chunks <= 1 or os.environ.get("DL_Z_OVERLAP", "1") == "0" or \
+            (dist.is_initialized() and dist.get_world_size(group) == 1):
+        return model.project(x_pad), None
+    Bc = part.chunk_rows
+    pieces, Z, gather = [], None, None
+    for c in range(part.n_chunks):
+        Zc = model.project(x_pad[c * Bc:(c + 1) * Bc])
+        if Z is None:
+            Z = torch.empty((shard.n_pad,) + tuple(Zc.shape[1:]), dtype=table_dtype, device=Zc.device)
+            gather = ChunkedRowGather(Z, part, shard.rank, group)
+        with torch.no_grad():
+            Z[shard.lo + c * Bc: shard.lo + (c + 1) * Bc] = Zc.detach().to(table_dtype)
+        gather.start_chunk(c)
+        pieces.append(Zc)
+    return torch.cat(pieces, dim=0), (Z, gather)
 
 
 def sharded_forward(model, x_local: torch.Tensor, shard: Shard, backend=None, group=None):
@@ -738,9 +779,9 @@ def sharded_forward(model, x_local: torch.Tensor, shard: Shard, backend=None, gr
     r1 - r0 rows of emb_local are the real nodes shard.local_real_rows().  The gathered tables take the module's
     ``table_dtype`` (bf16: half the all-gather bytes)."""
     backend = backend or HipBackend()
-    Z_loc = model.project(shard.pad_rows(x_local))
-    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group,
-                                       getattr(model, "table_dtype", torch.float32))
+    tab = getattr(model, "table_dtype", torch.float32)
+    Z_loc, pre = project_and_gather(model, shard.pad_rows(x_local), shard, group, tab)
+    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group, tab, pre)
     return H_loc.reshape(H_loc.shape[0], -1), prob
 
 
@@ -751,7 +792,7 @@ def sharded_forward_loss(model, x_local: torch.Tensor, shard: Shard, label: torc
     loss is the all-reduced sum of loss_local."""
     backend = backend or HipBackend()
     tab = getattr(model, "table_dtype", torch.float32)
-    Z_loc = model.project(shard.pad_rows(x_local))
+    Z_loc, pre = project_and_gather(model, shard.pad_rows(x_local), shard, group, tab)
     K, d = Z_loc.shape[1], Z_loc.shape[2]
     # Which scorer: the module's own rule (ops.one_pass_scorer_wanted); shapes without a one-pass kernel — and wide bf16 rows
     # that have only the group-per-entry one — take the forward scorer with stored terms + the coefficient-gather backward
@@ -764,9 +805,9 @@ def sharded_forward_loss(model, x_local: torch.Tensor, shard: Shard, label: torc
     scorer = "one_pass" if has_one and (want_one or not has_terms) else ("terms" if has_terms else None)
     if scorer is not None:
         H_loc, prob, loss = ShardedHotPathLoss.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature),
-                                                     group, tab, label, weight, scorer)
+                                                     group, tab, label, weight, scorer, pre)
         return H_loc.reshape(H_loc.shape[0], -1), prob, loss
-    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group, tab)
+    H_loc, prob = ShardedHotPath.apply(Z_loc, shard, backend, float(model.beta), float(model.temperature), group, tab, pre)
     q0, q1 = shard.pair_lo, shard.pair_hi
     y, w = label[q0:q1], weight[q0:q1]
     bce = torch.nn.functional.binary_cross_entropy(prob, y, weight=w, reduction="sum") if q1 > q0 else prob.sum() * 0.0

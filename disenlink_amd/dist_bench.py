@@ -490,20 +490,58 @@ def _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_
         loss.backward()
         return dd.allreduce_gradients(model)
 
-    how = tstep()
-    tstep()
-    ts = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tstep()
-        torch.cuda.synchronize()
-        dist.barrier()
-        ts.append((time.perf_counter() - t0) / steps)
-    step_s = _median_max_over_ranks(ts, red_dev)
+    def timed():
+        how = tstep()
+        tstep()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tstep()
+            torch.cuda.synchronize()
+            dist.barrier()
+            ts.append((time.perf_counter() - t0) / steps)
+        return _median_max_over_ranks(ts, red_dev), how
+
+    # The Z table's exchange: ONE all-gather after the projection (the default), or — the partition has row chunks —
+    # the projection in row chunks with every chunk's direct exchange in flight under the next chunk's projection
+    # (dist.project_and_gather).  Both are timed in the run; the default first, the other is used only if it is >= 5 %
+    # faster on the slowest rank and ran on EVERY rank (DL_Z_OVERLAP=0/1 forces one).
+    forced = os.environ.get("DL_Z_OVERLAP")
+    forms = {"one_gather": "0", "chunks_in_flight": "1"}
+    if world == 1 or part.n_chunks <= 1:
+        forms = {"one_gather": "0"}
+    elif forced in ("0", "1"):
+        forms = {k: v for k, v in forms.items() if v == forced}
+    z_ab, z_err, how = {}, {}, None
+    try:
+        for name, env in forms.items():
+            os.environ["DL_Z_OVERLAP"] = env
+            err = None
+            try:
+                tm, how_f = timed()
+            except Exception as e:                  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"[:300]
+            if _all_ok(err is None, ctrl):
+                z_ab[name], how = tm, (how_f if how is None or name == "one_gather" else how)
+            else:
+                if len(forms) == 1 or name == "one_gather":
+                    raise RuntimeError(f"the sharded training step failed on a rank ({err or 'another rank'})")
+                z_err[name] = err or "failed on another rank"
+    finally:
+        if forced is None:
+            os.environ.pop("DL_Z_OVERLAP", None)
+        else:
+            os.environ["DL_Z_OVERLAP"] = forced
+    z_form = _pick(z_ab, "one_gather")
+    step_s = z_ab[z_form]
     out = {"ms_per_step": step_s * 1e3, "steps": steps, "gradient_allreduce": how,
+           "z_exchange": {"used": z_form, "ms_per_step": {k: v * 1e3 for k, v in z_ab.items()}, "refused": z_err,
+                          "forced": forced, "chunks": part.n_chunks,
+                          "what": "one_gather = one all-gather of Z behind the projection; chunks_in_flight = projection in row "
+                                  "chunks, each chunk's direct exchange under the next chunk's projection"},
            "scorer": "sharded_forward_loss's choice: one pass over the rank's incidence rows (fp32 tables, bf16 beyond 512 MiB), "
                      "else forward-with-terms + coefficient-gather backward over the pairs touching the rank's nodes",
            "what": "sharded_forward_loss + backward + allreduce_gradients, max over ranks, median of 3 blocks"}

@@ -476,3 +476,68 @@ def test_sharded_training_step_from_the_touching_pairs(world, table):
     want = np.flatnonzero(((ppu >= sh.lo) & (ppu < sh.hi)) | ((ppv >= sh.lo) & (ppv < sh.hi)))
     assert np.array_equal(idx.numpy(), want) and a1 - a0 == sh.pair_hi - sh.pair_lo
     assert np.array_equal(idx.numpy()[a0:a1], np.arange(sh.pair_lo, sh.pair_hi))
+
+
+def _overlap_worker(rank, world, port, pb, sd, out, overlap, n_chunks):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DL_Z_OVERLAP=overlap)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disenlink_amd import dist as dd
+        from disenlink_amd.model import Disentangle
+        from oracle_backend import OracleBackend
+        torch.set_num_threads(1)
+        model = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"])
+        model.load_state_dict(sd)
+        shard = dd.Shard.build(rank, world, pb["N"], pb["src"], pb["dst"], pb["pu"], pb["pv"], "cpu", seg_len=4,
+                               n_chunks=n_chunks)
+        r0, r1 = shard.local_real_rows()
+        P = pb["pu"].size
+        label, weight = torch.from_numpy(pb["label"]), torch.full((P,), 1.0 / P)
+        calls = []
+        orig = model.project
+        model.project = lambda x: (calls.append(int(x.shape[0])), orig(x))[1]        # rows per projection launch
+        dd.reset_message_counts()
+        emb, prob, loss = dd.sharded_forward_loss(model, torch.from_numpy(pb["x"][r0:r1]), shard, label, weight,
+                                                  backend=OracleBackend())
+        fwd_counts = dd.reset_message_counts()
+        model.zero_grad()
+        loss.backward()
+        dd.allreduce_gradients(model)
+        out[rank] = dict(emb=emb.detach().numpy(), prob=prob.detach().numpy(), loss=float(loss.detach()), calls=calls,
+                         counts=fwd_counts, block=shard.part.block,
+                         grads={k: v.grad.numpy().copy() for k, v in model.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_chunks", [(2, 2), (3, 4)])
+def test_projection_in_row_chunks_with_the_z_exchange_in_flight(world, n_chunks):
+    """dist.project_and_gather (the Z gather under the projection): with a chunked partition the
+    local rows are projected chunk by chunk and every chunk's direct exchange is started before the next chunk is
+    projected; against DL_Z_OVERLAP=0 (one projection, one all-gather) on the same problem: the same embedding rows,
+    probabilities and loss, the same weight gradients to rounding (a sum over the chunks' backward passes), n_chunks
+    projection launches of block / n_chunks rows, and the forward's Z all-gather replaced by n_chunks batches of
+    2 (W - 1) point-to-point messages."""
+    from disenlink_amd.model import Disentangle
+    pb = _skewed_problem()
+    torch.manual_seed(0)
+    sd = Disentangle(pb["F"], pb["nhid"], pb["d"], nfactor=pb["K"], beta=pb["beta"], t=pb["t"]).state_dict()
+    res = {}
+    for overlap in ("1", "0"):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_overlap_worker, args=(world, _free_port(), pb, sd, out, overlap, n_chunks), nprocs=world, join=True)
+        res[overlap] = {r: out[r] for r in range(world)}
+    for r in range(world):
+        on, off = res["1"][r], res["0"][r]
+        np.testing.assert_allclose(on["emb"], off["emb"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(on["prob"], off["prob"], rtol=1e-6, atol=1e-7)
+        assert abs(on["loss"] - off["loss"]) <= 1e-6 * max(1.0, abs(off["loss"]))
+        for k, g in off["grads"].items():
+            scale = max(np.abs(g).max(), 1e-6)
+            assert np.abs(on["grads"][k] - g).max() <= 2e-5 * scale, (r, k)
+        assert off["calls"] == [off["block"]] and on["calls"] == [on["block"] // n_chunks] * n_chunks
+        assert on["counts"]["collectives"] == off["counts"]["collectives"] - 1
+        assert on["counts"]["p2p_ops"] == off["counts"]["p2p_ops"] + n_chunks * 2 * (world - 1)
