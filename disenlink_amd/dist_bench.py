@@ -451,7 +451,8 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     # the forward record stands
     if os.environ.get("DL_BENCH_TRAIN", "1") != "0":
         try:
-            out["training_step"] = _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_loc, red_dev)
+            out["training_step"] = _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_loc, red_dev,
+                                                  chunked_ok="chunked" in h_ab)
         except Exception as e:                      # noqa: BLE001 — a rank that fails INSIDE a collective cannot be rescued
             # (its peers block there); what this catches is a failure before the first collective of the step or after
             # the last: recorded, and the run ends here on every rank rather than entering the next block out of step
@@ -464,7 +465,7 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     return out
 
 
-def _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_loc, red_dev) -> dict:
+def _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_loc, red_dev, chunked_ok=True) -> dict:
     """One sharded training step = dist.sharded_forward_loss (all-gathers of Z, s, H; one-pass scorer over the rank's
     incidence rows) + backward (dH / ds gathers, routing / aggregation backward, projection backward) + ONE gradient
     all-reduce; labels / weights are synthetic (timing only).  Strong-scaling blocks also time the same step unsharded on
@@ -511,7 +512,9 @@ def _training_step(spec, args, rank, world, device, ctrl, prob, shard, model, x_
     # faster on the slowest rank and ran on EVERY rank (DL_Z_OVERLAP=0/1 forces one).
     forced = os.environ.get("DL_Z_OVERLAP")
     forms = {"one_gather": "0", "chunks_in_flight": "1"}
-    if world == 1 or part.n_chunks <= 1:
+    if world == 1 or part.n_chunks <= 1 or (not chunked_ok and forced != "1"):
+        # (chunked_ok: the same direct chunk exchange ran for H in the forward's A/B above — a transport that was refused
+        # there is not tried again here)
         forms = {"one_gather": "0"}
     elif forced in ("0", "1"):
         forms = {k: v for k, v in forms.items() if v == forced}
