@@ -251,6 +251,32 @@ Tensor auc_pair_counts(const Tensor& score, const Tensor& pos_idx, const Tensor&
     return u2;
 }
 
+// ---------------------------------------------------------------------------- end of an epoch on the device (main_disentangled.py:199-214)
+// early_stop.DeviceEarlyStop.finish without ctypes: the validation counts of `score_val` added to u2, then dl_epoch_finish
+// (AUC, best-weights copy, patience, history; ring_ptr = address of the pinned host ring, 0 for none).
+void epoch_finish(const Tensor& score_val, const Tensor& pos_idx, const Tensor& neg_idx, const Tensor& u2, const Tensor& loss,
+                  at::TensorList params, at::TensorList best, const Tensor& state, const Tensor& hist, int64_t ring_ptr,
+                  int64_t ring, double denom2, int64_t max_epochs, int64_t patience) {
+    TORCH_CHECK(score_val.is_cuda() && score_val.scalar_type() == at::kFloat && score_val.is_contiguous(), "score_val: dense CUDA fp32");
+    TORCH_CHECK(loss.is_cuda() && loss.scalar_type() == at::kFloat && loss.numel() == 1, "loss: one CUDA fp32 value");
+    TORCH_CHECK(pos_idx.scalar_type() == at::kLong && neg_idx.scalar_type() == at::kLong && u2.scalar_type() == at::kLong, "index sets / u2: int64");
+    const int n = (int)params.size();
+    TORCH_CHECK(n <= DL_ADAM_MAX_BUFS && (int)best.size() == n, "epoch_finish: buffer lists");
+    TORCH_CHECK((size_t)state.numel() * state.element_size() >= dl_epoch_state_bytes() && hist.scalar_type() == at::kDouble, "state / hist");
+    const float* pp[DL_ADAM_MAX_BUFS]; float* bp[DL_ADAM_MAX_BUFS]; size_t numel[DL_ADAM_MAX_BUFS];
+    for (int b = 0; b < n; ++b) {
+        TORCH_CHECK(params[b].scalar_type() == at::kFloat && params[b].is_contiguous() && best[b].is_contiguous() &&
+                    best[b].numel() == params[b].numel(), "epoch_finish: buffer ", b);
+        pp[b] = params[b].data_ptr<float>(); bp[b] = best[b].data_ptr<float>(); numel[b] = (size_t)params[b].numel();
+    }
+    auto* u2p = reinterpret_cast<unsigned long long*>(u2.data_ptr<int64_t>());
+    check(dl_auc_pair_counts_add(score_val.data_ptr<float>(), pos_idx.data_ptr<int64_t>(), (int)pos_idx.numel(),
+                                 neg_idx.data_ptr<int64_t>(), (int)neg_idx.numel(), u2p, stream()), "dl_auc_pair_counts_add");
+    check(dl_epoch_finish(n, pp, bp, numel, loss.data_ptr<float>(), u2p, denom2, state.data_ptr(), hist.data_ptr<double>(),
+                          (long long)max_epochs, (long long)patience, reinterpret_cast<double*>(ring_ptr), (int)ring, stream()),
+          "dl_epoch_finish");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(disenlink_native, m) {
@@ -260,6 +286,8 @@ TORCH_LIBRARY(disenlink_native, m) {
     m.def("adam_step(Tensor[] bufs, Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, Tensor state, float lr, float beta1, "
           "float beta2, float eps, float weight_decay, int host_step=0) -> ()");
     m.def("auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor");
+    m.def("epoch_finish(Tensor score_val, Tensor pos_idx, Tensor neg_idx, Tensor u2, Tensor loss, Tensor[] params, Tensor[] best, "
+          "Tensor state, Tensor hist, int ring_ptr, int ring, float denom2, int max_epochs, int patience) -> ()");
     m.def("abi_version() -> str");
 }
 
@@ -272,6 +300,7 @@ TORCH_LIBRARY_IMPL(disenlink_native, CUDA, m) {
     m.impl("project_stacked", project_stacked);
     m.impl("adam_step", adam_step);
     m.impl("auc_pair_counts", auc_pair_counts);
+    m.impl("epoch_finish", epoch_finish);
 }
 TORCH_LIBRARY_IMPL(disenlink_native, CompositeExplicitAutograd, m) {
     m.impl("abi_version", []() { return std::string(dl_version()); });

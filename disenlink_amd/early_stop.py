@@ -48,6 +48,8 @@ class DeviceEarlyStop:
         # pinned host memory the kernel writes (loss, auc, epoch + 1) into directly: no copy launch per epoch
         self.ring = torch.zeros(self.RING, 4, dtype=torch.float64).pin_memory()
         self.events = [torch.cuda.Event() for _ in range(self.EVENTS)]
+        from . import native
+        self._native = native.available()
 
     @staticmethod
     def usable(model, x, val_plan) -> bool:
@@ -72,7 +74,6 @@ class DeviceEarlyStop:
     def finish(self, loss: torch.Tensor, score_val: torch.Tensor):
         """The epoch's last two launches: validation counts of `score_val` (float32, the plan's label order) into u2, then
         the bookkeeping.  `loss`: the 0-dim float32 loss of the epoch's forward."""
-        st = torch.cuda.current_stream().cuda_stream
         score_val = score_val.detach().reshape(-1)
         if score_val.dtype != torch.float32 or not score_val.is_contiguous():
             raise RuntimeError("DeviceEarlyStop.finish: contiguous float32 scores expected")
@@ -81,6 +82,12 @@ class DeviceEarlyStop:
             raise RuntimeError("DeviceEarlyStop.finish: a float32 scalar loss expected")
         self._alive = (loss, score_val)                             # the launches are asynchronous
         p = self.plan
+        if self._native:                                            # the same two launches from the compiled binding
+            from . import native
+            native.epoch_finish(score_val, p.pos_idx, p.neg_idx, self.u2, loss.reshape(1), self.bufs, self.best, self.state,
+                                self.hist, self.ring.data_ptr(), self.RING, self.denom2, self.max_epochs, self.patience)
+            return
+        st = torch.cuda.current_stream().cuda_stream
         self.check(self.lib.dl_auc_pair_counts_add(score_val.data_ptr(), p.pos_idx.data_ptr(), p.n_pos, p.neg_idx.data_ptr(),
                                                    p.n_neg, self.u2.data_ptr(), st), "dl_auc_pair_counts_add")
         self.check(self.lib.dl_epoch_finish(len(self.bufs), self._p, self._b, self._numel, loss.data_ptr(), self.u2.data_ptr(),

@@ -100,3 +100,10 @@ def adam_step(bufs, params, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, w
 def auc_pair_counts(score: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor) -> torch.Tensor:
     """int64[1]: sum over positives of (2 #{negatives below} + #{negatives equal}) — dl_auc_pair_counts."""
     return torch.ops.disenlink_native.auc_pair_counts(score, pos_idx, neg_idx)
+
+
+def epoch_finish(score_val, pos_idx, neg_idx, u2, loss, params, best, state, hist, ring_ptr: int, ring: int, denom2: float,
+                 max_epochs: int, patience: int) -> None:
+    """early_stop.DeviceEarlyStop.finish in one C++ call: dl_auc_pair_counts_add + dl_epoch_finish."""
+    torch.ops.disenlink_native.epoch_finish(score_val, pos_idx, neg_idx, u2, loss, params, best, state, hist, int(ring_ptr),
+                                            int(ring), float(denom2), int(max_epochs), int(patience))

@@ -590,7 +590,10 @@ def test_compiled_torch_binding_builds_loads_and_registers_its_operator():
                                   "Tensor[] params, bool keep_hid, Tensor? xplanes) -> Tensor",
                "adam_step": "disenlink_native::adam_step(Tensor[] bufs, Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, "
                             "Tensor state, float lr, float beta1, float beta2, float eps, float weight_decay, int host_step=0) -> ()",
-               "auc_pair_counts": "disenlink_native::auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor"}
+               "auc_pair_counts": "disenlink_native::auc_pair_counts(Tensor score, Tensor pos_idx, Tensor neg_idx) -> Tensor",
+               "epoch_finish": "disenlink_native::epoch_finish(Tensor score_val, Tensor pos_idx, Tensor neg_idx, Tensor u2, Tensor loss, "
+                               "Tensor[] params, Tensor[] best, Tensor state, Tensor hist, int ring_ptr, int ring, float denom2, "
+                               "int max_epochs, int patience) -> ()"}
     for name, want in schemas.items():
         assert str(getattr(torch.ops.disenlink_native, name).default._schema) == want, name
     assert torch.ops.disenlink_native.abi_version() == _lib.load().dl_version().decode()
