@@ -53,6 +53,7 @@ EXPORTS = {
     "dl_host_plan_free": (None, [C.POINTER(DlHostPlan)]),
     "dl_version": (C.c_char_p, []),
     "dl_last_error": (C.c_char_p, []),
+    "dl_config_reload": (None, []),
     "dl_has_fast_path": (_i, [_i, _i]),
     "dl_has_fast_path_dtype": (_i, [_i, _i, _i]),
     "dl_set_force_generic": (_i, [_i]),
@@ -137,3 +138,9 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().dl_last_error().decode(errors="replace")
         raise DisenlinkHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def config_reload() -> None:
+    """Have the library read its environment switches again (it reads them once, at first use: csrc/dl_config.h).
+    For tests and A/B scripts that change a DL_* variable inside a running process."""
+    load().dl_config_reload()

@@ -103,7 +103,7 @@ using namespace dl;
 
 extern "C" {
 
-const char* dl_version(void) { return "disenlink_hip 0.7 (gfx950)"; }
+const char* dl_version(void) { return "disenlink_hip 0.8 (gfx950)"; }
 const char* dl_last_error(void) { return g_err; }
 int dl_has_fast_path(int K, int d) { return fast_supported(K, d, DL_F32) ? 1 : 0; }
 int dl_has_fast_path_dtype(int K, int d, dl_dtype dtype) { return fast_supported(K, d, (int)dtype) ? 1 : 0; }

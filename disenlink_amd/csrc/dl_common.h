@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "disenlink_hip.h"
+#include "dl_config.h"
 
 #define DL_WAVE 64
 

@@ -1,0 +1,368 @@
+// Shared pieces of the tuned gfx950 kernels (dl_route.hip, dl_aggregate.hip, dl_bwd.hip, dl_score.hip, dl_train.hip):
+// typed 16-byte chunks, the lane geometry, the unit reduction through LDS, the row combine, shape lists and dispatch.
+//
+//
+// Work decomposition: the plan cuts every CSR row into segments of <= seg_len (<= 64) consecutive
+// entries; ONE 64-lane wave owns one segment, so a hub row of thousands of edges is spread over
+// many waves and CUs while a median row (tens of edges) is a single wave.  Inside a wave, a group
+// of G = D/4 lanes owns one entry: lane c of the group holds elements 4c..4c+3 (16 bytes fp32, 8 bytes
+// bf16) of every factor slice, i.e. one neighbour row Z[j] (contiguous in HBM) is fetched by K
+// coalesced loads per lane and 64/G entries are in flight per wave iteration.
+//
+// Per-entry scalars (column, routing factor, weights) are loaded once per segment, one entry per
+// lane, and handed to the groups by shuffles: no dependent index load inside the loop.
+//
+// The K per-factor dot products are reduced with a TRANSPOSED butterfly (dl_common.h): after
+// log2(G) exchange steps every lane owns the complete dot product of one factor, so exp, softmax
+// weight and the per-factor terms are computed once per factor, not once per lane.
+//
+// A workgroup (4 waves) serves 4 consecutive segment positions; the segments of a row sit in aligned
+// runs (UNITS, dl_csr_plan) that the workgroup sums on chip through LDS, in segment order.  Rows of one
+// unit (<= 4 segments) write their outputs directly; only rows with several units write per-unit
+// partials (fp32, in the caller's workspace) that a combine kernel sums in unit order.  No float
+// atomics anywhere: results are bitwise reproducible, and independent of how the rows are sharded.
+//
+// Tables Z and H may be stored as fp32 or bf16 (dl_dtype); all arithmetic and all gradients are fp32.
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+#include "dl_common.h"
+#include "dl_kernels.h"
+
+namespace dl {
+namespace fast {
+
+// ---------------------------------------------------------------------------- typed 16-byte chunks
+typedef unsigned short bf16_t;      // raw bf16 bits
+
+template <int VEC>
+struct Chunk {
+    float v[VEC];
+};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned int hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ unsigned int f32_to_bf16(float f) {   // round to nearest even; NaN stays NaN
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <typename T>
+struct Tab;
+template <>
+struct Tab<float> {
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ Chunk<4> load(const float* p) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        return Chunk<4>{{q.x, q.y, q.z, q.w}};
+    }
+    static __device__ __forceinline__ void store(float* p, const Chunk<4>& c) {
+        *reinterpret_cast<float4*>(p) = make_float4(c.v[0], c.v[1], c.v[2], c.v[3]);
+    }
+};
+// bf16 tables keep the fp32 lane geometry (4 elements per lane, 8-byte loads): the same registers
+// per lane as the fp32 kernels, half the bytes per gathered row.  (8 elements per lane was tried:
+// it doubles the fp32 working set per lane and halves the occupancy.)
+template <>
+struct Tab<bf16_t> {
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ Chunk<4> load(const bf16_t* p) {
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        return Chunk<4>{{bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu),
+                         bf16_to_f32(q.y >> 16)}};
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const Chunk<4>& c) {
+        uint2 q;
+        q.x = f32_to_bf16(c.v[0]) | (f32_to_bf16(c.v[1]) << 16);
+        q.y = f32_to_bf16(c.v[2]) | (f32_to_bf16(c.v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = q;
+    }
+};
+
+// fp32 arrays (gradients, partials, LDS) accessed VEC elements at a time
+template <int VEC>
+__device__ __forceinline__ Chunk<VEC> load_f32(const float* p) {
+    Chunk<VEC> c;
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p + i);
+        c.v[i] = q.x; c.v[i + 1] = q.y; c.v[i + 2] = q.z; c.v[i + 3] = q.w;
+    }
+    return c;
+}
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* p, const Chunk<VEC>& c) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4)
+        *reinterpret_cast<float4*>(p + i) = make_float4(c.v[i], c.v[i + 1], c.v[i + 2], c.v[i + 3]);
+}
+template <int VEC>
+__device__ __forceinline__ Chunk<VEC> zero_chunk() {
+    Chunk<VEC> c;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) c.v[i] = 0.0f;
+    return c;
+}
+template <int VEC>
+__device__ __forceinline__ float dot(const Chunk<VEC>& x, const Chunk<VEC>& y) {
+    float r = x.v[0] * y.v[0];
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) r = fmaf(x.v[i], y.v[i], r);
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void fma_chunk(Chunk<VEC>& acc, float w, const Chunk<VEC>& x) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(w, x.v[i], acc.v[i]);
+}
+template <int G, int VEC>
+__device__ __forceinline__ void across_groups_sum_chunk(Chunk<VEC>& c) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) c.v[i] = across_groups_sum<G>(c.v[i]);
+}
+
+template <int K, int D, typename T>
+struct Geo {
+    static constexpr int VEC = Tab<T>::VEC;
+    static constexpr int G = D / VEC;             // lanes per entry
+    static constexpr int EPW = DL_WAVE / G;       // entries per wave iteration
+    static constexpr int ROW = K * D;             // elements per node row
+    using FL = FactorLanes<G, K>;
+    static_assert(D % VEC == 0 && (G & (G - 1)) == 0 && G <= DL_WAVE, "D must be VEC * a power of two <= 64");
+};
+
+// Per-lane softmax pieces of one entry after the transposed reduce: this lane owns factors
+// kb .. kb+VPL-1; ex[i] = exp(sigma/t); S = sum over all K factors (group-wide).
+template <int K, int G>
+__device__ __forceinline__ float lane_exps(float* part, int c, float t, float (&ex)[FactorLanes<G, K>::VPL]) {
+    using FL = FactorLanes<G, K>;
+    TransposedReduce<FL::KP, G / 2>::run(part, c);
+    const int kb = FL::factor_base(c);
+    float mine = 0.0f;
+#pragma unroll
+    for (int i = 0; i < FL::VPL; ++i) {
+        ex[i] = expf(div_t(part[i], t));
+        if (FL::primary(c) && kb + i < K) mine += ex[i];
+    }
+    return group_allreduce_sum<G>(mine);
+}
+
+// 4 consecutive elements of a table (fp32 or bf16 storage) as a float4
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu),
+                       bf16_to_f32(q.y >> 16));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
+    uint2 q;
+    q.x = f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16);
+    q.y = f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+// Streaming (non-temporal) store: the line is not kept in the caches for re-use.  For an output table far larger than the
+// caches (the H rows of the aggregation where HBM binds) that leaves the L2 / Infinity Cache to the gathered slices and
+// the normalisers: snap-patents x0.25 aggregation 789 -> 750 us.  On cache-resident graphs the next kernel WANTS the rows
+// in cache (the scorer reads H right away): the caller decides per launch.
+__device__ __forceinline__ void store4_stream(float* p, const float4& v) {
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    vf4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(p));
+}
+__device__ __forceinline__ void store4_stream(bf16_t* p, const float4& v) {
+    typedef unsigned int vu2 __attribute__((ext_vector_type(2)));
+    vu2 q = {f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16), f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16)};
+    __builtin_nontemporal_store(q, reinterpret_cast<vu2*>(p));
+}
+
+// ---------------------------------------------------------------------------- unit reduction through LDS
+// A segment kernel ends with per-GROUP partial results: lane c of group g holds elements kk*D + c*VEC .. of every factor
+// kk, summed over the entries its group walked.  Adding the 64/G groups of a wave with cross-lane butterflies costs
+// 2 log2(64/G) moves + adds per VALUE (K*VEC of them, twice that in the scorer backward): a third of all vector
+// instructions of these kernels.  Instead every group stages its partial row in the wave's LDS region and, after the
+// workgroup barrier, the head wave of each unit adds groups and segments straight out of LDS — in a fixed order
+// (segment by segment, group 0 .. NG-1 inside) — with all 64 lanes at work: lane l ends up with the float4s
+// x = q*64 + l of the row.  Where the staged rows would not leave room for two workgroups per CU (K = 16, d = 128 in the
+// scorer backward) the groups are added in registers first and only group 0 is staged.
+template <int K, int D, int VEC>
+__device__ __forceinline__ void stage_row(float* dst, const Chunk<VEC> (&acc)[K], int c) {
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) store_f32<VEC>(dst + kk * D + c * VEC, acc[kk]);
+}
+
+template <int K, int D, typename T, int NROWS, bool NO_GROUP_ROWS = false>
+struct Stage {
+    using GE = Geo<K, D, T>;
+    static constexpr int VEC = GE::VEC, G = GE::G;
+    static constexpr int NG = DL_WAVE / G;                         // lane groups per wave
+    static constexpr int ROWF = NROWS * GE::ROW;                   // floats of one wave's result
+    // Measured (profiles/r2p vs r2m): the two-row scorer backward gains 5 % from staging the groups (64 cross-lane sums
+    // fewer per wave); the one-row kernels do not — their waves are short, and on low-degree graphs (snap-patents-shaped:
+    // ~8 entries per row) writing four group rows per wave instead of one made the aggregate kernel 29 % slower.
+    static constexpr bool GROUPS_IN_LDS = !NO_GROUP_ROWS && NROWS == 2 && (size_t)WAVES_PER_BLOCK * NG * ROWF * sizeof(float) <= 64 * 1024;
+    static constexpr int SG = GROUPS_IN_LDS ? NG : 1;              // group rows staged per wave
+    static constexpr int FLOATS = WAVES_PER_BLOCK * SG * ROWF;     // LDS floats of the workgroup
+    static constexpr int F4 = ROWF / 4;
+    static constexpr int NQ = (F4 + DL_WAVE - 1) / DL_WAVE;
+    static_assert(ROWF % 4 == 0, "row length must be a multiple of 4 floats");
+
+    // this wave's region: [SG][ROWF] floats
+    static __device__ __forceinline__ float* region(float* red, int wave) { return red + (size_t)wave * SG * ROWF; }
+
+    // stage result row `r` (0 .. NROWS-1) of this lane's group
+    static __device__ __forceinline__ void put(float* red, int wave, int grp, int c, Chunk<VEC> (&acc)[K], int r) {
+        if constexpr (GROUPS_IN_LDS) {
+            stage_row<K, D, VEC>(region(red, wave) + grp * ROWF + r * GE::ROW, acc, c);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) across_groups_sum_chunk<G>(acc[kk]);
+            if (grp == 0) stage_row<K, D, VEC>(region(red, wave) + r * GE::ROW, acc, c);
+        }
+    }
+
+    // head wave, after the barrier: sum of the unit's n waves (segments), groups 0 .. SG-1 inside each
+    static __device__ __forceinline__ void sum(const float* red, int wave, int n, int lane, float4 (&out)[NQ]) {
+        const float4* red4 = reinterpret_cast<const float4*>(red);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            out[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x < F4) {
+                const float4* base = red4 + (size_t)wave * SG * F4 + x;
+                out[q] = base[0];
+#pragma unroll
+                for (int g = 1; g < SG; ++g) {
+                    const float4 v = base[g * F4];
+                    out[q].x += v.x; out[q].y += v.y; out[q].z += v.z; out[q].w += v.w;
+                }
+                for (int u = 1; u < n; ++u) {
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) {
+                        const float4 v = base[(u * SG + g) * F4];
+                        out[q].x += v.x; out[q].y += v.y; out[q].z += v.z; out[q].w += v.w;
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------- pair scorer
+// Stage the u rows of Z and H (as fp32) in this wave's LDS region.
+template <int K, int D, typename T>
+__device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ Z, const T* __restrict__ H, size_t u) {
+    using GE = Geo<K, D, T>;
+    constexpr int VEC = GE::VEC;
+    for (int x = lane_id(); x < GE::ROW / VEC; x += DL_WAVE) {
+        store_f32<VEC>(urow + x * VEC, Tab<T>::load(Z + u * GE::ROW + x * VEC));
+        store_f32<VEC>(urow + GE::ROW + x * VEC, Tab<T>::load(H + u * GE::ROW + x * VEC));
+    }
+}
+
+// Per multi-segment row:  out[grow] = (accumulate ? out[grow] : 0) + cx * X[grow] + cp * sum_slots part[slot].
+// One 256-thread block per row: each of the 4 waves sums every 4th slot, LDS combines them in wave
+// order.  Partials are fp32 rows `pstride` floats apart; X and out are tables of type TX / TO.
+template <int TOT, typename TX, typename TO>
+__global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const float* __restrict__ part0, int pstride,
+                                                            const TX* __restrict__ X, float cx, float cp,
+                                                            TO* __restrict__ out0, int accumulate,
+                                                            const float* __restrict__ part1 = nullptr,
+                                                            TO* __restrict__ out1 = nullptr,
+                                                            const TO* acc_in = nullptr,
+                                                            const float* __restrict__ scale = nullptr) {
+    // acc_in: the accumulated input read from its own array (may be `out0` itself); scale: a device scalar on the result
+    // gridDim.y == 2: two independent (partials, output) pairs over the same plan in one launch
+    const float* __restrict__ part = blockIdx.y ? part1 : part0;
+    TO* __restrict__ out = blockIdx.y ? out1 : out0;
+    constexpr int TOT4 = TOT / 4;
+    constexpr int NQ = (TOT4 + DL_WAVE - 1) / DL_WAVE;
+    __shared__ float4 red[WAVES_PER_BLOCK][NQ * DL_WAVE];
+    const int m = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    float4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s0 = g.multi_slot0[m], s1 = g.multi_slot0[m + 1];
+#pragma unroll 2
+    for (int slot = s0 + wave; slot < s1; slot += WAVES_PER_BLOCK) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            if (x < TOT4) {
+                const float4 v = load4<float>(part + (size_t)slot * pstride + 4 * x);
+                acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) red[wave][q * DL_WAVE + lane] = acc[q];
+    __syncthreads();
+    if (wave != 0) return;
+    const size_t grow = (size_t)g.multi_row[m] + g.row_offset;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int x = q * DL_WAVE + lane;
+        if (x < TOT4) {
+            float4 t = red[0][x];
+#pragma unroll
+            for (int w = 1; w < WAVES_PER_BLOCK; ++w) {
+                const float4 v = red[w][x];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            const size_t o = grow * TOT + 4 * x;
+            float4 r = acc_in ? load4<TO>(acc_in + o) : accumulate ? load4<TO>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cx != 0.0f) {
+                const float4 xv = load4<TX>(X + o);
+                r.x += cx * xv.x; r.y += cx * xv.y; r.z += cx * xv.z; r.w += cx * xv.w;
+            }
+            r.x += cp * t.x; r.y += cp * t.y; r.z += cp * t.z; r.w += cp * t.w;
+            if (scale) {
+                const float g = scale[0];
+                r.x *= g; r.y *= g; r.z *= g; r.w *= g;
+            }
+            store4(out + o, r);
+        }
+    }
+}
+
+static inline int pow2_at_least(int k) {
+    int p = 1;
+    while (p < k) p <<= 1;
+    return p;
+}
+
+// vec_combine_kernel / the row-sum pass live in dl_route.hip
+void launch_vec_combine(const dl_csr_plan* g, int K, const float* part, int mode, const float* s_raw, float* out, hipStream_t st);
+
+// The H rows of the aggregation go out as streaming stores when the table is far beyond the caches (256 MiB Infinity
+// Cache); on cache-resident graphs the scorer wants them in cache.  (The dZ / dH rows of the training kernels were
+// tried too: a snap-patents-sized epoch 311 -> 319 ms with all of them streaming — only the forward H store pays.)
+static inline int stream_rows(const dl_csr_plan* g, int row_elems, size_t elem) {
+    const int force = config().stream_rows;                     // DL_STREAM_ROWS=0 / 1: measurements only
+    if (force >= 0) return force;
+    return (size_t)g->n_total * row_elems * elem > ((size_t)256 << 20) ? 1 : 0;
+}
+
+}  // namespace fast
+
+// (K, D) pairs with a tuned instantiation.  D must be 4 * a power of two.
+#define DL_FAST_SHAPES_F32(X) \
+    X(4, 32) X(8, 64) X(16, 128) X(5, 32) X(5, 64) X(10, 32) X(10, 64) X(20, 32) X(8, 32) X(4, 64) X(4, 8) X(8, 8) X(3, 8)
+#define DL_FAST_SHAPES_BF16(X) X(4, 32) X(8, 64) X(16, 128) X(5, 64) X(8, 32)
+
+// CALL(OPS) is expanded with OPS = fast::Ops<K, D, T> of the matching instantiation
+#define DL_DISPATCH(CALL)                                                                         \
+    if (dtype == DL_F32) {                                                                        \
+        DL_FAST_SHAPES_F32(CALL##_F32)                                                            \
+    } else if (dtype == DL_BF16) {                                                                \
+        DL_FAST_SHAPES_BF16(CALL##_BF16)                                                          \
+    }                                                                                             \
+    set_error("no tuned kernel for K=%d d=%d dtype=%d", K, d, dtype);                             \
+    return DL_E_ARG;
+
+}  // namespace dl

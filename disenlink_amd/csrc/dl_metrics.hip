@@ -93,7 +93,7 @@ int auc_pair_counts(const float* score, const int64_t* pos_idx, int n_pos, const
     const int slices = (n_small + AUC_THREADS - 1) / AUC_THREADS;
     // ~1,024 workgroups where the sizes allow; a chunk of the searched class is at least one pass of the workgroup
     int target = 1024;                                          // tools/auc_time.py: flat from 128 to 2,048 at 11 slices x 54k, 1,024+ best at 67 x 340k
-    if (const char* e = getenv("DL_AUC_TARGET")) target = std::max(1, atoi(e));
+    if (config().auc_target > 0) target = config().auc_target;   // DL_AUC_TARGET
     int chunks = std::max(1, std::min((n_large + AUC_THREADS - 1) / AUC_THREADS, (target + slices - 1) / slices));
     chunks = std::min(chunks, 65535);
     const int per = (n_large + chunks - 1) / chunks;

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void project1_fwd_kernel(const float* __restri
 
 // Layer-1 products from three bf16 planes per operand (default) or plain fp32 MFMA (DL_PROJECT_FP32_MFMA=1).
 bool split_products() {
-    return getenv("DL_PROJECT_FP32_MFMA") == nullptr;
+    return !config().project_fp32_mfma;
 }
 
 bool project_supported(int d) { return d == 32 || d == 64 || d == 128; }
@@ -599,7 +599,7 @@ bool project_supported(int d) { return d == 32 || d == 64 || d == 128; }
 static int project2_groups(int N, int K, int nhid) {
     const long long wg = (long long)((N + project::TN - 1) / project::TN) * K;
     const int nhc = (nhid + project::TH - 1) / project::TH;
-    if (const char* e = getenv("DL_FWD_GROUPS")) return std::max(1, std::min(nhc, atoi(e)));     // tuning knob
+    if (config().fwd_groups > 0) return std::max(1, std::min(nhc, config().fwd_groups));           // DL_FWD_GROUPS: tuning knob
     if (wg >= 512) return 1;
     const int cpg = std::max(1, (int)(nhc / std::min<long long>(nhc, (512 + wg - 1) / wg)));
     return (nhc + cpg - 1) / cpg;
@@ -609,7 +609,7 @@ static int project2_groups(int N, int K, int nhid) {
 // the graph (2.9M nodes x 288 features would be 5 GB of planes).  Large graphs only — they never use the group split.
 static int fwd_block_rows(int N) {
     long long rows = 1 << 17;
-    if (const char* e = getenv("DL_FWD_BLOCK_ROWS")) rows = std::max(1LL, atoll(e)) * project::TN;   // tests: force blocking
+    if (config().fwd_block_rows > 0) rows = config().fwd_block_rows * project::TN;                  // DL_FWD_BLOCK_ROWS (tests: force blocking)
     return N <= 2 * rows ? N : (int)rows;
 }
 

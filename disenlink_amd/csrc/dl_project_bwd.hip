@@ -753,7 +753,7 @@ static int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static int bwd_block_rows(int N, int K, int nhid, bool two_layer) {
     if (!two_layer) return N;
     long long cap_bytes = 1LL << 30;
-    if (const char* e = getenv("DL_BWD_BLOCK_BYTES")) cap_bytes = std::max(1LL, atoll(e));   // tests: force blocking
+    if (config().bwd_block_bytes > 0) cap_bytes = config().bwd_block_bytes;                 // DL_BWD_BLOCK_BYTES (tests: force blocking)
     const long long cap = cap_bytes / ((long long)K * nhid * (split_products() ? 6 : 4));
     const long long rows = std::max<long long>(4096, cap / TILE_N * TILE_N);
     return (int)std::min<long long>(N, rows);
@@ -768,8 +768,8 @@ static BwdLayout bwd_layout(int N, int F, int K, int nhid, int d, bool two_layer
     // staging, first tile) and the slab it writes are per-workgroup costs.  Measured (DL_BWD_TARGET sweeps):
     // narrow features want few long ranges, wide features many short ones.
     auto pick = [](int n_units, int steps_per_unit, long long wg_per_range, int min_steps) {
-        if (const char* e = getenv("DL_BWD_TARGET"))                       // tuning knob: workgroups per launch
-            return (int)std::max(1LL, std::min<long long>(n_units, ceil_div(std::max(1, atoi(e)), wg_per_range)));
+        if (config().bwd_target > 0)                                       // DL_BWD_TARGET: tuning knob, workgroups per launch
+            return (int)std::max(1LL, std::min<long long>(n_units, ceil_div(config().bwd_target, wg_per_range)));
         const long long lo = ceil_div(256, wg_per_range), hi = ceil_div(1536, wg_per_range);
         const long long by_steps = n_units / std::max(1, ceil_div(min_steps, steps_per_unit));
         return (int)std::max(1LL, std::min<long long>(n_units, std::min(hi, std::max(lo, by_steps))));

@@ -325,13 +325,13 @@ static void launch_dense(const float* Z, const float* H, int N, int K, int d, fl
 }
 
 size_t dense_score_workspace_bytes(int N, int K, int d) {
-    if (!dense_mfma_supported(d) || getenv("DL_DENSE_FP32_MFMA")) return 0;
+    if (!dense_mfma_supported(d) || config().dense_fp32_mfma) return 0;
     return 2 * sizeof(__bf16) * (size_t)K * project::plane_array_elems(N, d, project::SPLIT_COLS);
 }
 
 int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, int d, float t, float* prob, void* ws,
                                   size_t ws_bytes, hipStream_t st) {
-    if (!getenv("DL_DENSE_FP32_MFMA")) {                        // default: three-plane bf16 products (fp32-grade accuracy)
+    if (!config().dense_fp32_mfma) {                        // default: three-plane bf16 products (fp32-grade accuracy)
         using namespace dense;
         static unsigned long long lds_done_p = 0, lds_done_s = 0;
         constexpr size_t lds = (size_t)2 * 2 * 3 * TT * SLD * 2;
@@ -355,7 +355,7 @@ int dense_mfma_score_allpairs_fwd(const float* Z, const float* H, int N, int K, 
         }
         return check_launch("score_allpairs_fwd(split bf16)");
     }
-    if (d % 64 == 0 && !getenv("DL_DENSE_DC32")) launch_dense<64>(Z, H, N, K, d, t, prob, st);
+    if (d % 64 == 0 && !config().dense_dc32) launch_dense<64>(Z, H, N, K, d, t, prob, st);
     else launch_dense<32>(Z, H, N, K, d, t, prob, st);
     return check_launch("score_allpairs_fwd(mfma)");
 }

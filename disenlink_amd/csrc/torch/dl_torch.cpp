@@ -20,6 +20,10 @@
 #include <c10/hip/HIPStream.h>
 #include "disenlink_hip.h"
 
+// Operator set + schemas of this binding; native.py refuses a library built for another number (a stale .so would
+// otherwise fail deep inside a training step with an AttributeError or a schema error).  Bump with every schema change.
+#define DL_TORCH_BINDING_ABI 6
+
 namespace {
 
 using at::Tensor;
@@ -224,7 +228,11 @@ void adam_step(at::TensorList bufs, at::TensorList params, at::TensorList exp_av
             gp[b] = g0.data_ptr<float>();
         } else {
             std::vector<Tensor> gs;
-            for (int64_t k = 0; k < K; ++k) gs.push_back(params[b * K + k].grad().to(at::kFloat));
+            for (int64_t k = 0; k < K; ++k) {
+                TORCH_CHECK(params[b * K + k].grad().defined(), "adam_step: parameter ", b * K + k, " (buffer ", b, ", factor ", k,
+                            ") has no gradient — every factor of a stacked buffer must have taken part in the backward pass");
+                gs.push_back(params[b * K + k].grad().to(at::kFloat));
+            }
             keep.push_back(at::stack(gs).contiguous());
             gp[b] = keep.back().data_ptr<float>();
         }
@@ -289,6 +297,7 @@ TORCH_LIBRARY(disenlink_native, m) {
     m.def("epoch_finish(Tensor score_val, Tensor pos_idx, Tensor neg_idx, Tensor u2, Tensor loss, Tensor[] params, Tensor[] best, "
           "Tensor state, Tensor hist, int ring_ptr, int ring, float denom2, int max_epochs, int patience) -> ()");
     m.def("abi_version() -> str");
+    m.def("binding_abi() -> int");
 }
 
 TORCH_LIBRARY_IMPL(disenlink_native, Autograd, m) {
@@ -304,4 +313,5 @@ TORCH_LIBRARY_IMPL(disenlink_native, CUDA, m) {
 }
 TORCH_LIBRARY_IMPL(disenlink_native, CompositeExplicitAutograd, m) {
     m.impl("abi_version", []() { return std::string(dl_version()); });
+    m.impl("binding_abi", []() { return (int64_t)DL_TORCH_BINDING_ABI; });
 }

@@ -26,6 +26,8 @@ from .graph import Graph, PairList
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdisenlink_torch.so")
 _state = {"loaded": None}
+BINDING_ABI = 6                  # csrc/torch/dl_torch.cpp: DL_TORCH_BINDING_ABI
+_OPS = ("hot_path_pairs_loss", "project_stacked", "adam_step", "auc_pair_counts", "epoch_finish", "binding_abi")
 
 
 def load() -> bool:
@@ -36,8 +38,15 @@ def load() -> bool:
             _lib.load()
             try:
                 torch.ops.load_library(LIB_PATH)
-                ok = hasattr(torch.ops, "disenlink_native") and hasattr(torch.ops.disenlink_native, "hot_path_pairs_loss")
-            except (OSError, RuntimeError) as e:   # built against another torch / registered twice: the ctypes binding (the same HIP kernels) carries on
+                ns = getattr(torch.ops, "disenlink_native", None)
+                missing = [o for o in _OPS if ns is None or not hasattr(ns, o)]
+                abi = None if missing else int(ns.binding_abi())
+                ok = not missing and abi == BINDING_ABI
+                if not ok:                         # a library built before the operator set / a schema changed
+                    import warnings
+                    warnings.warn(f"libdisenlink_torch.so is stale (missing operators {missing}, binding ABI {abi}, expected "
+                                  f"{BINDING_ABI}); rebuild with python -m disenlink_amd.build — using the ctypes binding of the same C ABI")
+            except OSError as e:                   # built against another torch: the ctypes binding (the same HIP kernels) carries on
                 import warnings
                 warnings.warn(f"libdisenlink_torch.so does not load ({e}); rebuild with python -m disenlink_amd.build — "
                               "using the ctypes binding of the same C ABI")

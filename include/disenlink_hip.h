@@ -153,6 +153,9 @@ void dl_host_plan_free(dl_host_plan* plan);
 
 const char* dl_version(void);
 const char* dl_last_error(void);
+/* The library's environment switches (measurement / test knobs, csrc/dl_config.h) are read once, at the first call that
+ * needs one: no launch path touches the environment.  This reads them again (for a process that changes one). */
+void dl_config_reload(void);
 
 /* 1 if (K,d) runs on the tuned wavefront-tiled kernels, 0 if it falls back to the generic ones. */
 int dl_has_fast_path(int K, int d);

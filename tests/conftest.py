@@ -22,6 +22,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def lib_env(monkeypatch):
+    """Set (value) or unset (None) one of the LIBRARY's environment switches inside a test: the library reads its
+    switches once (csrc/dl_config.h), so every change is followed by dl_config_reload(); the environment and the
+    library's view of it are restored when the test ends."""
+    from disenlink_amd import _lib
+
+    def change(name, value=None):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+        _lib.config_reload()
+    yield change
+    monkeypatch.undo()
+    _lib.config_reload()
+
+
 def golden_case_names():
     return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "case_*.npz")))
 

@@ -1242,7 +1242,7 @@ def test_projection_backward_kernels(N, F, K, nhid, d):
             assert float((Z.cpu().double() - Zref).abs().max()) <= 2e-5 * float(Zref.abs().max())
 
 
-def test_projection_backward_in_node_blocks(monkeypatch):
+def test_projection_backward_in_node_blocks(lib_env):
     """Graphs whose masked hidden gradient would exceed the workspace cap are processed in node blocks that
     accumulate into the gradients (cap forced down here): same result as one block, up to summation order."""
     from disenlink_amd import ops
@@ -1255,7 +1255,7 @@ def test_projection_backward_in_node_blocks(monkeypatch):
     dZ = torch.randn(N, K, d, generator=g)
     dev = [v.to(DEV) for v in (x, W1, b1, W2, dZ)]
     whole = ops.project_bwd(*dev)
-    monkeypatch.setenv("DL_BWD_BLOCK_BYTES", str(1 << 20))          # 4096-row blocks: 4096 + 4096 + 1808
+    lib_env("DL_BWD_BLOCK_BYTES", 1 << 20)          # 4096-row blocks: 4096 + 4096 + 1808
     blocks = ops.project_bwd(*dev)
     _Z, hid = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], torch.zeros(K, d, device=DEV), keep_hid=True)
     for name, a, b in zip(("dW1", "db1", "dW2", "db2"), whole, ops.project_bwd(*dev, hid=hid)):
@@ -1263,10 +1263,10 @@ def test_projection_backward_in_node_blocks(monkeypatch):
     for name, a, b in zip(("dW1", "db1", "dW2", "db2"), whole, blocks):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
     # the forward makes its x planes per node block on large graphs (block forced down here): same bits
-    monkeypatch.delenv("DL_BWD_BLOCK_BYTES")
+    lib_env("DL_BWD_BLOCK_BYTES")
     b2 = torch.randn(K, d, generator=g).to(DEV)
     Z1, hid1 = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2, keep_hid=True)
-    monkeypatch.setenv("DL_FWD_BLOCK_ROWS", "8")                     # 1024-row blocks
+    lib_env("DL_FWD_BLOCK_ROWS", 8)                     # 1024-row blocks
     Z2, hid2 = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2, keep_hid=True)
     ldh = (N + 3) // 4 * 4
     assert torch.equal(Z1, Z2) and torch.equal(hid1.view(K, nhid, ldh)[:, :, :N], hid2.view(K, nhid, ldh)[:, :, :N])
@@ -1570,7 +1570,7 @@ def test_auc_counting_kernel_equals_the_sort_form_and_sklearn_vectors():
 
 
 @pytest.mark.gpu
-def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
+def test_three_plane_bf16_products_are_fp32_grade(lib_env):
     """Layer 1 and the dW1 contraction run as six exact bf16 products per term from three bf16 planes per operand
     (dl_tiles.h).  Full-mantissa random operands, odd sizes (feature / node / hidden tails of the padded plane arrays):
     the error against fp64 stays within 2x that of the plain fp32 MFMA form (DL_PROJECT_FP32_MFMA=1) and within fp32
@@ -1592,9 +1592,9 @@ def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
         errs = {}
         for form in ("planes", "fp32"):
             if form == "fp32":
-                monkeypatch.setenv("DL_PROJECT_FP32_MFMA", "1")
+                lib_env("DL_PROJECT_FP32_MFMA", 1)
             else:
-                monkeypatch.delenv("DL_PROJECT_FP32_MFMA", raising=False)
+                lib_env("DL_PROJECT_FP32_MFMA")
             Z, kept = ops.project_fwd(dev[0], dev[1], dev[2], dev[3], b2.to(DEV), keep_hid=True)
             dW1 = ops.project_bwd(*dev, hid=kept)[0]
             # reference gradient with the ReLU mask this run actually used (near-zero pre-activations may flip in fp32)
@@ -1604,7 +1604,7 @@ def test_three_plane_bf16_products_are_fp32_grade(monkeypatch):
             dW1ref = torch.einsum("nkh,nf->khf", dh, X)
             errs[form] = (float((Z.cpu().double() - Zref).abs().max() / Zref.abs().max()),
                           float((dW1.cpu().double() - dW1ref).abs().max() / dW1ref.abs().max()))
-        monkeypatch.delenv("DL_PROJECT_FP32_MFMA", raising=False)
+        lib_env("DL_PROJECT_FP32_MFMA")
         for i, what in enumerate(("Z", "dW1")):
             assert errs["planes"][i] <= max(2.0 * errs["fp32"][i], 2e-7), (what, errs, (N, F, K, nhid, d))
             assert errs["planes"][i] <= 5e-6, (what, errs)

@@ -597,5 +597,8 @@ def test_compiled_torch_binding_builds_loads_and_registers_its_operator():
     for name, want in schemas.items():
         assert str(getattr(torch.ops.disenlink_native, name).default._schema) == want, name
     assert torch.ops.disenlink_native.abi_version() == _lib.load().dl_version().decode()
+    # the operator set / schema number the Python side expects: a library built for another one is refused (available() False
+    # -> the ctypes binding carries on), instead of failing inside a training step
+    assert int(torch.ops.disenlink_native.binding_abi()) == native.BINDING_ABI
     with pytest.raises(RuntimeError, match="CUDA fp32"):
         op(torch.zeros(3, 2, 8), 0, 0, 0, 0.5, 1.0, torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), 0)
