@@ -19,6 +19,7 @@ class DlCsrPlan(C.Structure):
         ("seg_row", C.c_void_p), ("seg_beg", C.c_void_p), ("seg_end", C.c_void_p), ("seg_slot", C.c_void_p),
         ("n_slices", C.c_int32), ("slice_max_seg", C.c_int32), ("slice_seg0", C.c_void_p),
         ("n_multi", C.c_int32), ("n_slots", C.c_int32), ("multi_row", C.c_void_p), ("multi_slot0", C.c_void_p),
+        ("slot_multi", C.c_void_p), ("unit_count", C.c_void_p),
     ]
 
 
@@ -27,7 +28,7 @@ class DlGraph(C.Structure):
 
 
 class DlPairIncidence(C.Structure):
-    _fields_ = [("csr", DlCsrPlan), ("inc_pair", C.c_void_p), ("n_pairs", C.c_int32)]
+    _fields_ = [("csr", DlCsrPlan), ("inc_pair", C.c_void_p), ("n_pairs", C.c_int32), ("entry_yw", C.c_void_p)]
 
 
 class DlHostCsr(C.Structure):
@@ -38,7 +39,7 @@ class DlHostCsr(C.Structure):
 class DlHostPlan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("seg_len", "n_seg", "n_slices", "slice_max_seg", "n_multi", "n_slots")] + \
                [(n, C.POINTER(C.c_int32)) for n in ("seg_row", "seg_beg", "seg_end", "seg_slot", "slice_seg0",
-                                                    "multi_row", "multi_slot0")]
+                                                    "multi_row", "multi_slot0", "slot_multi")]
 
 
 _P = C.c_void_p          # device pointers travel as integers

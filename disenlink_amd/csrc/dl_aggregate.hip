@@ -29,7 +29,7 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
                                                               const uint8_t* __restrict__ p,
                                                               const float* __restrict__ a,
                                                               const float* __restrict__ s, T* __restrict__ H,
-                                                              float* __restrict__ h_part, int stream_out) {
+                                                              float* __restrict__ h_part, int stream_out, int sum_rows_here) {
     using GE = Geo<K, D, T>;
     constexpr int VEC = GE::VEC, G = GE::G, NG = GE::EPW, ROW = GE::ROW;
     constexpr int NC = K < NG ? K : NG;                           // classes = lane groups at work
@@ -126,6 +126,18 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
     float4 r[US::NQ];
     US::sum(red, ws.wave, ws.n_unit, lane, r);
     const float omb = 1.0f - beta;
+    if (!direct && sum_rows_here) {                                 // a row of several units: the last of them to get here writes H[row]
+        if (!publish_unit_and_sum_row<US::F4>(g, si.slot, h_part, ROW, r, lane)) return;
+#pragma unroll
+        for (int q = 0; q < US::NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            if (x < US::F4) {                                       // the combine launch's arithmetic: 0 + beta z + (1 - beta) sum
+                const float4 z = load4<T>(Z + (size_t)si.grow * ROW + 4 * x);
+                store4(H + (size_t)si.grow * ROW + 4 * x, combine_finish(make_float4(0.f, 0.f, 0.f, 0.f), beta != 0.0f, beta, z, omb, r[q], nullptr));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {
         const int x = q * DL_WAVE + lane;
@@ -148,9 +160,10 @@ struct AggOps {
     static constexpr int ROW = K * D;
     static int aggregate_fwd(const dl_csr_plan* g, const void* Z, float beta, const uint8_t* p, const float* a,
                              const float* s, void* H, float* h_part, hipStream_t st) {
+        const bool here = sums_rows_in_launch(g);
         hipLaunchKernelGGL((aggregate_cls_kernel<K, D, T, 4>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                           beta, p, a, s, (T*)H, h_part, stream_rows(g, ROW, sizeof(T)));
-        if (g->n_multi > 0)
+                           beta, p, a, s, (T*)H, h_part, stream_rows(g, ROW, sizeof(T)), here ? 1 : 0);
+        if (g->n_multi > 0 && !here)
             hipLaunchKernelGGL((row_combine_kernel<ROW, T, T>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g, h_part, ROW,
                                (const T*)Z, beta, 1.0f - beta, (T*)H, 0);
         return check_launch("aggregate_fwd(fast)");

@@ -118,6 +118,30 @@ __device__ __forceinline__ float butterfly_up(float v) {
     }
 }
 
+// ---- hand-off between units of a row that run on DIFFERENT XCDs, inside one launch -------------------------------------
+// The XCD L2s are not coherent with each other.  The form used here is the one MI355X_MICROARCH.md lists as measured
+// for "each storing wave for itself": the producer wave stores every byte with `sc1` (written through to memory, not
+// kept in its L2), waits for its stores (s_waitcnt vmcnt(0)), then adds 1 to an agent-scope counter; the wave whose add
+// RETURNED the last count reads every byte with `sc1` loads (never served by its L1).  One wave on either side: no
+// workgroup barrier is involved.  hipcc does not count inline-asm memory operations in its own s_waitcnt bookkeeping,
+// so the waits are written out and the loaded registers are tied to the wait.
+typedef float dl_vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_sc1(float* p, const float4& v) {
+    const dl_vf4 t = {v.x, v.y, v.z, v.w};
+    // (s_nop: the hazard recogniser does not see inside inline asm — a VALU write of the data registers right behind a store
+    // of more than 8 bytes needs a wait state; without it the next address computation landed in the stored row)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ dl_vf4 load4_sc1_issue(const float* p) {          // valid only behind wait_loads_sc1()
+    dl_vf4 t;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t) : "v"(p) : "memory");
+    return t;
+}
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+__device__ __forceinline__ void wait_loads_sc1(dl_vf4& a, dl_vf4& b, dl_vf4& c, dl_vf4& d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
 // Butterfly all-reduce over the 64 lanes of a wave; every lane ends with the same bits.
 __device__ __forceinline__ float wave_allreduce_sum(float v) { return butterfly_down<32, 1>(v); }
 

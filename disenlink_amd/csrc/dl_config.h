@@ -18,6 +18,8 @@ struct Config {
     int bwd_target;             // DL_BWD_TARGET: workgroups per launch of the projection backward (0 = default)
     bool dense_fp32_mfma;       // DL_DENSE_FP32_MFMA: dense scorer on fp32 MFMA
     bool dense_dc32;            // DL_DENSE_DC32: dense scorer in 32-feature steps
+    int inkernel_combine;       // DL_INKERNEL_COMBINE: 0 = rows of several units always through the separate combine launch,
+                                // 1 (default) = inside the launch where the plan's rows are few units long, 2 = wherever a kernel can
 };
 
 const Config& config();

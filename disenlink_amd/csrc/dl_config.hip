@@ -34,6 +34,8 @@ void read_environment() {
     c.bwd_target = (int)std::max(0LL, number("DL_BWD_TARGET"));
     c.dense_fp32_mfma = getenv("DL_DENSE_FP32_MFMA") != nullptr;
     c.dense_dc32 = getenv("DL_DENSE_DC32") != nullptr;
+    const char* ic = getenv("DL_INKERNEL_COMBINE");
+    c.inkernel_combine = (ic == nullptr || ic[0] == '\0') ? 1 : std::max(0, std::min(2, atoi(ic)));
     g_config = c;
 }
 

@@ -264,6 +264,20 @@ __device__ __forceinline__ void stage_u_rows(float* urow, const T* __restrict__ 
     }
 }
 
+// The arithmetic behind a row of several units once its slots are added (t): r + cx * x + cp * t, times a device scalar —
+// written out with fmaf so that row_combine_kernel and the kernels that sum such rows inside their own launch
+// (publish_unit_and_sum_row) produce the same bits.
+__device__ __forceinline__ float4 combine_finish(float4 r, bool has_x, float cx, const float4& xv, float cp, const float4& t,
+                                                 const float* __restrict__ scale) {
+    if (has_x) { r.x = fmaf(cx, xv.x, r.x); r.y = fmaf(cx, xv.y, r.y); r.z = fmaf(cx, xv.z, r.z); r.w = fmaf(cx, xv.w, r.w); }
+    r.x = fmaf(cp, t.x, r.x); r.y = fmaf(cp, t.y, r.y); r.z = fmaf(cp, t.z, r.z); r.w = fmaf(cp, t.w, r.w);
+    if (scale) {
+        const float g = scale[0];
+        r.x *= g; r.y *= g; r.z *= g; r.w *= g;
+    }
+    return r;
+}
+
 // Per multi-segment row:  out[grow] = (accumulate ? out[grow] : 0) + cx * X[grow] + cp * sum_slots part[slot].
 // One 256-thread block per row: each of the 4 waves sums every 4th slot, LDS combines them in wave
 // order.  Partials are fp32 rows `pstride` floats apart; X and out are tables of type TX / TO.
@@ -316,18 +330,80 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
             }
             const size_t o = grow * TOT + 4 * x;
             float4 r = acc_in ? load4<TO>(acc_in + o) : accumulate ? load4<TO>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cx != 0.0f) {
-                const float4 xv = load4<TX>(X + o);
-                r.x += cx * xv.x; r.y += cx * xv.y; r.z += cx * xv.z; r.w += cx * xv.w;
-            }
-            r.x += cp * t.x; r.y += cp * t.y; r.z += cp * t.z; r.w += cp * t.w;
-            if (scale) {
-                const float g = scale[0];
-                r.x *= g; r.y *= g; r.z *= g; r.w *= g;
-            }
-            store4(out + o, r);
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cx != 0.0f) xv = load4<TX>(X + o);
+            store4(out + o, combine_finish(r, cx != 0.0f, cx, xv, cp, t, scale));
         }
     }
+}
+
+// ---------------------------------------------------------------------------- rows of several units, summed inside the launch
+// The head wave of a unit whose row has several units (slot >= 0) calls this with its unit's result in o[]: lane l holds
+// the float4s x = q * 64 + l (x < TOT4) of the [TOT]-float partial.  The partial goes to its slot (sc1 stores), the row's
+// counter (plan.unit_count, all zero between launches) is incremented, and the wave whose increment completes the row —
+// it may run on any XCD, at any time — adds the row's slots in EXACTLY the order row_combine_kernel uses (wave w of that
+// kernel takes the slots s0 + w, s0 + w + 4, ...; then ((w0 + w1) + w2) + w3), so both forms give the same bits; it puts
+// the counter back to zero and returns true with the total in o[].  Every other caller returns false.  (Protocol and its
+// limits: dl_common.h, "hand-off between units".)  pstride = floats between consecutive slots.
+template <int TOT4>
+__device__ __forceinline__ bool publish_unit_and_sum_row(const dl_csr_plan& g, int slot, float* __restrict__ part, int pstride,
+                                                         float4 (&o)[(TOT4 + DL_WAVE - 1) / DL_WAVE], int lane) {
+    constexpr int NQ = (TOT4 + DL_WAVE - 1) / DL_WAVE;
+    float* mine = part + (size_t)slot * pstride;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (q * DL_WAVE + lane < TOT4) store4_sc1(mine + 4 * (q * DL_WAVE + lane), o[q]);
+    wait_vmem();                                                   // every byte of this wave's partial has left
+    const int m = g.slot_multi[slot];
+    const int s0 = g.multi_slot0[m], s1 = g.multi_slot0[m + 1];
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(g.unit_count + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != s1 - s0 - 1) return false;
+    if (lane == 0) __hip_atomic_store(g.unit_count + m, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody else touches it any more
+    float4 acc[WAVES_PER_BLOCK][NQ];
+#pragma unroll
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[w][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four slots per round (one per accumulator set), each lane's float4s of a slot in flight together
+    for (int sl = s0; sl < s1; sl += WAVES_PER_BLOCK) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            if (x < TOT4) {
+                dl_vf4 v[WAVES_PER_BLOCK];
+#pragma unroll
+                for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+                    const int sw = sl + w < s1 ? sl + w : s1 - 1;       // clamped: a valid slot, added with weight 0 below
+                    v[w] = load4_sc1_issue(part + (size_t)sw * pstride + 4 * x);
+                }
+                wait_loads_sc1(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+                    if (sl + w < s1) {
+                        acc[w][q].x += v[w].x; acc[w][q].y += v[w].y; acc[w][q].z += v[w].z; acc[w][q].w += v[w].w;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float4 t = acc[0][q];
+#pragma unroll
+        for (int w = 1; w < WAVES_PER_BLOCK; ++w) { t.x += acc[w][q].x; t.y += acc[w][q].y; t.z += acc[w][q].z; t.w += acc[w][q].w; }
+        o[q] = t;
+    }
+    return true;
+}
+// Worth it where such rows are few units long (adjacency plans: hub rows of 2-4 units; one launch and its gap saved — squirrel
+// forward step 210 -> 206 us, chameleon 55.8 -> 54.1, same bits); not for plans that cut EVERY row into 8-16 units (the XCD-
+// sliced incidence plan of the training scorer: the last unit's chain of slot reads lengthens the tail, see dl_train.hip).
+static inline bool sums_rows_in_launch(const dl_csr_plan* g) {
+    const int mode = config().inkernel_combine;
+    return g->n_multi > 0 && g->slot_multi != nullptr && g->unit_count != nullptr && mode > 0 &&
+           (mode > 1 || (long long)g->n_slots <= 5LL * g->n_multi);
 }
 
 static inline int pow2_at_least(int k) {

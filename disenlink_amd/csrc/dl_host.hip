@@ -200,15 +200,19 @@ int dl_host_plan_build(int32_t n_rows, int32_t n_total, const int32_t* rowptr, c
     out->n_multi = (int32_t)multi_row.size(); out->n_slots = multi_slot0.back();
     out->seg_row = dup(seg_row); out->seg_beg = dup(seg_beg); out->seg_end = dup(seg_end); out->seg_slot = dup(seg_slot);
     out->slice_seg0 = dup(slice_seg0); out->multi_row = dup(multi_row); out->multi_slot0 = dup(multi_slot0);
+    std::vector<int32_t> slot_multi((size_t)multi_slot0.back());           // the row (index into multi_row) of every slot
+    for (size_t m = 0; m + 1 < multi_slot0.size(); ++m)
+        for (int32_t sl = multi_slot0[m]; sl < multi_slot0[m + 1]; ++sl) slot_multi[(size_t)sl] = (int32_t)m;
+    out->slot_multi = dup(slot_multi);
     DL_REQUIRE(out->seg_row && out->seg_beg && out->seg_end && out->seg_slot && out->slice_seg0 && out->multi_row &&
-                   out->multi_slot0, "out of memory");
+                   out->multi_slot0 && out->slot_multi, "out of memory");
     return DL_OK;
 }
 
 void dl_host_plan_free(dl_host_plan* p) {
     if (!p) return;
     free(p->seg_row); free(p->seg_beg); free(p->seg_end); free(p->seg_slot);
-    free(p->slice_seg0); free(p->multi_row); free(p->multi_slot0);
+    free(p->slice_seg0); free(p->multi_row); free(p->multi_slot0); free(p->slot_multi);
     memset(p, 0, sizeof(*p));
 }
 

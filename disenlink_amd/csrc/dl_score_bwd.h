@@ -58,8 +58,14 @@ __global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score
             const int q = inc_pair[si.beg + lane];
             if constexpr (FUSED) {
                 my_q = q;
-                my_y = y[q];
-                my_w = w[q];
+                if (w == nullptr) {                                 // y = per-entry (label, signed weight) pairs: dl_pair_incidence.entry_yw
+                    const float2 yw = reinterpret_cast<const float2*>(y)[si.beg + lane];
+                    my_y = yw.x;
+                    my_w = yw.y;
+                } else {
+                    my_y = y[q];
+                    my_w = w[q];
+                }
             } else {
                 const float pr = prob[q];
                 my_gl = g_prob[q] * pr * (1.0f - pr);       // sigmoid backward p(1-p)
@@ -93,13 +99,14 @@ __global__ __launch_bounds__(BLOCK, (TrainWaves<K, D, FUSED>::value)) void score
                 for (int i = 0; i < VPL; ++i)
                     if (FL::primary(c) && FL::factor_base(c) + i < K) term += pq[i] * ek_lane[i];
                 const float p = sigmoid_ref(group_allreduce_sum<G>(term));
-                const float yy = __shfl(my_y, idx, DL_WAVE), ww = __shfl(my_w, idx, DL_WAVE);   // w = 0 past the segment end
+                const float yy = __shfl(my_y, idx, DL_WAVE), wsg = __shfl(my_w, idx, DL_WAVE);  // w = 0 past the segment end
+                const float ww = fabsf(wsg);                       // a negative sign (per-entry weights only) = the pair's other entry writes prob
                 const int qq = __shfl(my_q, idx, DL_WAVE);
                 // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(r, 1e-12) * r with r = p (1 - p) — i.e.
                 // w (p - y) itself unless r underflows the clamp (saturated scores: r = 0 gives exactly 0), without the division
                 const float r = p * (1.0f - p);
                 gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (r >= 1e-12f ? 1.0f : r * 1e12f);
-                if (base + grp < si.end && c == 0) prob_out[qq] = p;
+                if (base + grp < si.end && c == 0 && !(__float_as_uint(wsg) >> 31)) prob_out[qq] = p;
             }
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {

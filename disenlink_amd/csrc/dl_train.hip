@@ -111,8 +111,14 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
             if (si.beg + lane < si.end) {
                 my_col = g.col[si.beg + lane];
                 my_q = inc_pair[si.beg + lane];
-                my_y = y[my_q];
-                my_w = w[my_q];
+                if (w == nullptr) {                                 // y = per-entry (label, signed weight) pairs: dl_pair_incidence.entry_yw
+                    const float2 yw = reinterpret_cast<const float2*>(y)[si.beg + lane];
+                    my_y = yw.x;
+                    my_w = yw.y;
+                } else {
+                    my_y = y[my_q];
+                    my_w = w[my_q];
+                }
             }
             ent_y[wave][lane] = my_y;                               // written and read by this wave only: no barrier
             ent_w[wave][lane] = my_w;
@@ -172,13 +178,14 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
             const float logit = add_xor<32>(add_xor<16>(term));                              // ... over the 4 rows (all factors)
             const float p = sigmoid_ref(logit);
             const int idx = step * U + (i & 3);
-            const float yy = ent_y[wave][idx & 63], ww = ent_w[wave][idx & 63];
+            const float yy = ent_y[wave][idx & 63], wsg = ent_w[wave][idx & 63];
+            const float ww = fabsf(wsg);                           // a negative sign (per-entry weights only) = the pair's other entry writes prob
             const int qq = ent_q[wave][idx & 63];
             // dl_pair_bce's gradient times the sigmoid backward: w (p - y) / max(q, 1e-12) * q with q = p (1 - p) — i.e.
             // w (p - y) itself unless q underflows the clamp (saturated scores: q = 0 gives exactly 0), without the division
             const float pr = p * (1.0f - p);
             const float gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (pr >= 1e-12f ? 1.0f : pr * 1e12f);     // valid in lanes 8..15
-            if (lane >= 8 && lane < 12 && si.beg + idx < si.end) prob_out[qq] = p;
+            if (lane >= 8 && lane < 12 && si.beg + idx < si.end && !(__float_as_uint(wsg) >> 31)) prob_out[qq] = p;
             // the two coefficients of (entry, chunk), formed ONCE in the lane that holds its exponent / its product and
             // handed to the row afterwards: lanes 0..7: gl e^., lanes 8..15: gl (h.h) e^. / t.  0 * inf must stay 0 (an
             // overflowed exponent saturates p, so its gl is exactly 0): the factors are clamped to the largest finite value
@@ -223,6 +230,9 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
     if (!ws.head) return;
     float4 o[US::NQ];
     US::sum(red, wave, ws.n_unit, lane, o);
+    // (rows of several units summed by their last unit inside this launch — publish_unit_and_sum_row, as the aggregation does —
+    // were measured here and lose: with XCD slicing EVERY row has 4-16 units, and the last unit's chain of slot reads sits
+    // in the kernel's tail: squirrel +27 us at 8 slices, Penn94-sized K = 8 +540 us at 16; profiles/r7b_train_scorer_ab.txt)
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {
         const int x = q * DL_WAVE + lane;
@@ -380,8 +390,14 @@ __global__ __launch_bounds__(BLOCK, WAVES) void score_train_wide_kernel(
             if (si.beg + lane < si.end) {
                 my_col = g.col[si.beg + lane];
                 my_q = inc_pair[si.beg + lane];
-                my_y = y[my_q];
-                my_w = w[my_q];
+                if (w == nullptr) {                                 // y = per-entry (label, signed weight) pairs: dl_pair_incidence.entry_yw
+                    const float2 yw = reinterpret_cast<const float2*>(y)[si.beg + lane];
+                    my_y = yw.x;
+                    my_w = yw.y;
+                } else {
+                    my_y = y[my_q];
+                    my_w = w[my_q];
+                }
             }
             ent_y[wave][lane] = my_y;                               // written and read by this wave only: no barrier
             ent_w[wave][lane] = my_w;
@@ -429,11 +445,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void score_train_wide_kernel(
             logit = add_xor<32>(logit);
             const float p = sigmoid_ref(logit);
             const int idx = step * U + (((c & (G / 2 - 1)) / DUPL) & (U - 1));
-            const float yy = ent_y[wave][idx & 63], ww = ent_w[wave][idx & 63];
+            const float yy = ent_y[wave][idx & 63], wsg = ent_w[wave][idx & 63];
+            const float ww = fabsf(wsg);                           // (sign: see the D = 64 kernel)
             const int qq = ent_q[wave][idx & 63];
             const float pr = p * (1.0f - p);
             const float gl = ww == 0.0f ? 0.0f : ww * (p - yy) * (pr >= 1e-12f ? 1.0f : pr * 1e12f);     // valid above G/2
-            if (lane >= G / 2 && lane < G / 2 + U * DUPL && (lane & (DUPL - 1)) == 0 && si.beg + idx < si.end) prob_out[qq] = p;
+            if (lane >= G / 2 && lane < G / 2 + U * DUPL && (lane & (DUPL - 1)) == 0 && si.beg + idx < si.end && !(__float_as_uint(wsg) >> 31)) prob_out[qq] = p;
             const float exc = fminf(ex, 3.402823466e38f);          // 0 * inf must stay 0 (see the D = 64 kernel)
             const float ttc = __builtin_amdgcn_fmed3f(T1 ? ttv : ttv / t, -3.402823466e38f, 3.402823466e38f);
             const float gl_partner = xor_lane<G / 2>(gl);           // OUTSIDE the select (a DPP move under a divergent branch reads 0)
@@ -599,6 +616,10 @@ int pair_bce(const float* prob, const float* y, const float* w, int n, float* lo
 
 int fast_score_pairs_train(const dl_pair_incidence* inc, const void* Z, const void* H, int K, int d, int dtype, float t,
                            const float* y, const float* w, float* prob, float* dZ, float* dH, float* part, hipStream_t st) {
+    if (inc->entry_yw != nullptr) {      // labels / weights per entry (dl_pair_incidence.entry_yw): the kernels take them through `y`, w = NULL
+        y = inc->entry_yw;
+        w = nullptr;
+    }
 #define X_F32(KK, DD) if (K == KK && d == DD) return fast::TrainOps<KK, DD, float>::score_train(inc, Z, H, t, y, w, prob, dZ, dH, part, st);
 #define X_BF16(KK, DD) if (K == KK && d == DD) return fast::TrainOps<KK, DD, fast::bf16_t>::score_train(inc, Z, H, t, y, w, prob, dZ, dH, part, st);
     DL_DISPATCH(X)

@@ -82,6 +82,37 @@ def auto_slices(n_nodes: int, row_bytes: int, entries_per_row: float = 1e9, n_ta
     return DEFAULT_SLICES * t
 
 
+def auto_inc_slices(n_nodes: int, row_bytes: int, entries_per_row: float, n_tables: int = 2) -> int:
+    """Column slices of the INCIDENCE plan (one-pass training scorer, scorer backward).  Every (row, slice) group there
+    is a unit with a partial slot — 2 K d 4 bytes written, then read by the combine launch, through memory — so slices
+    cost per group what they buy per gathered row.  Measured (profiles/r7a_inc_slices_sweep.txt, r7b_train_scorer_ab.txt,
+    interleaved same-process runs): squirrel (21 MB of Z + H, 388 entries per row) 379 us at 4, 363 at 8, 454 at 16;
+    chameleon (9 MB, 148) 73 / 70 / 89 at 2 / 4 / 8; Penn94-sized K = 8 fp32 (170 MB, 331) 6.79 ms at 8, 5.78 at 16, 5.95
+    at 32; K = 16 bf16 (340 MB) 15.4 ms unsliced, 14.5 at 16, 16.3 at 32.  The rule that picks the best of each: the
+    fewest slices that put a slice of the tables inside an XCD's L2 (0.7 x 4 MiB), but never groups shorter than ~20
+    entries; nothing where even that leaves slices 8x beyond the L2 (the hit rate it buys is then below ~1/8)."""
+    forced = os.environ.get("DL_FORCE_INC_SLICES")                 # experiments only
+    if forced:
+        return int(forced)
+    table = float(n_nodes) * row_bytes * n_tables
+    s_len = 1
+    while 2 * s_len * 20 <= entries_per_row:                        # groups of >= ~20 entries
+        s_len *= 2
+    s_fit = 1
+    while table / s_fit > 0.7 * L2_BYTES_PER_XCD and s_fit < 256:
+        s_fit *= 2
+    s = max(1, min(s_fit, s_len))
+    return s if table / s <= 8 * L2_BYTES_PER_XCD else 1
+
+
+def slice_bounds(col: torch.Tensor, n_slices: int) -> torch.Tensor:
+    """The n_slices - 1 boundaries of column_slices (quantiles of `col`): slice q = [bounds[q-1], bounds[q])."""
+    E = int(col.numel())
+    sorted_col = torch.sort(col).values
+    cut = (torch.arange(1, n_slices, device=col.device, dtype=torch.int64) * E) // n_slices
+    return sorted_col[cut]
+
+
 def column_slices(col: torch.Tensor, n_slices: int) -> torch.Tensor:
     """Slice id of every entry: the column (node id) space is cut into n_slices contiguous ranges holding EQUAL
     NUMBERS OF ENTRIES (boundaries at the quantiles of `col`), not equal numbers of nodes — each XCD stream then gets
@@ -149,6 +180,17 @@ class CsrPlan:
     multi_row: torch.Tensor
     multi_slot0: torch.Tensor
     n_slots: int
+    slot_multi: torch.Tensor | None = None      # [n_slots] index (into multi_row) of the row a partial slot belongs to
+    unit_count: torch.Tensor | None = None      # [n_multi] zeroed int32, owned by the plan: the in-launch row sums count
+                                                # the units of a row here and leave it all zero again (disenlink_hip.h)
+
+    def __post_init__(self):
+        dev = self.multi_slot0.device
+        if self.slot_multi is None:
+            n = self.multi_slot0[1:] - self.multi_slot0[:-1]
+            self.slot_multi = torch.repeat_interleave(torch.arange(n.numel(), device=dev, dtype=torch.int32), n.long())
+        if self.unit_count is None:
+            self.unit_count = torch.zeros(int(self.multi_row.numel()), dtype=torch.int32, device=dev)
 
     @property
     def n_entries(self) -> int:
@@ -165,11 +207,14 @@ class CsrPlan:
     @staticmethod
     def build(rowptr: torch.Tensor, col: torch.Tensor, n_total: int, row_offset: int = 0,
               seg_len: int = DEFAULT_SEG_LEN, n_slices: int = 1, keep: torch.Tensor | None = None,
-              unit_segs: int = UNIT_SEGS, by_length: bool = False) -> "CsrPlan":
+              unit_segs: int = UNIT_SEGS, by_length: bool = False, bounds: torch.Tensor | None = None) -> "CsrPlan":
         """``keep`` (bool per entry, optional): segments cover only the kept entries, which must form one
         contiguous run inside every row (e.g. the upper triangle ``col >= row`` of a sorted row).
         ``unit_segs = 1``: every segment is its own unit — for plans whose kernels reduce nothing across segments
-        (routing, the forward scorer): positions then simply follow the entry order."""
+        (routing, the forward scorer): positions then simply follow the entry order.
+        ``bounds`` (optional, n_slices - 1 ascending node ids): the column slices' boundaries given from outside instead of
+        the quantiles of THIS plan's columns — a row shard passes the whole list's boundaries, so that its rows are cut
+        into exactly the units the unsharded plan cuts them into (the units of a row are summed in slot order: same bits)."""
         if unit_segs not in (1, UNIT_SEGS):
             raise ValueError(f"unit_segs must be 1 or {UNIT_SEGS}")
         if seg_len < 1 or n_slices < 1:
@@ -192,7 +237,13 @@ class CsrPlan:
             row_of, kcol = row_all[orig], col[orig]
         E = int(orig.numel())
         deg = torch.bincount(row_of, minlength=n_rows) if E else torch.zeros(n_rows, dtype=torch.int64, device=dev)
-        gid = row_of * n_slices + (column_slices(kcol, n_slices) if n_slices > 1 else 0)
+        if n_slices > 1 and bounds is not None:
+            if int(bounds.numel()) != n_slices - 1:
+                raise ValueError("bounds must hold n_slices - 1 boundaries")
+            sl_of = torch.bucketize(kcol, bounds.to(kcol.device), right=True)
+        else:
+            sl_of = column_slices(kcol, n_slices) if n_slices > 1 else 0
+        gid = row_of * n_slices + sl_of
         if E and n_slices > 1 and bool((gid[1:] < gid[:-1]).any()):
             raise ValueError("sliced plans need col ascending inside every row")
         new = torch.ones(E, dtype=torch.bool, device=dev)
@@ -303,7 +354,8 @@ class CsrPlan:
             self.n_rows, self.row_offset, self.n_total, self.n_entries, self.rowptr.data_ptr(), self.col.data_ptr(),
             self.seg_len, self.n_seg, self.seg_row.data_ptr(), self.seg_beg.data_ptr(), self.seg_end.data_ptr(),
             self.seg_slot.data_ptr(), self.n_slices, self.slice_max_seg, self.slice_seg0.data_ptr(),
-            int(self.multi_row.numel()), self.n_slots, self.multi_row.data_ptr(), self.multi_slot0.data_ptr())
+            int(self.multi_row.numel()), self.n_slots, self.multi_row.data_ptr(), self.multi_slot0.data_ptr(),
+            self.slot_multi.data_ptr(), self.unit_count.data_ptr())
 
 
 @dataclass
@@ -424,9 +476,43 @@ class PairList:
     inc_pair: torch.Tensor
     _struct: _lib.DlPairIncidence | None = field(default=None, repr=False)
     _struct_u: _lib.DlPairIncidence | None = field(default=None, repr=False)
+    _yw: torch.Tensor | None = field(default=None, repr=False)      # per-entry (label, signed weight): bind_labels
+    _yw_key: tuple | None = field(default=None, repr=False)
+    _yw_seen: tuple | None = field(default=None, repr=False)
 
     def __post_init__(self):
         _assign_handle(self)
+
+    def bind_labels(self, label: torch.Tensor, weight: torch.Tensor, n_pairs_total: int | None = None) -> None:
+        """Lay the labels / loss weights of a training step out per incidence entry (dl_pair_incidence.entry_yw: a
+        coalesced stream instead of two random reads per entry; the weight's sign picks the one entry of a pair that
+        writes prob) — for the label and weight tensors the loop passes EVERY epoch (main_disentangled.py:195: the masks
+        are fixed for a run).  Keyed on the tensors' identity and version counter; built the second time the same pair
+        of tensors is seen, so a caller that draws new labels for every step never pays for it.  Writes that bypass the
+        version counter (``.data``, raw kernels) are not seen: call ``unbind_labels()`` after such a write."""
+        if os.environ.get("DL_ENTRY_LABELS", "1") == "0" or label.is_inference() or weight.is_inference():   # (A/B runs; no version counter)
+            self.unbind_labels()
+            return
+        key = (label.data_ptr(), label._version, weight.data_ptr(), weight._version, int(label.numel()), label.device)
+        if self._yw_key != key:
+            if self._yw_seen != key:                                # first sight: keep the gathers, remember the pair
+                self._yw_seen = key
+                self.unbind_labels()
+                return
+            q = self.inc_pair.long()
+            deg = (self.inc.rowptr[1:] - self.inc.rowptr[:-1]).long()
+            rows = torch.repeat_interleave(torch.arange(self.inc.n_rows, device=q.device), deg) + self.inc.row_offset
+            first = rows == self.pu.long()[q]                        # the entry in the row of the pair's first endpoint
+            w = weight.reshape(-1).float()[q]
+            self._yw = torch.stack([label.reshape(-1).float()[q], torch.where(first, w, -w)], dim=1).contiguous()
+            self._yw_key = key
+        self.c_struct(n_pairs_total)
+        self._struct.entry_yw = self._yw.data_ptr()
+
+    def unbind_labels(self) -> None:
+        self._yw = self._yw_key = None
+        if self._struct is not None:
+            self._struct.entry_yw = None
 
     @property
     def n_pairs(self) -> int:
@@ -440,10 +526,8 @@ class PairList:
         """``row_range`` restricts the incidence rows to one shard's nodes (the pair ids in ``inc_pair``
         then index prob / g_prob arrays covering the whole pair list); ``by_u_range`` restricts the rows
         of the forward plan (every pu must lie inside it).  ``n_slices`` / ``inc_slices``: column slices of the forward
-        plan / of the incidence plan (default: auto_slices, and half of it for the incidence plan — the backward kernels
-        carry more fixed work per wave (staging, partial rows, the unit sum), so they prefer segments twice as long:
-        one-pass training scorer on squirrel 531 -> 497 us at 4 slices instead of 8, chameleon 150 -> 119, Penn94-sized
-        K=8 8.6 -> 6.3 ms at 16 instead of 32, while the forward scorer is fastest at 8 / 8 / 32)."""
+        plan / of the incidence plan (defaults: auto_slices / auto_inc_slices — the incidence plan pays a partial slot
+        per (row, slice) group, the forward plan sums nothing across segments)."""
         pu = pu.reshape(-1).to(torch.int64)
         pv = pv.reshape(-1).to(torch.int64)
         if pu.numel() != pv.numel():
@@ -452,8 +536,8 @@ class PairList:
         if n_slices is None:
             n_slices = auto_slices(n_nodes, row_bytes, entries_per_row=P / max(1, len(torch.unique(pu))))
         if inc_slices is None:
-            forced = os.environ.get("DL_FORCE_INC_SLICES")                # experiments only
-            inc_slices = int(forced) if forced else max(1, n_slices // 2)
+            # (from the WHOLE list, whatever row_range says: a shard must cut its rows exactly as the unsharded plan does)
+            inc_slices = auto_inc_slices(n_nodes, row_bytes, entries_per_row=2.0 * P / max(1, n_nodes))
         if 2 * P >= 2 ** 31:
             raise ValueError("too many pairs for int32 incidence")
         if P and (int(torch.minimum(pu.min(), pv.min())) < 0 or int(torch.maximum(pu.max(), pv.max())) >= n_nodes):
@@ -463,6 +547,8 @@ class PairList:
 
         def csr(node, other, pair, lo, hi, seg, unit_segs=UNIT_SEGS, slices=None):
             slices = n_slices if slices is None else slices
+            # slice boundaries from ALL entries of the list (before the row range cuts it): the same for every shard
+            bnd = slice_bounds(other, slices) if slices > 1 and other.numel() else None
             keep = (node >= lo) & (node < hi)
             node, other, pair = node[keep], other[keep], pair[keep]
             order = torch.argsort((node - lo) * n_nodes + other, stable=True)   # fixed order -> reproducible sums
@@ -470,7 +556,7 @@ class PairList:
             if node.numel():
                 rowptr[1:] = torch.cumsum(torch.bincount(node - lo, minlength=hi - lo), dim=0)
             plan = CsrPlan.build(rowptr, other[order], n_nodes, row_offset=lo, seg_len=seg, n_slices=slices,
-                                 unit_segs=unit_segs, by_length=length_order(n_nodes, row_bytes))
+                                 unit_segs=unit_segs, by_length=length_order(n_nodes, row_bytes), bounds=bnd)
             return plan, _i32(pair[order])
 
         ulo, uhi = (0, n_nodes) if by_u_range is None else by_u_range

@@ -69,6 +69,7 @@ def hot_path_pairs_loss(Z: torch.Tensor, graph: Graph, pairs: PairList, beta: fl
     if P != pairs.n_pairs:
         raise ValueError("label / weight must cover the pair list")
     graph.c_struct()
+    pairs.bind_labels(label, weight, P)                             # per-entry labels once the same tensors come back (graph.py)
     pairs.c_struct(P)
     ws_g = ops._workspace(graph.c_plan(), Z.device, K, d)
     ws_p = ops._workspace(pairs.c_plan(), Z.device, K, d)

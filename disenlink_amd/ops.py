@@ -268,6 +268,7 @@ def score_pairs_train(Z, H, pairs: PairList, t: float, label, weight):
     prob = _empty(P, torch.float32, Z.device)
     dZ = _empty(Z.shape, torch.float32, Z.device)
     dH = _empty(Z.shape, torch.float32, Z.device)
+    pairs.bind_labels(label, weight, P)                             # per-entry labels once the same tensors come back (graph.py)
     inc = pairs.c_struct(P)
     ws = _workspace(pairs.c_plan(), Z.device, K, d)
     _lib.check(lib.dl_score_pairs_train(Z.data_ptr(), H.data_ptr(), K, d, dt, float(t), inc, label.data_ptr(),

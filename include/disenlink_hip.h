@@ -88,6 +88,14 @@ typedef struct dl_csr_plan {
     int32_t n_slots;            /* units belonging to such rows */
     const int32_t* multi_row;   /* [n_multi] local row */
     const int32_t* multi_slot0; /* [n_multi+1] first slot of each such row (slots are consecutive) */
+    /* Optional pair (both NULL = rows of several units are always summed by a separate combine launch): with them the
+     * kernels that know how sum such a row INSIDE the launch — every unit stores its partial slot, adds 1 to the row's
+     * counter, and the unit whose add comes last adds the slots in the combine kernel's own order and writes the row
+     * (same bits as the separate launch; no float atomics).  unit_count belongs to the plan: n_multi zero-initialised
+     * int32 in device memory that only the library writes — the last unit of a row puts its counter back to 0, so the
+     * array is all zero again when a launch has completed; one launch at a time per plan. */
+    const int32_t* slot_multi;  /* [n_slots] index (into multi_row / multi_slot0) of the row a slot belongs to */
+    int32_t* unit_count;        /* [n_multi] */
 } dl_csr_plan;
 
 /* The binarised, symmetrised training adjacency (main_disentangled.py:137-142): entries are the
@@ -112,6 +120,13 @@ typedef struct dl_pair_incidence {
     dl_csr_plan csr;
     const int32_t* inc_pair;    /* [csr.n_entries] */
     int32_t n_pairs;            /* extent of the prob / g_prob arrays */
+    /* Optional (NULL = not given), read by dl_score_pairs_train only: the labels and loss weights of its `y` / `w`
+     * arguments laid out PER ENTRY, [csr.n_entries][2] = (y[inc_pair[e]], +-w[inc_pair[e]]) — a coalesced stream instead of
+     * two random 4-byte reads per entry.  The sign of the weight marks the entry that writes prob[]: + in the row of the
+     * pair's FIRST endpoint (csr row == pu), - (also -0.0) in the other one, so every probability is written once.
+     * Whoever sets it keeps it consistent with the y / w passed alongside (disenlink_amd/graph.py caches it per label /
+     * weight tensor). */
+    const float* entry_yw;
 } dl_pair_incidence;
 
 /* ---- host-side graph preparation (no GPU; the only entry points that allocate: malloc'd outputs are
@@ -129,6 +144,7 @@ typedef struct dl_host_csr {
 typedef struct dl_host_plan {   /* the segment-plan fields of dl_csr_plan, in host memory */
     int32_t seg_len, n_seg, n_slices, slice_max_seg, n_multi, n_slots;
     int32_t *seg_row, *seg_beg, *seg_end, *seg_slot, *slice_seg0, *multi_row, *multi_slot0;
+    int32_t* slot_multi;        /* [n_slots]; unit_count is not built here: n_multi zeroed int32 on the device */
 } dl_host_plan;
 
 /* Directed edge rows (duplicates allowed) -> CSR of the binarised adjacency; symmetrise != 0 reproduces

@@ -227,7 +227,13 @@ def test_pair_incidence_lists_every_slot_once():
         for q, v in zip(uid[uptr[u]:uptr[u + 1]], ucol[uptr[u]:uptr[u + 1]]):
             assert pu[q] == u and pv[q] == v
     _check_plan(pl.by_u, uptr, 4, unit_segs=1)
-    assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 4          # the incidence plan takes half the forward plan's slices
+    assert pl.by_u.n_slices == 8 and pl.inc.n_slices == 1          # the incidence plan has its own rule (graph.auto_inc_slices): tiny table, short rows -> unsliced
+    pl4 = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=4, run_len=4, n_slices=8, inc_slices=4)
+    assert pl4.inc.n_slices == 4 and np.array_equal(pl4.inc.col.numpy(), other)       # slicing re-places segments only
+    _check_plan(pl4.inc, ptr, 4)
+    from disenlink_amd.graph import auto_inc_slices                # the measured shapes (profiles/r7b_train_scorer_ab.txt)
+    assert [auto_inc_slices(5201, 2048, 388), auto_inc_slices(2277, 2048, 148), auto_inc_slices(41554, 2048, 331),
+            auto_inc_slices(41554, 4096, 331), auto_inc_slices(2923922, 2048, 49)] == [8, 4, 16, 16, 1]
     both = PairList.build(torch.from_numpy(pu), torch.from_numpy(pv), n, seg_len=3, run_len=4, n_slices=8, inc_slices=8)
     assert both.inc.n_slices == 8
     _check_plan(both.inc, both.inc.rowptr.numpy(), 3)
@@ -345,7 +351,7 @@ def test_c_abi_host_graph_prep_matches_python_builders(seed):
                 assert got == (ref.n_seg, ref.n_slices, ref.slice_max_seg, int(ref.multi_row.numel()), ref.n_slots)
                 for name, count in (("seg_row", hp.n_seg), ("seg_beg", hp.n_seg), ("seg_end", hp.n_seg),
                                     ("seg_slot", hp.n_seg), ("slice_seg0", hp.n_slices + 1), ("multi_row", hp.n_multi),
-                                    ("multi_slot0", hp.n_multi + 1)):
+                                    ("multi_slot0", hp.n_multi + 1), ("slot_multi", hp.n_slots)):
                     assert np.array_equal(_host_arr(getattr(hp, name), count), getattr(ref, name).numpy()), name
             finally:
                 lib.dl_host_plan_free(C.byref(hp))
