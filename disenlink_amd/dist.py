@@ -749,15 +749,18 @@ class ShardedHotPathLoss(torch.autograd.Function):
 
 def project_and_gather(model, x_pad: torch.Tensor, shard: Shard, group, table_dtype):
     """(Z_loc, pre): the projection of this rank's rows (model.py:106; autograd input of the sharded hot path) and — when
-    the partition has row chunks (Partition.n_chunks > 1), there is more than one rank and DL_Z_OVERLAP != 0 — the Z
+    the partition has row chunks (Partition.n_chunks > 1), there is more than one rank and DL_Z_OVERLAP=1 — the Z
     table with this rank's block in place and its exchange IN FLIGHT: chunk c of the local rows is projected, stored to its
     place in the table and handed to the direct exchange (ChunkedRowGather.start_chunk) while chunk c + 1 is projected, so
     only the last chunk's transfer is exposed.  The K MLPs act row by row, so the chunks'
     outputs are the rows of the whole projection; the weight gradients become a sum over the chunks' backward passes (a
     different summation order from the single launch: equal to rounding, not bit for bit).  pre = None otherwise (the hot
-    path then gathers Z itself, in one collective)."""
+    path then gathers Z itself, in one collective, and routes the peers' blocks in arrival order where Shard.route_by_peer
+    is set).  OFF unless asked for: this form gives up the arrival-order routing and the bit-identical weight gradients of
+    the single launch, and it has never been timed on real links — `bench.py --gpus N` times both forms in the run and
+    switches it on (DL_Z_OVERLAP=1 for its own timed steps) only where it wins by >= 5 % on every rank."""
     part = shard.part
-    if shard.world == 1 or part.n_chunks <= 1 or os.environ.get("DL_Z_OVERLAP", "1") == "0" or \
+    if shard.world == 1 or part.n_chunks <= 1 or os.environ.get("DL_Z_OVERLAP", "0") != "1" or \
             (dist.is_initialized() and dist.get_world_size(group) == 1):
         return model.project(x_pad), None
     Bc = part.chunk_rows

@@ -164,6 +164,57 @@ def _pick(times: dict, default: str) -> str:
     return best if (best == default or default not in times or times[best] < AB_MARGIN * times[default]) else default
 
 
+def _cpu_baseline_b(_bench, args, g1, p1, Z, prob_gpu, beta, t, bf16, budget_s=40.0):
+    """Baseline B (the multi-threaded C edge-list restatement, oracle/c/sparse_ref.c) for THIS block's
+    problem, timed on rank 0's host cores while the other ranks wait at a host barrier — with the parity of the unsharded
+    GPU step against it.  None when --no-cpu-baseline is given.  (The GPU box's cores are shared by all ranks' processes;
+    the others sleep in a gloo barrier meanwhile.)"""
+    if getattr(args, "no_cpu_baseline", False):
+        return None
+    try:
+        gc = g1.to("cpu")
+        n_units = g1.n_edges + p1.n_pairs
+        got = _bench.cpu_baseline_sparse(Z.float().cpu(), gc, (p1.pu.cpu(), p1.pv.cpu()), n_units, beta, t, budget_s=budget_s,
+                                         parity=(None, prob_gpu), bf16=bf16)
+        base, par = got
+        base["parity_of_the_unsharded_gpu_step"] = par
+        return base
+    except Exception as e:                                          # noqa: BLE001 — a baseline must not take the record down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+XGMI_LINK_GBS = 153.0          # MI355X: 7 xGMI links per GPU, ~153 GB/s each, point to point (no switch)
+
+
+def predicted_step(n1, world: int, block_rows: int, K: int, d: int, wb: int, scaling: str) -> dict:
+    """What the sharded forward step SHOULD take, from this run's own one-GPU phase times and the bytes every rank receives —
+    the number the first multi-GPU measurement is to be compared with ("something to be wrong against").
+    compute = the three kernels' one-GPU times / W for the strong blocks (the work is cut by nnz / pairs), unchanged for
+    the weak ones; exchange = the Z, s and H blocks of the W-1 peers over xGMI: every peer has its own link, so with all links
+    busy at once a table costs ONE block / 153 GB/s; a ring, or a transport that serialises the peers, costs W-1 of them.
+    The chunked H exchange runs under the scorer: 'overlapped' counts max(score, H exchange) instead of their sum."""
+    if n1 is None or world < 1:
+        return None
+    k = n1["kernels_us"]
+    div = world if scaling == "strong" else 1
+    route, agg, score = (k.get(n, 0.0) / div * 1e-3 for n in ("route", "aggregate", "score"))      # ms
+    blk_tab = block_rows * K * d * wb                                # one peer's block of Z (or H), bytes
+    blk_s = block_rows * K * 4
+    links = max(world - 1, 0)
+    one = lambda nbytes: nbytes / (XGMI_LINK_GBS * 1e9) * 1e3       # ms for one block over one link
+    ex_par = {"Z": one(blk_tab) if links else 0.0, "s": one(blk_s) if links else 0.0, "H": one(blk_tab) if links else 0.0}
+    ex_ser = {n: v * links for n, v in ex_par.items()}
+    def total(ex, overlap):
+        return route + agg + ex["Z"] + ex["s"] + (max(score, ex["H"]) if overlap else score + ex["H"])
+    return {"compute_ms": {"route": route, "aggregate": agg, "score": score},
+            "exchange_ms_all_links_at_once": ex_par, "exchange_ms_one_link_at_a_time": ex_ser,
+            "step_ms": {"all_links_H_under_the_scorer": total(ex_par, True), "all_links_blocking": total(ex_par, False),
+                        "one_link_at_a_time_blocking": total(ex_ser, False)},
+            "assumptions": f"{XGMI_LINK_GBS:.0f} GB/s per xGMI link, {links} peers, blocks of {block_rows} rows; one-GPU kernel times of this "
+                           "run divided by W (strong) — gathers from W-times larger tables run slower than that, so the compute term "
+                           "is a lower bound; no launch or collective latency"}
+
+
 def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
     """One (workload, scaling, K, d, dtype) block.  One step = all-gather Z, route, all-gather s, aggregate, all-gather H,
     score the local pairs; value = (E_sym + P over all ranks) / max-over-ranks time."""
@@ -218,6 +269,7 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
                 Z, backend.ops.aggregate_fwd(g1, Z, beta, *backend.ops.route_fwd(g1, Z, t)), p1.pu, p1.pv, t, p1)
             n1 = dict(ms=float(np.median(blocks1)) * 1e3, kernels_us={k: v * 1e6 for k, v in kt1.items()},
                       E=g1.n_edges, P=p1.n_pairs, prob=prob1[shard.pair_lo:shard.pair_hi].clone())
+            n1["cpu_baseline"] = _cpu_baseline_b(_bench, args, g1, p1, Z, prob1, beta, t, spec["dtype"] == "bf16")
             del g1, p1, prob1
             torch.cuda.empty_cache()
     else:                                           # weak: the per-GPU problem is the graph at the base scale
@@ -228,7 +280,10 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
             blocks1, kt1 = _bench.time_forward(backend.ops, g1, p1, Z1, beta, t, args.steps, args.warmup, 3, min_region_s=0.5)
             n1 = dict(ms=float(np.median(blocks1)) * 1e3, kernels_us={k: v * 1e6 for k, v in kt1.items()},
                       E=g1.n_edges, P=p1.n_pairs, prob=None)
-            del g1, p1, Z1, _model, _x
+            prob1 = backend.ops.score_pairs_fwd(
+                Z1, backend.ops.aggregate_fwd(g1, Z1, beta, *backend.ops.route_fwd(g1, Z1, t)), p1.pu, p1.pv, t, p1)
+            n1["cpu_baseline"] = _cpu_baseline_b(_bench, args, g1, p1, Z1, prob1, beta, t, spec["dtype"] == "bf16")
+            del g1, p1, Z1, _model, _x, prob1
             torch.cuda.empty_cache()
     dist.barrier(group=ctrl)                        # the others wait on the host (gloo), not in a spinning RCCL kernel
 
@@ -415,6 +470,8 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
         "speedup_vs_n1": None if n1 is None else (n1["ms"] / step_ms if spec["scaling"] == "strong" else
                                                   value / ((n1["E"] + n1["P"]) / (n1["ms"] * 1e-3))),
         "parity": parity,
+        "cpu_baseline": None if n1 is None else n1.get("cpu_baseline"),
+        "predicted": predicted_step(n1, world, B, K, d, wb, spec["scaling"]),
         "gather_ab": {"z_gather_ms": z_ab, "z_gather_used": z_mode, "h_phase_ms": h_ab, "h_phase_used": h_form,
                       "forced": {"DL_GATHER_MODE": forced, "DL_H_GATHER": want_form}, "refused": ab_errors,
                       "note": "allgather = one all_gather_into_tensor into the table itself (in place); p2p = one grouped "
@@ -444,6 +501,9 @@ def run_block(spec: dict, args, rank: int, world: int, device, ctrl) -> dict:
                    "parallelism": f"row-shard x{world}",
                    "fast_path": bool(lib.dl_has_fast_path_dtype(K, d, 1 if wb == 2 else 0))},
     }
+    if out["predicted"] is not None:
+        out["predicted"]["measured_over_predicted"] = {k: step_ms / v for k, v in out["predicted"]["step_ms"].items() if v > 0}
+        out["predicted"]["measured_step_ms"] = step_ms
     del Z, H, s
     torch.cuda.empty_cache()
     # ---- the sharded TRAINING step (forward with the one-pass scorer, backward, gradient all-reduce): timed beside the
@@ -619,8 +679,11 @@ def bench_sharded(args, rank: int, world: int, device) -> dict:
             "dtype": head["dtype"], "data": "synthetic", "config": head_cfg,
             "n1_same_problem_ms": head["n1_same_problem_ms"], "speedup_vs_n1": head["speedup_vs_n1"],
             "parity": head["parity"], "roofline": head["roofline"],
-            "cpu_baseline": None,
-            "cpu_baseline_note": "timed on rank 0 at N=1 only (bench.py --gpus 1), as the contract says",
+            "cpu_baseline": head.get("cpu_baseline"),
+            "cpu_baseline_note": "Baseline B (oracle/c/sparse_ref.c, OpenMP on the host cores) of the head block's problem, timed on rank 0 "
+                                 "while the other ranks wait at a host barrier; every block carries its own (blocks.*.cpu_baseline) with "
+                                 "the parity of the unsharded GPU step against it; the dense reference form is in the `--gpus 1` record",
+            "predicted": head.get("predicted"),
             "blocks": {r["name"]: r for r in results},
             "launch": {"self_launched": bool(os.environ.get("DL_BENCH_SELF_LAUNCHED")),
                        "backend": dist.get_backend(), "rehearsal_on_one_gpu": bool(os.environ.get("DL_REHEARSE_ON_ONE_GPU")),

@@ -284,7 +284,8 @@ class Disentangle(nn.Module):
         Z = self.project(x)
         H = ops.RouteAggregate.apply(Z, graph, float(self.beta), float(self.temperature))
         link_pred = ops.ScoreAllPairs.apply(Z, H, float(self.temperature), self._dense_plan)
-        return H.view(H.shape[0], -1), link_pred
+        # (a Tensor whose indexing reports the entries taken to this module's pair-plan cache: ops.LinkPred)
+        return H.view(H.shape[0], -1), ops.as_link_pred(link_pred, self._dense_plan)
 
     def forward_pairs_loss(self, x, graph: Graph, pairs: PairList, label, weight):
         """(emb [N,K*d], prob [P], loss) with loss = sum_q weight BCE(prob, label) (main_disentangled.py:195 on a pair

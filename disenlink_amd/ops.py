@@ -383,7 +383,10 @@ class _XPlanes:
     TENSOR (object identity + version counter, like _PaddedFeatures): model.py:106 evaluates the MLPs on the same x every
     epoch, and the projection kernels otherwise split x (forward) and x^T (backward) into their three bf16 planes on every
     call.  An entry is made the SECOND time a tensor is seen (a one-off call splits inside its own workspace, as before),
-    only for graphs the kernels process as one node block, and dies with its tensor."""
+    only for graphs the kernels process as one node block, and dies with its tensor.
+    CONTRACT: the planes follow the tensor's identity and VERSION COUNTER — a write that bypasses the counter (``x.data``,
+    a raw-pointer kernel) leaves stale planes in use; write through torch (any in-place op bumps the version) or set
+    DL_X_PLANES=0.  Up to MAX_BYTES (1 GiB, about 3x the size of x) of device memory per cached tensor."""
     MAX_ROWS = 2 << 17              # fwd_block_rows: larger graphs are processed in node blocks that re-split themselves
     MAX_BYTES = 1 << 30
 
@@ -392,6 +395,10 @@ class _XPlanes:
 
     def get(self, x: torch.Tensor, force: bool = False):
         if os.environ.get("DL_X_PLANES", "1") == "0" or x.shape[0] > self.MAX_ROWS or not x.is_cuda:
+            return None
+        # no version counter to watch (inference-mode tensors raise on ._version), or a view made for this call (a row chunk of
+        # the sharded path: a new tensor object every epoch, it would never be seen twice): split per call, as before the cache
+        if x.is_inference() or x._base is not None:
             return None
         key = id(x)
         hit = self._by_id.get(key)
@@ -823,9 +830,14 @@ class DensePairPlanCache:
 
       * ``set_pairs(masks ...)`` (Disentangle.set_loss_pairs / assume_static_loss_masks(mask, ...)): the plan IS the
         support of the caller's masks; entries whose gradient is zero cost a little arithmetic and add exactly zero.
-      * no masks given: the plan is learnt from the gradients and only ever GROWS — a backward whose non-zero entries
-        are not all inside the cached set extends it by the new ones (union) and rebuilds; it never shrinks to the
-        current non-zero set.  Once every masked entry has carried gradient the plan is the masks' support.
+      * no masks given: the plan is learnt — first from the caller's own INDEXING of link_pred (round 6: forward returns
+        a LinkPred, a Tensor subclass whose only difference is that ``link_pred[mask]`` / ``link_pred[rows, cols]`` tells
+        this cache the support of the index before handing over to torch: main_disentangled.py:195, 202 index it with
+        the fixed masks every epoch, so after the first epoch the plan is their union and never changes again), and, as
+        the safety net behind that, from the gradients: a backward whose non-zero entries are not all inside the cached
+        set extends it by the new ones (union) and rebuilds; it never shrinks to the current non-zero set.  (Learning
+        from the gradients ALONE rebuilt the plan in every one of the first 40 epochs on squirrel and chameleon — each
+        epoch desaturates a few more pairs — 4 ms per epoch: profiles/r7d_dropin_*.)
       * validation: non-zeros(g) must be a SUBSET of the plan.  Default: two device counters are read back per backward
         (one 16-byte host read; the reference's own loop reads back the validation scores and the loss every epoch,
         main_disentangled.py:204,214).  ``static=True`` (needs masks): no host read — the same two counters stay on
@@ -839,6 +851,10 @@ class DensePairPlanCache:
         self.key = None          # (N, device)
         self.static = False
         self.from_masks = False  # the set is the caller's declared support (never extended behind their back)
+        self.rebuilds = 0        # how often the plan was (re)built: a learnt plan is rebuilt whenever new entries carry gradient
+        self._seen_index = set() # fingerprints of the index masks link_pred was indexed with (note_index)
+        self._pending = []       # flat positions learnt from indexing, not yet in the plan
+        self._hash_vec = None
 
     # ---- the caller's declared support
     def set_pairs(self, N: int, device, *supports):
@@ -867,11 +883,43 @@ class DensePairPlanCache:
     def clear(self):
         self.pairs = self.flat = self.key = None
         self.from_masks = False
+        self._seen_index, self._pending = set(), []
+
+    # ---- learnt from the caller's indexing of link_pred (LinkPred.__torch_function__)
+    def note_index(self, N: int, index) -> None:
+        """``link_pred[index]`` is about to be evaluated: remember the support of a boolean [N,N] mask or of a
+        (rows, cols) pair of index tensors.  A mask is recognised by a fingerprint (count, hashed row sums, hashed
+        column sums: two reductions over the mask and one 24-byte read — the indexing that follows synchronises anyway),
+        so the masks the loop passes every epoch cost a nonzero() once."""
+        if self.from_masks or self.static:
+            return                                                  # the caller declared the support: nothing to learn
+        try:
+            if torch.is_tensor(index) and index.dtype == torch.bool and tuple(index.shape) == (N, N) and index.is_cuda:
+                if self._hash_vec is None or self._hash_vec.numel() != N or self._hash_vec.device != index.device:
+                    g = torch.Generator().manual_seed(0x5eed)
+                    self._hash_vec = torch.randint(1, 1 << 20, (N,), generator=g, dtype=torch.int64).to(index.device)
+                rs, cs = index.sum(dim=1), index.sum(dim=0)
+                fp = tuple(torch.stack([rs.sum(), (rs * self._hash_vec).sum(), (cs * self._hash_vec).sum()]).tolist())
+                if fp in self._seen_index:
+                    return
+                self._seen_index.add(fp)
+                self._pending.append(torch.nonzero(index.reshape(-1)).reshape(-1))
+            elif isinstance(index, tuple) and len(index) == 2 and all(torch.is_tensor(v) and v.dtype == torch.int64 and v.dim() == 1
+                                                                        for v in index) and index[0].is_cuda:
+                fp = ("ij", index[0].data_ptr(), index[0]._version, index[1].data_ptr(), index[1]._version, int(index[0].numel()))
+                if fp in self._seen_index:
+                    return
+                self._seen_index.add(fp)
+                self._pending.append((index[0] % N) * N + (index[1] % N))
+        except RuntimeError:                                        # an index torch itself will reject: let torch say so
+            return
 
     def _install(self, flat: torch.Tensor, N: int, device):
         self.flat = flat
-        self.pairs = PairList.build(torch.div(flat, N, rounding_mode="floor"), flat % N, N)
+        # (only the incidence plan is walked by dl_score_allpairs_bwd: the forward plan of the list is not built)
+        self.pairs = PairList.build(torch.div(flat, N, rounding_mode="floor"), flat % N, N, build_by_u=False)
         self.key = (N, device)
+        self.rebuilds += 1
 
     # ---- per backward
     def lookup(self, g_prob: torch.Tensor):
@@ -883,6 +931,10 @@ class DensePairPlanCache:
             if self.from_masks:
                 raise ValueError(f"the loss pairs were declared for {self.key}, the gradient is for {key}")
             self.clear()
+        if self._pending and not self.from_masks:                   # supports learnt from the caller's indexing since the last backward
+            known = [self.flat] if self.flat is not None and self.key == key else []
+            self._install(torch.unique(torch.cat(known + self._pending)), N, g_prob.device)
+            self._pending = []
         if self.pairs is None:
             if self.static:
                 raise RuntimeError("assume_static_loss_masks() needs the masks (or index pairs) the loss is taken on: "
@@ -920,6 +972,32 @@ def score_allpairs_bwd(Z, H, pairs: PairList, t: float, prob, g_prob):
                                          dZ.data_ptr(), dH.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                "dl_score_allpairs_bwd")
     return dZ, dH
+
+
+class LinkPred(torch.Tensor):
+    """The dense link_pred of Disentangle.forward(x, adj): a torch.Tensor in every respect, except that indexing it —
+    ``a_pred[pos_train_adj == 1]`` (main_disentangled.py:195, 202, 217) — first tells the owning module's DensePairPlanCache
+    which entries are being taken (note_index), so that the dense backward knows the support of the caller's loss without
+    a declaration and without learning it from gradients whose zero pattern moves.  Every operation, indexing included, is
+    then torch's own, and every result is a plain torch.Tensor."""
+    _dl_cache = None
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], LinkPred):
+            cache = args[0]._dl_cache
+            if cache is not None and args[0].dim() == 2:
+                cache.note_index(int(args[0].shape[0]), args[1])
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def as_link_pred(prob: torch.Tensor, cache: "DensePairPlanCache") -> torch.Tensor:
+    if os.environ.get("DL_LINK_PRED_SUBCLASS", "1") == "0":        # plain tensor: the plan is learnt from the gradients alone
+        return prob
+    out = prob.as_subclass(LinkPred)
+    out._dl_cache = cache
+    return out
 
 
 class ScoreAllPairs(torch.autograd.Function):

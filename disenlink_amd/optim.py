@@ -87,7 +87,11 @@ class StackedAdam:
         # what a captured graph replays must stay alive and in place: exposed like torch's optimizer.state
         self.state = {i: {"step": self.steps[i], "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
                       for i in range(len(self.bufs))}
-        self.state["dl"] = {"state": self.dl_state}
+        # the eager loop's step count lives on the host — as a tensor inside `state`, so that whoever resets the optimiser the
+        # way torch's are reset (zeroing every tensor of optimizer.state: train._graphed_epoch after its warm-up) resets it too
+        self._host_count = torch.zeros((), dtype=torch.int64)
+        self._host_stale = False                                    # the device counter ran ahead (captured / replayed steps)
+        self.state["dl"] = {"state": self.dl_state, "host_step": self._host_count}
         if not self.use_torch_kernel:
             import ctypes as C
             n = len(self.bufs)
@@ -124,8 +128,16 @@ class StackedAdam:
         # an eager loop counts its steps on the host (dl_adam_step_at: no counter launch in front of the update); a loop that
         # is captured and replayed cannot — its counter lives in dl_state (dl_adam_step)
         host_step = 0
-        if not self.use_torch_kernel and not self.capturable and _HOST_STEP:
-            self._host_step = host_step = self.__dict__.get("_host_step", 0) + 1
+        if not self.use_torch_kernel and self.bufs[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # a step number passed as a kernel argument would be baked into the graph: every replay would repeat it.  Under
+            # capture the counter is the device's (dl_state[0], which dl_adam_step_at keeps current too), whatever `capturable` says
+            self._host_stale = True
+        elif not self.use_torch_kernel and not self.capturable and _HOST_STEP:
+            if self._host_stale:                                    # replays advanced the device counter: read it back once
+                self._host_count.fill_(int(self.dl_state[0].item()))
+                self._host_stale = False
+            self._host_count += 1
+            host_step = int(self._host_count)
         if not self.use_torch_kernel and self._native():
             from . import native                                   # gradient bookkeeping + launch in C++ (no ctypes, no per-parameter Python)
             native.adam_step(self.bufs, self._flat_params, self.exp_avg, self.exp_avg_sq, self.dl_state, self.lr, self.betas[0],

@@ -70,3 +70,78 @@ def test_twitch_de():
     from disenlink_amd.datasets import load_twitch
     ds = load_twitch(_need(f"{REF}/data/twitch/DE"), "DE", standardise=False)
     assert ds.n_nodes == 9498 and ds.src.size == 2 * 153138 and ds.x.shape[1] <= 3170
+
+
+@pytest.mark.parametrize("school", ["Amherst41", "Reed98", "JohnsHopkins55"])
+def test_fb100_equals_the_references_label_binarize_construction(school):
+    """f4 guard: load_fb100 against the reference's construction, restated here line by line from
+    /root/reference/other_hetero_datasets.py:131-154 (load_fb100_dataset) over load_data.py:11-19 with the installed
+    sklearn: edge_index = A.nonzero(), features = hstack over the metadata columns (gender left out) of
+    label_binarize(col, classes=np.unique(col)) — which gives ONE column for a two-valued column and a zero column for a
+    single-valued one — as float32.  Equality, not shapes."""
+    import scipy.io
+    from sklearn.preprocessing import label_binarize
+    from disenlink_amd.datasets import load_fb100
+    path = _need(f"{REF}/data/facebook100/{school}.mat")
+    mat = scipy.io.loadmat(path)
+    A, metadata = mat["A"], mat["local_info"].astype(np.int64)           # (np.int of the reference: removed from numpy)
+    row, col = A.nonzero()
+    feature_vals = np.hstack((np.expand_dims(metadata[:, 0], 1), metadata[:, 2:]))
+    features = np.empty((A.shape[0], 0))
+    for c in range(feature_vals.shape[1]):
+        feat_col = feature_vals[:, c]
+        features = np.hstack((features, label_binarize(feat_col, classes=np.unique(feat_col))))
+    want_x = features.astype(np.float32)                                # torch.tensor(features, dtype=torch.float)
+    ds = load_fb100(path, school, standardise=False)
+    assert ds.x.dtype == np.float32 and ds.x.shape == want_x.shape and np.array_equal(ds.x, want_x)
+    assert np.array_equal(ds.src, row.astype(np.int64)) and np.array_equal(ds.dst, col.astype(np.int64))
+    # ... and the standardised form the script trains on (main_disentangled.py:107-109)
+    import torch
+    t = torch.from_numpy(want_x)
+    ref = (t - torch.mul(torch.ones(t.shape), torch.mean(t, dim=1).unsqueeze(dim=1))) / torch.std(t, dim=1).unsqueeze(dim=1)
+    np.testing.assert_allclose(load_fb100(path, school).x, ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_twitch_de_equals_the_references_arrays():
+    """f4 guard: load_twitch against /root/reference/load_data.py:21-70 restated here (np.int -> np.int64, the one edit the
+    installed numpy forces) + main_disentangled.py:111-116: features — 3170 one-hot columns, zero columns removed — equal
+    exactly; the edge rows are those of A.nonzero() with the reversed rows appended, as a multiset (the loader keeps the
+    csv order, scipy's CSR walks them row by row: only the order differs, and the split shuffles it anyway)."""
+    import csv
+    import json
+    import scipy.sparse
+    from disenlink_amd.datasets import load_twitch
+    lang = "DE"
+    filepath = _need(f"{REF}/data/twitch/{lang}")
+    label, node_ids, src, targ, uniq_ids = [], [], [], [], set()
+    with open(f"{filepath}/musae_{lang}_target.csv", "r") as f:
+        reader = csv.reader(f)
+        next(reader)
+        for row in reader:
+            node_id = int(row[5])
+            if node_id not in uniq_ids:
+                uniq_ids.add(node_id)
+                label.append(int(row[2] == "True"))
+                node_ids.append(int(row[5]))
+    with open(f"{filepath}/musae_{lang}_edges.csv", "r") as f:
+        reader = csv.reader(f)
+        next(reader)
+        for row in reader:
+            src.append(int(row[0]))
+            targ.append(int(row[1]))
+    with open(f"{filepath}/musae_{lang}_features.json", "r") as f:
+        j = json.load(f)
+    n = len(label)
+    A = scipy.sparse.csr_matrix((np.ones(len(src)), (np.array(src), np.array(targ))), shape=(n, n))
+    features = np.zeros((n, 3170))
+    for node, feats in j.items():
+        if int(node) >= n:
+            continue
+        features[int(node), np.array(feats, dtype=int)] = 1
+    features = features[:, np.sum(features, axis=0) != 0]
+    r, c = A.nonzero()
+    want_src, want_dst = np.concatenate([r, c]).astype(np.int64), np.concatenate([c, r]).astype(np.int64)   # :114-116
+    ds = load_twitch(filepath, lang, standardise=False)
+    assert ds.n_nodes == n and np.array_equal(ds.x, features.astype(np.float32))
+    key = lambda a, b: np.sort(a * n + b)
+    assert np.array_equal(key(ds.src, ds.dst), key(want_src, want_dst))

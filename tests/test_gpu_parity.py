@@ -527,13 +527,17 @@ def test_caches_follow_tensor_identity_not_addresses():
     assert not torch.equal(z1, z2)
 
 
-def test_dense_backward_plan_is_per_module_grows_with_the_gradients_and_never_goes_wrong_silently():
-    """The backward of the dense [N,N] link_pred runs on a pair plan owned by the MODULE.  Declared masks
+@pytest.mark.parametrize("subclass", ["1", "0"])
+def test_dense_backward_plan_is_per_module_grows_with_the_gradients_and_never_goes_wrong_silently(subclass, monkeypatch):
+    """(subclass = "1": link_pred is an ops.LinkPred whose indexing reports the entries taken — the plan is learnt from the
+    caller's masks; "0": a plain tensor, the plan is learnt from the gradients alone, the safety net behind the former.)
+    The backward of the dense [N,N] link_pred runs on a pair plan owned by the MODULE.  Declared masks
     (set_loss_pairs / assume_static_loss_masks(masks)): the plan is their support.  Undeclared: the plan is learnt from
     the gradients and only grows (union), so two models of equal N do not disturb each other and a new mask is noticed.
     In the promised-static mode (no host read) a loss taken OUTSIDE the declared masks gives NaN gradients, and in the
     validated mode it raises — never silently wrong gradients."""
     from disenlink_amd.model import Disentangle
+    monkeypatch.setenv("DL_LINK_PRED_SUBCLASS", subclass)
     torch.manual_seed(5)
     N, Fdim = 90, 12
     g = torch.Generator().manual_seed(0)
@@ -635,7 +639,8 @@ def test_dense_backward_under_fixed_masks_while_saturation_moves(case):
     d loss / d link_pred grows from step to step (k4_d8: 264 -> 295 of 295 masked entries, k5_d64: 805 -> 1,063) because
     saturated positives carry exactly zero gradient until they de-saturate.  The drop-in module must follow the
     reference's losses and end at its weights in every mode: masks declared + no host read (static), masks declared +
-    validated, and nothing declared (plan learnt from the gradients, growing).  The two declared modes share one plan
+    validated, and nothing declared — the plan learnt from the caller's indexing of link_pred (ops.LinkPred: complete at the
+    first backward) and, with that switched off, from the gradients alone (growing).  The two declared modes share one plan
     and must agree bit for bit."""
     import json
     import os
@@ -649,6 +654,7 @@ def test_dense_backward_under_fixed_masks_while_saturation_moves(case):
     pm, nm = torch.from_numpy(c["pos_mask"]).to(DEV), torch.from_numpy(c["neg_mask"]).to(DEV)
 
     def run(mode):
+        os.environ["DL_LINK_PRED_SUBCLASS"] = "0" if mode == "learnt" else "1"      # "learnt": from the gradients alone; "indexed": from a_pred[mask]
         model = Disentangle(m["F"], m["nhid"], m["d"], nfactor=m["K"], beta=m["beta"], t=m["t"])
         model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in c.items() if k.startswith("sd__")})
         model = model.to(DEV)
@@ -672,7 +678,10 @@ def test_dense_backward_under_fixed_masks_while_saturation_moves(case):
             opt.step()
         return losses, nnz, plan, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
 
-    runs = {mode: run(mode) for mode in ("static", "declared", "learnt")}
+    try:
+        runs = {mode: run(mode) for mode in ("static", "declared", "learnt", "indexed")}
+    finally:
+        os.environ.pop("DL_LINK_PRED_SUBCLASS", None)
     for mode, (losses, nnz, plan, sd) in runs.items():
         np.testing.assert_allclose(losses, g["losses"], rtol=5e-5, err_msg=mode)
         # the same entries saturate as in the reference (an entry whose logit sits on the fp32 boundary p == 1.0 may differ)
@@ -684,6 +693,7 @@ def test_dense_backward_under_fixed_masks_while_saturation_moves(case):
         assert np.array_equal(runs["static"][3][k], runs["declared"][3][k]), k      # ... and weights
     assert runs["learnt"][2][0] < runs["learnt"][2][-1] <= int(g["n_masked"])        # the learnt plan grew towards the masks
     assert runs["learnt"][2][-1] >= int(g["n_masked"]) - 2
+    assert set(runs["indexed"][2]) == {int(((pm == 1) | (nm == 1)).sum())}         # from the indexing: the entries the loss takes, at once
     assert set(runs["static"][2]) == {int(((pm != 0) | (nm != 0)).sum())}
 
 
@@ -2462,3 +2472,70 @@ def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkey
         tests_got.append(res.test_auc)
     assert abs(np.mean(tests_got) - m["test_auc_mean"]) <= 1e-3
     print(f"conv{tag} {mode}: test AUC {np.mean(tests_got):.6f} +- {np.std(tests_got):.6f} (reference {m['test_auc_mean']:.6f} +- {m['test_auc_std']:.6f})")
+
+
+
+@pytest.mark.gpu
+def test_the_unchanged_reference_loop_teaches_the_dense_backward_its_masks_in_one_epoch():
+    """Round 6: the drop-in module inside the reference's loop as it is written
+    (main_disentangled.py:192-214: dense masks, ``a_pred[pos_train_adj == 1]``, F.binary_cross_entropy, Adam, the validation
+    gather after the step) with NOTHING declared.  link_pred is an ops.LinkPred: its indexing tells the module which entries
+    are taken, so the pair plan of dl_score_allpairs_bwd is built from the train masks at the first backward, extended once
+    by the validation mask, and never again — learning from the gradients alone rebuilt it in every epoch, because every
+    epoch desaturates a few more pairs.  Parameters after 12 epochs equal those of the run that declared its masks
+    (assume_static_loss_masks) to rounding, and equal the gradient-learnt run's."""
+    import torch.nn.functional as F
+    from disenlink_amd.model import Disentangle
+    rng = np.random.default_rng(3)
+    N, Fd, K, d = 300, 24, 4, 32
+    src, dst = rng.integers(0, N, 2500), rng.integers(0, N, 2500)
+    ori = torch.zeros(N, N, device=DEV)
+    ori[torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV)] = 1
+    tr = rng.random(2500) < 0.85
+    adj = torch.zeros(N, N, device=DEV)
+    adj[torch.from_numpy(src[tr]).to(DEV), torch.from_numpy(dst[tr]).to(DEV)] = 1
+    adj_sym = ((adj + adj.t()) != 0).float()
+    pos_train_adj = torch.zeros(N, N, device=DEV).index_put_((torch.from_numpy(src[tr]).to(DEV), torch.from_numpy(dst[tr]).to(DEV)),
+                                                             torch.ones(int(tr.sum()), device=DEV), accumulate=True)
+    nu, nv = rng.integers(0, N, 8000), rng.integers(0, N, 8000)
+    neg_train_adj = torch.zeros(N, N, device=DEV).index_put_((torch.from_numpy(nu).to(DEV), torch.from_numpy(nv).to(DEV)),
+                                                             torch.ones(8000, device=DEV), accumulate=True)
+    all_val_adj = torch.zeros(N, N, device=DEV)
+    all_val_adj[torch.from_numpy(src[~tr]).to(DEV), torch.from_numpy(dst[~tr]).to(DEV)] = 1
+    all_val_adj[torch.from_numpy(rng.integers(0, N, 600)).to(DEV), torch.from_numpy(rng.integers(0, N, 600)).to(DEV)] = 1
+    x = torch.from_numpy(rng.standard_normal((N, Fd)).astype(np.float32) * 1.5).to(DEV)      # large enough for saturated scores
+
+    def loop(mode, epochs=12):
+        os.environ["DL_LINK_PRED_SUBCLASS"] = "0" if mode == "gradients" else "1"
+        try:
+            torch.manual_seed(4)
+            model = Disentangle(Fd, 32, d, nfactor=K, beta=0.6, t=1).to(DEV)
+            if mode == "declared":
+                model.assume_static_loss_masks(pos_train_adj, neg_train_adj)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+            builds = []
+            for _ in range(epochs):
+                _h, a_pred = model(x, adj_sym)
+                assert isinstance(a_pred, torch.Tensor)
+                loss = F.binary_cross_entropy(a_pred[pos_train_adj == 1].unsqueeze(0), ori[pos_train_adj == 1].unsqueeze(0)) + \
+                    F.binary_cross_entropy(a_pred[neg_train_adj == 1].unsqueeze(0), ori[neg_train_adj == 1].unsqueeze(0)) / 5
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                pred_score = a_pred[all_val_adj == 1]
+                assert type(pred_score) is torch.Tensor and pred_score.numel() == int((all_val_adj == 1).sum())
+                builds.append(model._dense_plan.rebuilds)
+            return [p.detach().clone() for p in model.parameters()], builds, model
+        finally:
+            os.environ.pop("DL_LINK_PRED_SUBCLASS", None)
+    import os
+    w_idx, b_idx, m_idx = loop("indexing")
+    w_dec, b_dec, _m = loop("declared")
+    w_grd, b_grd, _m = loop("gradients")
+    assert b_dec[-1] == 1                                             # declared: built once
+    assert b_idx[0] == 1 and b_idx[-1] == 2 and b_idx[1] == 2, b_idx   # train masks at the first backward, + the validation mask, then never again
+    support = int(((pos_train_adj != 0) | (neg_train_adj != 0) | (all_val_adj != 0)).sum())
+    assert m_idx._dense_plan.flat.numel() == support
+    for a, b, c in zip(w_idx, w_dec, w_grd):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7) and torch.allclose(a, c, rtol=1e-5, atol=1e-7)
+    assert b_grd[-1] >= b_idx[-1]                                     # what the indexing saves (saturated pairs wake up epoch by epoch)
