@@ -37,9 +37,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase1_seg_kernel(dl_csr_plan g, co
         for (int base = si.beg; base < si.end; base += EPW) {
             const int e = base + grp;
             const bool live = e < si.end;
-            const int j = __shfl(my_col, e - si.beg, DL_WAVE);
-            const int k = __shfl(my_k, e - si.beg, DL_WAVE);
-            const float ae = __shfl(my_a, e - si.beg, DL_WAVE);
+            const int j = entry_scalar<EPW>(my_col, base - si.beg, grp);
+            const int k = entry_scalar<EPW>(my_k, base - si.beg, grp);
+            const float ae = entry_scalar<EPW>(my_a, base - si.beg, grp);
             const size_t oi = (size_t)si.grow * GE::ROW + k * D + c * VEC, oj = (size_t)j * GE::ROW + k * D + c * VEC;
             const float v = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oi), Tab<T>::load(Z + oj)));
             const float vr = omb * group_allreduce_sum<G>(dot(load_f32<VEC>(dH + oj), Tab<T>::load(Z + oi)));
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     dl_csr_plan g, const T* __restrict__ Z, const float* __restrict__ dH, float beta, float t,
     const uint8_t* __restrict__ p, const float* __restrict__ a, const float* __restrict__ s,
     const float* __restrict__ dw, const float* __restrict__ dwr, const float* __restrict__ ds,
-    const float* dz_in, const float* __restrict__ scale, float* dZ, float* __restrict__ dz_part) {
+    const float* dz_in, const float* __restrict__ scale, float* dZ, float* __restrict__ dz_part, int sum_rows_here) {
     // dZ = scale[0] * (dz_in + ...): dz_in may be NULL (0) or dZ itself (accumulate in place), scale may be NULL (1)
     using GE = Geo<K, D, T>;
     using FL = typename GE::FL;
@@ -110,11 +110,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
             my_w2 = omb * ae / s_i;
         }
         for (int base = si.beg; base < si.end; base += EPW) {
-            const int idx = base + grp - si.beg;
-            const int j = __shfl(my_col, idx, DL_WAVE);
-            const int k = __shfl(my_k, idx, DL_WAVE);
-            const float cc = __shfl(my_cc, idx, DL_WAVE);          // 0 past the segment end
-            const float w2 = __shfl(my_w2, idx, DL_WAVE);
+            const int j = entry_scalar<EPW>(my_col, base - si.beg, grp);
+            const int k = entry_scalar<EPW>(my_k, base - si.beg, grp);
+            const float cc = entry_scalar<EPW>(my_cc, base - si.beg, grp);          // 0 past the segment end
+            const float w2 = entry_scalar<EPW>(my_w2, base - si.beg, grp);
             Chunk<VEC> zj[K];
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) zj[kk] = Tab<T>::load(Z + (size_t)j * ROW + kk * D + c * VEC);
@@ -141,6 +140,19 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     if (!ws.head) return;
     float4 r[US::NQ];
     US::sum(red, ws.wave, ws.n_unit, lane, r);
+    if (si.slot >= 0 && sum_rows_here) {                            // a row of several units: the last of them to get here writes dZ[row]
+        if (!publish_unit_and_sum_row<US::F4>(g, si.slot, dz_part, ROW, r, lane)) return;
+#pragma unroll
+        for (int q = 0; q < US::NQ; ++q) {
+            const int x = q * DL_WAVE + lane;
+            if (x < US::F4) {                                       // the combine launch's arithmetic: (dz_in + beta dH + sum) scale
+                const size_t o = (size_t)si.grow * ROW + 4 * x;
+                const float4 acc = dz_in ? load4<float>(dz_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                store4(dZ + o, combine_finish(acc, beta != 0.0f, beta, load4<float>(dH + o), 1.0f, r[q], scale));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < US::NQ; ++q) {
         const int x = q * DL_WAVE + lane;
@@ -178,9 +190,10 @@ struct BwdOps {
     static int bwd_phase2(const dl_csr_plan* g, const void* Z, float beta, float t, const uint8_t* p, const float* a,
                           const float* s, const float* dH, const float* dw, const float* dwr, const float* ds,
                           const float* dz_in, const float* scale, float* dZ, float* dz_part, hipStream_t st) {
+        const bool here = sums_rows_in_launch(g);
         hipLaunchKernelGGL((bwd_phase2_seg_kernel<K, D, T>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, (const T*)Z,
-                           dH, beta, t, p, a, s, dw, dwr, ds, dz_in, scale, dZ, dz_part);
-        if (g->n_multi > 0)
+                           dH, beta, t, p, a, s, dw, dwr, ds, dz_in, scale, dZ, dz_part, here ? 1 : 0);
+        if (g->n_multi > 0 && !here)
             hipLaunchKernelGGL((row_combine_kernel<ROW, float, float>), dim3(g->n_multi), dim3(BLOCK), 0, st, *g,
                                dz_part, ROW, dH, beta, 1.0f, dZ, 0, (const float*)nullptr, (float*)nullptr, dz_in, scale);
         return check_launch("route_aggregate_bwd_phase2(fast)");

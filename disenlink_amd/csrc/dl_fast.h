@@ -131,6 +131,30 @@ struct Geo {
     static_assert(D % VEC == 0 && (G & (G - 1)) == 0 && G <= DL_WAVE, "D must be VEC * a power of two <= 64");
 };
 
+// The per-entry scalar (column, pair id, ...) of the entry this lane's GROUP works on in the current iteration: entry
+// i0 + grp of the segment, held by lane i0 + grp (one entry per lane, loaded once per segment).  i0 is wave-uniform, so
+// with up to four groups per wave (d >= 64) it is four v_readlane with a scalar lane index and three selects — all VALU /
+// SALU; HIP's __shfl is ds_bpermute_b32, a trip through the LDS crossbar whose latency sits in front of every
+// iteration's row gathers (the address needs the column).  More groups (d <= 32): the permute.
+template <int EPW>
+__device__ __forceinline__ int entry_scalar(int v, int i0, int grp) {
+    if constexpr (EPW <= 4) {
+        int r = __builtin_amdgcn_readlane(v, i0 & 63);
+#pragma unroll
+        for (int g = 1; g < EPW; ++g) {
+            const int o = __builtin_amdgcn_readlane(v, (i0 + g) & 63);
+            r = grp == g ? o : r;
+        }
+        return r;
+    } else {
+        return __shfl(v, i0 + grp, DL_WAVE);
+    }
+}
+template <int EPW>
+__device__ __forceinline__ float entry_scalar(float v, int i0, int grp) {
+    return __int_as_float(entry_scalar<EPW>(__float_as_int(v), i0, grp));
+}
+
 // Per-lane softmax pieces of one entry after the transposed reduce: this lane owns factors
 // kb .. kb+VPL-1; ex[i] = exp(sigma/t); S = sum over all K factors (group-wide).
 template <int K, int G>

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 
     for (int base = si.beg; base < si.end; base += EPW) {
         const int e = base + grp;
         const bool live = e < si.end;
-        const int j = __shfl(my_col, e - si.beg, DL_WAVE);
+        const int j = entry_scalar<EPW>(my_col, base - si.beg, grp);
         float part[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLOCK, (K <= 8 && sizeof(T) == 4) ? 8 : (K <= 10 ? 
             group_argmax_first<G>(best, win);
         }
         if (MIRROR) {
-            const int r = __shfl(my_rev, e - si.beg, DL_WAVE);
+            const int r = entry_scalar<EPW>(my_rev, base - si.beg, grp);
             if (live && c == 0) { p[e] = (uint8_t)win; a[e] = best; }
             if (live && c == 1 % G && r != e) { p[r] = (uint8_t)win; a[r] = best; }
         } else {

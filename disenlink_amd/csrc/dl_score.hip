@@ -40,8 +40,8 @@ __global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl
     for (int base = si.beg; base < si.end; base += EPW) {
         const int it = base + grp;
         const bool live = it < si.end;
-        const size_t v = (size_t)__shfl(my_col, it - si.beg, DL_WAVE);
-        const int q = __shfl(my_pair, it - si.beg, DL_WAVE);
+        const size_t v = (size_t)entry_scalar<EPW>(my_col, base - si.beg, grp);
+        const int q = entry_scalar<EPW>(my_pair, base - si.beg, grp);
         // factors are processed in blocks of KB <= 8: at most 2*KB row chunks live at a time, whatever K is
         float term = 0.0f;
 #pragma unroll

@@ -2376,13 +2376,21 @@ def test_rows_of_several_units_summed_inside_the_launch_equal_the_combine_launch
     Z = (torch.randn(N, K, d, generator=torch.Generator().manual_seed(5)) * 0.4).to(DEV)
     Zt = Z if dtype == torch.float32 else Z.to(dtype)
     p, a, s = ops.route_fwd(G, Zt, 1.0)
+    dH = torch.randn(N, K, d, generator=torch.Generator().manual_seed(6)).to(DEV)
+    acc0 = torch.randn(N, K, d, generator=torch.Generator().manual_seed(7)).to(DEV)
     lib_env("DL_INKERNEL_COMBINE", 0)
     ref = ops.aggregate_fwd(G, Zt, 0.55, p, a, s)
+    ref_b = ops.route_aggregate_bwd(G, Zt, 0.55, 1.0, p, a, s, dH)                          # the backward's phase 2 sums such rows too
+    ref_acc = ops.route_aggregate_bwd(G, Zt, 0.55, 1.0, p, a, s, dH, dZ_accum=acc0.clone())   # ... also onto an accumulated input
     for mode in (2, 1):                                               # 2: wherever the kernel can; 1: the default rule (rows of few units)
         lib_env("DL_INKERNEL_COMBINE", mode)
         for rep in range(8):
             got = ops.aggregate_fwd(G, Zt, 0.55, p, a, s)
             assert torch.equal(got, ref), (K, d, mode, rep, float((got.float() - ref.float()).abs().max()))
+            assert int(G.plan.unit_count.abs().sum()) == 0
+        for rep in range(4):
+            assert torch.equal(ops.route_aggregate_bwd(G, Zt, 0.55, 1.0, p, a, s, dH), ref_b), (K, d, mode, rep)
+            assert torch.equal(ops.route_aggregate_bwd(G, Zt, 0.55, 1.0, p, a, s, dH, dZ_accum=acc0.clone()), ref_acc), (K, d, mode, rep)
             assert int(G.plan.unit_count.abs().sum()) == 0
 
 
@@ -2534,7 +2542,7 @@ def test_the_unchanged_reference_loop_teaches_the_dense_backward_its_masks_in_on
     w_grd, b_grd, _m = loop("gradients")
     assert b_dec[-1] == 1                                             # declared: built once
     assert b_idx[0] == 1 and b_idx[-1] == 2 and b_idx[1] == 2, b_idx   # train masks at the first backward, + the validation mask, then never again
-    support = int(((pos_train_adj != 0) | (neg_train_adj != 0) | (all_val_adj != 0)).sum())
+    support = int(((pos_train_adj == 1) | (neg_train_adj == 1) | (all_val_adj == 1)).sum())    # what the loop takes: entries == 1 of the SUMMED masks
     assert m_idx._dense_plan.flat.numel() == support
     for a, b, c in zip(w_idx, w_dec, w_grd):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7) and torch.allclose(a, c, rtol=1e-5, atol=1e-7)

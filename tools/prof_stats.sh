@@ -11,5 +11,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out"
 f=$(find "$out" -name '*kernel_stats.csv' | head -n 1)
 if [ -z "$f" ]; then echo "no kernel_stats.csv for $tag"; tail -n 5 "$out.log"; exit 1; fi
 cp "$f" "$root/gpurun_out/${tag}_kernel_stats.csv"
+grep -v "amdgpu.ids" "$out.log" | tail -n 40 > "$root/gpurun_out/${tag}_stdout.txt"      # what the script itself printed
 echo "== $tag: $*"
 cut -d, -f1-4 "$f" < /dev/null | sed -n 1,9p

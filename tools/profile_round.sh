@@ -18,6 +18,9 @@ bash tools/prof_stats.sh ${tag}_chameleon bench.py --workload chameleon --sectio
 bash tools/prof_stats.sh ${tag}_penn94_K16_d128_bf16 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 10 --warmup 3 --no-cpu-baseline || exit 1
 bash tools/prof_stats.sh ${tag}_training bench.py --sections fwd_bwd,scorer_train --steps 20 --warmup 5 --no-cpu-baseline --warm-s 0 --min-region-s 0 || exit 1
 bash tools/prof_stats.sh ${tag}_penn94_training bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections fwd_bwd --steps 10 --warmup 3 --no-cpu-baseline --warm-s 0 --min-region-s 0 || exit 1
+# the path the one-line swap gives: the reference's dense-mask loop around the drop-in module (tools/dropin_epoch.py)
+bash tools/prof_stats.sh ${tag}_dropin_static tools/dropin_epoch.py squirrel_real 30 static || exit 1
+bash tools/prof_stats.sh ${tag}_dropin_default tools/dropin_epoch.py squirrel_real 30 default || exit 1
 bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32 --sections headline --steps 5 --warmup 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32_train --sections fwd_bwd --steps 5 --warmup 2 || exit 1
 # L2-side request counters (what `moved_bytes` is checked against): headline, training step, hbm_bound
