@@ -287,12 +287,38 @@ def parity_block(prob_cpu, label, prob_gpu, tol_prob=1e-5, what=None, routing=No
     # CPU's summation orders may pick different factors for that edge — the reference against itself on another BLAS does
     # the same.  `routing` = (edges routed differently, largest |a_gpu - a_cpu| among them): with flips present, isolated
     # pairs beyond the tolerance are theirs; the metric's criterion (AUC within 1e-4) and a bound on their number stay.
-    flips, flip_gap = routing if routing is not None else (0, 0.0)
+    flips, flip_gap = routing[:2] if routing is not None else (0, 0.0)
+    near_tie = False
     if routing is not None:
         out["routing_flips"] = {"edges": int(flips), "max_abs_da_at_flips": float(flip_gap)}
-    near_tie = flips > 0 and flip_gap <= 1e-5 and beyond <= max(1, int(1e-4 * label.size))
+        if flips > 0 and len(routing) > 3 and beyond > 0:
+            # a flipped edge (r, c) changes the normalisers s[r], s[c] (model.py:69-72), hence the aggregation weights of every
+            # edge pointing at r or c (model.py:73: att[i, j] = alpha1[i, j] / s[j]), hence H of r, c and all their neighbours
+            # (routing[2]: that node set) — and every scored pair touching one of those nodes.  Nothing else may differ.
+            touched, (pu, pv) = routing[2], routing[3]
+            far = diff > tol_prob
+            explained = touched[pu[far]] | touched[pv[far]]
+            out["routing_flips"].update(nodes_whose_H_changes=int(touched.sum()), pairs_beyond_tolerance_touching_them=int(explained.sum()))
+            near_tie = bool(flip_gap <= 1e-5 and explained.all())
     out["ok"] = bool(abs(auc_gpu - auc_cpu) <= 1e-4 and (dmax <= tol_prob or near_tie))
     return out
+
+
+def routing_flips(p_gpu, a_gpu, p_cpu, a_cpu, rowptr, col, pairs_uv):
+    """-> (edges the GPU and the oracle routed to different factors, largest |a_gpu - a_cpu| among them, bool[N] of the nodes
+    whose H such a flip changes: its endpoints and their neighbours, (pu, pv))."""
+    pg, ag = p_gpu.cpu().numpy(), a_gpu.float().cpu().numpy()
+    fl = np.flatnonzero(pg != p_cpu)
+    n = rowptr.size - 1
+    touched = np.zeros(n, dtype=bool)
+    if fl.size:
+        rows = np.searchsorted(rowptr, fl, side="right") - 1
+        ends = np.unique(np.concatenate([rows, col[fl]]))
+        touched[ends] = True
+        for u in ends:
+            touched[col[rowptr[u]:rowptr[u + 1]]] = True
+    gap = float(np.abs(ag[fl] - a_cpu[fl]).max()) if fl.size else 0.0
+    return (int(fl.size), gap, touched, pairs_uv)
 
 
 def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=30.0, label=None, parity=None, bf16=False):
@@ -317,10 +343,8 @@ def cpu_baseline_sparse(Z_cpu, graph_cpu, pairs_cpu, n_units, beta, t, budget_s=
         dt = time.perf_counter() - t0
         if it == 0 and parity is not None:
             routing = None
-            if len(parity) > 3 and parity[2] is not None:           # the GPU's routing of the same step: count near-tie flips
-                pg_, ag_ = parity[2].cpu().numpy(), parity[3].float().cpu().numpy()
-                fl = pg_ != p
-                routing = (int(fl.sum()), float(np.abs(ag_[fl] - a[fl]).max()) if fl.any() else 0.0)
+            if len(parity) > 3 and parity[2] is not None:           # the GPU's routing of the same step: near-tie flips and what they touch
+                routing = routing_flips(parity[2], parity[3], p, a, rowptr, col, (pu, pv))
             par = parity_block(prob_c, parity[0], parity[1], tol_prob=2e-2 if bf16 else 1e-5, routing=routing,
                                what="timed GPU step (route+aggregate+score on the scored train pairs) vs oracle/c/sparse_ref.c "
                                     "(edge-list form, OpenMP) on the same Z" + (" — bf16-rounded tables on both sides, the oracle's H "
@@ -1119,10 +1143,9 @@ def main():
                 if args.dtype == "bf16":
                     H_c = torch.from_numpy(H_c).to(torch.bfloat16).float().numpy()
                 prob_c = c_ref.score_pairs(Zsh, H_c, pcpu[0].numpy(), pcpu[1].numpy(), t)
-                fl = rs[0].cpu().numpy() != p_c
                 result["parity_unsaturated"] = parity_block(
                     prob_c, label_cpu, ps, tol_prob=2e-2 if args.dtype == "bf16" else 1e-5,
-                    routing=(int(fl.sum()), float(np.abs(rs[1].float().cpu().numpy()[fl] - a_c[fl]).max()) if fl.any() else 0.0),
+                    routing=routing_flips(rs[0], rs[1], p_c, a_c, rp, cl, (pcpu[0].numpy(), pcpu[1].numpy())),
                     what=f"the same step, untimed, on Z x {sc:g} (the workload's own random-init scores saturate) vs oracle/c/sparse_ref.c")
                 result["parity_unsaturated"]["z_scale"] = sc
     print(json.dumps(result), flush=True)

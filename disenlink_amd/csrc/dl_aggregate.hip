@@ -127,15 +127,11 @@ __global__ __launch_bounds__(BLOCK) void aggregate_cls_kernel(dl_csr_plan g, con
     US::sum(red, ws.wave, ws.n_unit, lane, r);
     const float omb = 1.0f - beta;
     if (!direct && sum_rows_here) {                                 // a row of several units: the last of them to get here writes H[row]
-        if (!publish_unit_and_sum_row<US::F4>(g, si.slot, h_part, ROW, r, lane)) return;
-#pragma unroll
-        for (int q = 0; q < US::NQ; ++q) {
-            const int x = q * DL_WAVE + lane;
-            if (x < US::F4) {                                       // the combine launch's arithmetic: 0 + beta z + (1 - beta) sum
-                const float4 z = load4<T>(Z + (size_t)si.grow * ROW + 4 * x);
-                store4(H + (size_t)si.grow * ROW + 4 * x, combine_finish(make_float4(0.f, 0.f, 0.f, 0.f), beta != 0.0f, beta, z, omb, r[q], nullptr));
-            }
-        }
+        publish_unit_and_sum_row<US::F4>(g, si.slot, h_part, ROW, r, lane, [&](int x, const float4& tot) {
+            // the combine launch's arithmetic: 0 + beta z + (1 - beta) sum
+            const float4 z = load4<T>(Z + (size_t)si.grow * ROW + 4 * x);
+            store4(H + (size_t)si.grow * ROW + 4 * x, combine_finish(make_float4(0.f, 0.f, 0.f, 0.f), beta != 0.0f, beta, z, omb, tot, nullptr));
+        });
         return;
     }
 #pragma unroll

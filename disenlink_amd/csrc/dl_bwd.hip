@@ -141,16 +141,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_phase2_seg_kernel(
     float4 r[US::NQ];
     US::sum(red, ws.wave, ws.n_unit, lane, r);
     if (si.slot >= 0 && sum_rows_here) {                            // a row of several units: the last of them to get here writes dZ[row]
-        if (!publish_unit_and_sum_row<US::F4>(g, si.slot, dz_part, ROW, r, lane)) return;
-#pragma unroll
-        for (int q = 0; q < US::NQ; ++q) {
-            const int x = q * DL_WAVE + lane;
-            if (x < US::F4) {                                       // the combine launch's arithmetic: (dz_in + beta dH + sum) scale
-                const size_t o = (size_t)si.grow * ROW + 4 * x;
-                const float4 acc = dz_in ? load4<float>(dz_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-                store4(dZ + o, combine_finish(acc, beta != 0.0f, beta, load4<float>(dH + o), 1.0f, r[q], scale));
-            }
-        }
+        publish_unit_and_sum_row<US::F4>(g, si.slot, dz_part, ROW, r, lane, [&](int x, const float4& tot) {
+            // the combine launch's arithmetic: (dz_in + beta dH + sum) scale
+            const size_t o = (size_t)si.grow * ROW + 4 * x;
+            const float4 acc = dz_in ? load4<float>(dz_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            store4(dZ + o, combine_finish(acc, beta != 0.0f, beta, load4<float>(dH + o), 1.0f, tot, scale));
+        });
         return;
     }
 #pragma unroll

@@ -367,11 +367,12 @@ __global__ __launch_bounds__(BLOCK) void row_combine_kernel(dl_csr_plan g, const
 // counter (plan.unit_count, all zero between launches) is incremented, and the wave whose increment completes the row —
 // it may run on any XCD, at any time — adds the row's slots in EXACTLY the order row_combine_kernel uses (wave w of that
 // kernel takes the slots s0 + w, s0 + w + 4, ...; then ((w0 + w1) + w2) + w3), so both forms give the same bits; it puts
-// the counter back to zero and returns true with the total in o[].  Every other caller returns false.  (Protocol and its
+// the counter back to zero, hands every float4 column of the total to `finish(x, total)` (x = float4 index in the row; the
+// caller's epilogue: it writes the row) and returns true.  Every other caller returns false.  (Protocol and its
 // limits: dl_common.h, "hand-off between units".)  pstride = floats between consecutive slots.
-template <int TOT4>
+template <int TOT4, typename Finish>
 __device__ __forceinline__ bool publish_unit_and_sum_row(const dl_csr_plan& g, int slot, float* __restrict__ part, int pstride,
-                                                         float4 (&o)[(TOT4 + DL_WAVE - 1) / DL_WAVE], int lane) {
+                                                         const float4 (&o)[(TOT4 + DL_WAVE - 1) / DL_WAVE], int lane, Finish&& finish) {
     constexpr int NQ = (TOT4 + DL_WAVE - 1) / DL_WAVE;
     float* mine = part + (size_t)slot * pstride;
 #pragma unroll
@@ -385,45 +386,37 @@ __device__ __forceinline__ bool publish_unit_and_sum_row(const dl_csr_plan& g, i
     old = __builtin_amdgcn_readfirstlane(old);
     if (old != s1 - s0 - 1) return false;
     if (lane == 0) __hip_atomic_store(g.unit_count + m, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody else touches it any more
-    float4 acc[WAVES_PER_BLOCK][NQ];
+    // One float4 column of the row at a time, four slots in flight per round (one per accumulator), in a loop that is NOT
+    // unrolled and indexes no register array: 16 + 16 registers live, so this tail does not set the kernel's register count
+    // (summing all columns at once took the aggregation kernel from 60 to 88 registers — 8 to 5 waves per SIMD — and cost it
+    // 18 % where HBM binds: profiles/r7_hbm_bound_kernel_stats.csv against r6).
+#pragma unroll 1
+    for (int x = lane; x < TOT4; x += DL_WAVE) {
+        float4 acc[WAVES_PER_BLOCK];
 #pragma unroll
-    for (int w = 0; w < WAVES_PER_BLOCK; ++w)
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) acc[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = s0; sl < s1; sl += WAVES_PER_BLOCK) {
+            dl_vf4 v[WAVES_PER_BLOCK];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[w][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // four slots per round (one per accumulator set), each lane's float4s of a slot in flight together
-    for (int sl = s0; sl < s1; sl += WAVES_PER_BLOCK) {
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+                const int sw = sl + w < s1 ? sl + w : s1 - 1;           // clamped: a valid slot, left out below
+                v[w] = load4_sc1_issue(part + (size_t)sw * pstride + 4 * x);
+            }
+            wait_loads_sc1(v[0], v[1], v[2], v[3]);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int x = q * DL_WAVE + lane;
-            if (x < TOT4) {
-                dl_vf4 v[WAVES_PER_BLOCK];
-#pragma unroll
-                for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
-                    const int sw = sl + w < s1 ? sl + w : s1 - 1;       // clamped: a valid slot, added with weight 0 below
-                    v[w] = load4_sc1_issue(part + (size_t)sw * pstride + 4 * x);
-                }
-                wait_loads_sc1(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
-                    if (sl + w < s1) {
-                        acc[w][q].x += v[w].x; acc[w][q].y += v[w].y; acc[w][q].z += v[w].z; acc[w][q].w += v[w].w;
-                    }
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+                if (sl + w < s1) {
+                    acc[w].x += v[w].x; acc[w].y += v[w].y; acc[w].z += v[w].z; acc[w].w += v[w].w;
                 }
             }
         }
-    }
+        float4 t = acc[0];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        float4 t = acc[0][q];
-#pragma unroll
-        for (int w = 1; w < WAVES_PER_BLOCK; ++w) { t.x += acc[w][q].x; t.y += acc[w][q].y; t.z += acc[w][q].z; t.w += acc[w][q].w; }
-        o[q] = t;
+        for (int w = 1; w < WAVES_PER_BLOCK; ++w) { t.x += acc[w].x; t.y += acc[w].y; t.z += acc[w].z; t.w += acc[w].w; }
+        finish(x, t);
     }
     return true;
 }
-// Worth it where such rows are few units long (adjacency plans: hub rows of 2-4 units; one launch and its gap saved — squirrel
-// forward step 210 -> 206 us, chameleon 55.8 -> 54.1, same bits); not for plans that cut EVERY row into 8-16 units (the XCD-
-// sliced incidence plan of the training scorer: the last unit's chain of slot reads lengthens the tail, see dl_train.hip).
 static inline bool sums_rows_in_launch(const dl_csr_plan* g) {
     const int mode = config().inkernel_combine;
     return g->n_multi > 0 && g->slot_multi != nullptr && g->unit_count != nullptr && mode > 0 &&

@@ -1,6 +1,6 @@
 """Forward step (route, aggregate, score) with the rows of several units summed inside the launch against the separate
 combine launches (DL_INKERNEL_COMBINE=0), same process and plans: same bits, time per phase.
-usage: python tools/edge_scatter_ab.py [workload] [K] [d]"""
+usage: python tools/edge_scatter_ab.py [workload] [K] [d] [scale]"""
 import os, sys
 import numpy as np
 import torch
@@ -11,7 +11,8 @@ dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "squirrel_real"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-sg, split, graph, pairs, model, x, Z = bench.build_workload(name, dev, K, d, 512)
+scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+sg, split, graph, pairs, model, x, Z = bench.build_workload(name, dev, K, d, 512, scale=scale)
 t, beta = 1.0, 0.5
 p, a, s = ops.route_fwd(graph, Z, t)
 
@@ -41,7 +42,7 @@ for rnd in range(2):
     for on in (False, True):
         mode(on)
         same = torch.equal(agg(), ref)
-        res.setdefault(on, []).append((timed(agg), timed(step, 20), same))
+        res.setdefault(on, []).append((timed(agg, 50 if sg.n_nodes < 100000 else 8), timed(step, 20 if sg.n_nodes < 100000 else 3), same))
 mode(False)
 print(f"{name} K={K} d={d}: rows of several units {int(graph.plan.multi_row.numel())}, partial slots {graph.plan.n_slots}")
 for on in (False, True):
