@@ -113,6 +113,43 @@ struct W2Stage {
 #define DL_W2_LDS 1               // -DDL_W2_LDS=0: the W2 operand straight from global memory (the round-2 form), for A/B runs
 #endif
 
+// Layer-1 tiles by LDS-DMA (round 6; -DDL_PROJ_DMA=0: the register-staged form, for A/B runs).  A [3][128][32] bf16 plane tile
+// (24 KB, contiguous in the plane array) goes to its padded LDS image — 384 rows of 80 bytes: 4 data pieces + 1 pad piece of
+// 16 bytes — by 30 global_load_lds_dwordx4 wave-instructions: the LDS side of such an instruction is linear (wave-uniform
+// base + 16 bytes per lane), the GLOBAL address is per lane, so lane l of instruction i fetches the piece that belongs at
+// padded position i * 64 + l (a pad position fetches its row's last piece again: a fifth of the requests buy nothing, all of
+// them L2 hits).  No staging registers (the register form held a whole tile pair: 30 registers), no ds_write pass, and no
+// vmcnt(0) in the middle of a step waiting for the tile loads: stamps of the register form showed 1,000-2,200 of a step's
+// 3,800 cycles in "stash" + "fetch issue".  Wave w issues instructions w, w + 8, w + 16, w + 24 of each tile.
+#ifndef DL_PROJ_DMA
+#define DL_PROJ_DMA 1
+#endif
+struct PlaneDma {
+    static constexpr int PIECES = 3 * PLANE_ROWS * 5;           // padded 16-byte positions of a tile
+    static constexpr int INSTR = PIECES / DL_WAVE;               // 30
+    static constexpr int PER_WAVE = (INSTR + NTHR / DL_WAVE - 1) / (NTHR / DL_WAVE);
+    static_assert(PIECES % DL_WAVE == 0 && SPLIT_COLS == 32 && SPLIT_PITCH == 40, "80-byte LDS rows of 64-byte tile rows");
+    unsigned off[PER_WAVE];                                     // byte offset of this lane's piece inside the global tile
+    __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const unsigned pos = (unsigned)((wave + (NTHR / DL_WAVE) * j) * DL_WAVE + lane), row = pos / 5u, slot = pos - row * 5u;
+            off[j] = (row * 4u + (slot < 4u ? slot : 3u)) * 16u;
+        }
+    }
+    __device__ __forceinline__ void issue(const __bf16* __restrict__ tile, __bf16* lds_tile, int wave) const {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int i = wave + (NTHR / DL_WAVE) * j;           // wave-uniform
+            if (i < INSTR)
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(tile) + off[j]),
+                                                 (lptr_t)(reinterpret_cast<char*>(lds_tile) + i * (DL_WAVE * 16)), 16, 0, 0);
+        }
+    }
+};
+
 // Two-layer projection.  W1 [K][nhid][F], b1 [K][nhid], W2 [K][D][nhid], b2 [K][D].
 // VEC: F % 4 == 0 and nhid % 4 == 0.  1-D grid of xcd_grid(node tiles of 128, K * G hidden-chunk groups).
 // out: Z [N][K][D] with b2 != nullptr (G == 1), or slab [G][N][K][D] of partial sums with b2 == nullptr.
@@ -181,10 +218,22 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     TileStage<TN, FC, VEC, NTHR> xt;
     TileStage<TH, FC, VEC, NTHR> wt;
     static_assert(TN == PLANE_ROWS && TH == PLANE_ROWS, "tiles of the plane arrays");
-    PlaneStage<NTHR, SPLIT_COLS> xq, wq;
+    constexpr bool DMA = SPLIT && DL_PROJ_DMA;
+    PlaneStage<NTHR, DMA ? 8 * NTHR / PLANE_ROWS : SPLIT_COLS> xq, wq;   // (DMA: unused — the smallest instantiation)
+    PlaneDma dma;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (DMA) dma.init(wave_s, lane);
+    // DMA: both tiles of step s straight into its parity buffer (which every wave left at the barrier before)
+    auto dma_tile = [&](int s) {
+        const int hc = hc0 + s / nfc, fc = s % nfc;
+        dma.issue(P.x + plane_tile<SPLIT_COLS>(item.a, fc, P.ncb), pbuf + (s & 1) * PBUF, wave_s);
+        dma.issue(P.w + (size_t)k * P.w_batch + plane_tile<SPLIT_COLS>(hc, fc, P.ncb), pbuf + (s & 1) * PBUF + XBUF, wave_s);
+    };
     auto fetch = [&](int s) {
         const int hc = hc0 + s / nfc, fc = s % nfc;
-        if constexpr (SPLIT) {
+        if constexpr (DMA) {
+            (void)hc; (void)fc;
+        } else if constexpr (SPLIT) {
             xq.fetch(P.x + plane_tile<SPLIT_COLS>(item.a, fc, P.ncb), tid);
             wq.fetch(P.w + (size_t)k * P.w_batch + plane_tile<SPLIT_COLS>(hc, fc, P.ncb), tid);
         } else {
@@ -193,7 +242,9 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
         }
     };
     auto stash = [&](int s) {
-        if constexpr (SPLIT) {
+        if constexpr (DMA) {
+            (void)s;
+        } else if constexpr (SPLIT) {
             xq.stash(pbuf + (s & 1) * PBUF, tid);
             wq.stash(pbuf + (s & 1) * PBUF + XBUF, tid);
         } else {
@@ -221,7 +272,10 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
     // of the first MFMA block of step s (every wave left that buffer at the barrier before), and the loads of
     // tile s+2 are issued right behind it.
     if (steps > 0) {
-        if constexpr (SPLIT) {
+        if constexpr (DMA) {
+            dma_tile(0);                                          // tiles 0 and 1 on their way into the two buffers together
+            if (steps > 1) dma_tile(1);
+        } else if constexpr (SPLIT) {
             // tiles 0 and 1 in flight together (a second register set while no accumulator is live yet): one global
             // round trip in the prologue instead of two — a workgroup runs only 8 steps at F = 128
             PlaneStage<NTHR, SPLIT_COLS> x0, w0;
@@ -244,6 +298,11 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
         const bool last = fc == nfc - 1;
         const int hbase = hc * TH + wh * 64;                    // first hidden unit of this wave's tile
         DL_STAMP(10);
+        if constexpr (DMA) {
+            // tile s + 1 into the other buffer — free since the barrier that ended step s - 1 — with the whole step to land
+            // (tile 1 left in the prologue); the barrier at the end of this step waits for it (vmcnt(0) + s_barrier)
+            if (s >= 1 && s + 1 < steps) dma_tile(s + 1);
+        }
         float4 bias[2][4], wnext[2][4];                         // quad g of tile ht = hidden rows 8g+4*half .. +3
         if constexpr (!SPLIT) {
             if (last) {
