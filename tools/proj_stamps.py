@@ -17,7 +17,7 @@ lib.dl_debug_read_stamps.restype = C.c_int
 assert lib.dl_debug_read_stamps(buf) == 0
 a = np.array(buf[:], dtype=np.uint64).reshape(2, 512)
 names = {1: "start", 2: "prologue loads issued+stashed", 3: "after prologue barrier", 10: "step top", 11: "LDS operands read issued", 12: "12 MFMAs issued (block 0)",
-         13: "stash(s+1) done", 14: "fetch(s+2) issued", 15: "12 MFMAs issued (block 1)", 16: "before barrier", 17: "after barrier", 20: "bias+ReLU done",
+         13: "stash(s+1) done [LDS-DMA build: nothing to stash — bias / W2 requests]", 14: "fetch(s+2) issued [LDS-DMA build: no-op]", 15: "12 MFMAs issued (block 1)", 16: "before barrier", 17: "after barrier", 20: "bias+ReLU done",
          21: "planes split (layer 2 ready)", 22: "layer-2 MFMAs issued", 30: "Z hand-over staged", 31: "end"}
 for w in range(2):
     n = int(a[w, 511]); t = a[w, :n] & np.uint64((1 << 56) - 1); code = (a[w, :n] >> np.uint64(56)).astype(int)
