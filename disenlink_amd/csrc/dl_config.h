@@ -10,6 +10,7 @@ struct Config {
     int stream_rows;            // DL_STREAM_ROWS: -1 = by table size (default), 0 / 1 = never / always stream the H rows
     bool route_ballot;          // DL_ROUTE_BALLOT=1: ballot arg-max in the router (measured slower)
     bool train_group_kernel;    // DL_TRAIN_GROUP_KERNEL: group-per-entry one-pass scorer instead of the wave-per-entry ones
+    bool fwd_group_kernel;      // DL_FWD_GROUP_KERNEL: group-per-entry forward scorer instead of the wave-per-entry one
     int auc_target;             // DL_AUC_TARGET: workgroups of the AUC count kernel (0 = default)
     bool project_fp32_mfma;     // DL_PROJECT_FP32_MFMA: plain fp32 MFMA projection instead of the three-plane products
     int fwd_groups;             // DL_FWD_GROUPS: hidden-chunk groups of the projection forward (0 = default)

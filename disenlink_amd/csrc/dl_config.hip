@@ -26,6 +26,7 @@ void read_environment() {
     c.stream_rows = (sr == nullptr || sr[0] == '\0') ? -1 : (sr[0] == '1' ? 1 : 0);
     c.route_ballot = flag("DL_ROUTE_BALLOT");
     c.train_group_kernel = flag("DL_TRAIN_GROUP_KERNEL");
+    c.fwd_group_kernel = flag("DL_FWD_GROUP_KERNEL");
     c.auc_target = (int)std::max(0LL, number("DL_AUC_TARGET"));
     c.project_fp32_mfma = getenv("DL_PROJECT_FP32_MFMA") != nullptr;
     c.fwd_groups = (int)std::max(0LL, number("DL_FWD_GROUPS"));

@@ -204,6 +204,32 @@ __device__ __forceinline__ void store4_stream(bf16_t* p, const float4& v) {
     __builtin_nontemporal_store(q, reinterpret_cast<vu2*>(p));
 }
 
+// 4-element dot product as two packed operations and one add (v_pk_mul_f32, v_pk_fma_f32: two lanes of fp32 per
+// instruction on gfx950) instead of a chain of four; symmetric in its arguments, so both endpoints of a pair still
+// compute the same bits.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot4_packed(const float4& a, const float4& b) {
+    const v2f a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    const v2f p = __builtin_elementwise_fma(a1, b1, a0 * b0);
+    return p.x + p.y;
+}
+
+// A table row whose index is WAVE-UNIFORM (the wave-per-entry kernels: the 64 lanes share one gathered row), as a pointer
+// the compiler keeps in SGPRs and knows to be global: `row[(unsigned)(lane + j * 64)]` then compiles to
+//     global_load_dwordx4 v[..], v_lane_off, s[base:base+1] offset:1024 j
+// — one 32-bit lane offset register for every load of the kernel and the row base in two SGPRs.  (The empty asm keeps the
+// byte offset a scalar that is not folded into a hoisted per-table vector base.  Round 6: the earlier spelling passed the
+// POINTER through the empty asm, which hid its address space — the gathers came out as flat_load_dwordx4 with a 64-bit
+// vector address each, counted on lgkmcnt as well as vmcnt.)
+template <typename V>
+__device__ __forceinline__ const __attribute__((address_space(1))) V* uniform_row(const void* table, size_t byte_off) {
+    const __attribute__((address_space(1))) char* row =
+        reinterpret_cast<const __attribute__((address_space(1))) char*>((const __attribute__((address_space(1))) void*)table) + byte_off;
+    asm volatile("" : "+s"(row));        // a scalar the optimiser cannot take apart again — and, typed, still a GLOBAL pointer behind it
+    return reinterpret_cast<const __attribute__((address_space(1))) V*>(row);
+}
+__device__ __forceinline__ float4 as_float4(dl_vf4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+
 // ---------------------------------------------------------------------------- unit reduction through LDS
 // A segment kernel ends with per-GROUP partial results: lane c of group g holds elements kk*D + c*VEC .. of every factor
 // kk, summed over the entries its group walked.  Adding the 64/G groups of a wave with cross-lane butterflies costs

@@ -75,6 +75,106 @@ __global__ __launch_bounds__(BLOCK, K <= 8 ? 4 : 1) void score_fwd_seg_kernel(dl
     }
 }
 
+// ---------------------------------------------------------------------------- forward scorer, wave per entry (round 6)
+// The forward pass in the geometry of the one-pass training scorer (dl_train.hip: score_train_wave_kernel) for d = 64,
+// K in {4, 8}, fp32 tables: the 64 lanes share ONE pair, lane l holds float4 number j * 64 + l of a row (a DPP row of 16
+// lanes = one factor slice), the row base is a scalar (readlane of the segment's columns) and the lane offset a constant,
+// the u rows are re-read from the wave's LDS region every step, U = 4 pairs per step, the 16 partial dot products reduced
+// over the DPP row by one transposed reduction: one expf and one sigmoid per step.  No accumulators, so fewer registers
+// than the training kernel; the arithmetic up to the probability is that kernel's, operation for operation — the two give the
+// same bits.  The group-per-entry kernel above stays for every other shape (and as the reference form: -DDL_FWD_WAVE_KERNEL=0).
+// Why: the training kernel's bound build ran these very gathers, without arithmetic, at 0.86 of the L2 peak; the
+// group-per-entry forward reached 0.79.
+#ifndef DL_FWD_WAVE_KERNEL
+#define DL_FWD_WAVE_KERNEL 1
+#endif
+#ifndef DL_FWD_WAVE_MAXW
+#define DL_FWD_WAVE_MAXW 6            // waves per SIMD the register allocation aims at (4 / 5 / 6 measured: 156.6 / 156.8 / 154.4 us, profiles/r7n_*)
+#endif
+template <int K, int D>
+struct FwdWave {
+    static constexpr bool ok = DL_FWD_WAVE_KERNEL && D == 64 && (K == 4 || K == 8);
+    static constexpr int NJ = K * D / 256, U = 4;
+};
+
+// (amdgpu_waves_per_eu(4, 5): left to itself hipcc aims at 8 waves per SIMD = 64 registers — exactly the 16 gathered float4 of a
+// step — by requesting only 12 of them up front and the rest behind three more vmcnt(0) round trips per step.)
+template <int K, int D, bool T1, bool COEF>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, DL_FWD_WAVE_MAXW))) void score_fwd_wave_kernel(dl_csr_plan g, const int32_t* __restrict__ pair_id,
+                                                                  const float* __restrict__ Z, const float* __restrict__ H, float t,
+                                                                  float* __restrict__ prob, float* __restrict__ coef_e,
+                                                                  float* __restrict__ coef_q) {
+    using FW = FwdWave<K, D>;
+    constexpr int NJ = FW::NJ, U = FW::U, ROW = K * D;
+    static_assert(D == 64 && NJ >= 1 && U * NJ <= 8, "one DPP row of 16 lanes per factor slice; at most 8 exponents per row and step");
+    __shared__ __attribute__((aligned(16))) float4 urow[WAVES_PER_BLOCK][2 * ROW / 4];      // [Z row | H row] of the segment's u
+    __shared__ int ent_q[WAVES_PER_BLOCK][DL_WAVE];
+    const WaveSeg ws = load_wave_seg(g);
+    if (!ws.active) return;                                         // no barrier in this kernel: every region is its wave's own
+    const SegInfo si = ws.si;
+    const int wave = ws.wave, lane = lane_id();
+    const int i = lane & 15, r = lane >> 4;                         // position in the DPP row; the row holds the factors r, r + 4
+    float4* const mine = urow[wave];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        mine[j * 64 + lane] = *reinterpret_cast<const float4*>(Z + (size_t)si.grow * ROW + (j * 64 + lane) * 4);
+        mine[ROW / 4 + j * 64 + lane] = *reinterpret_cast<const float4*>(H + (size_t)si.grow * ROW + (j * 64 + lane) * 4);
+    }
+    int my_col = si.grow, my_q = 0;
+    if (si.beg + lane < si.end) {
+        my_col = g.col[si.beg + lane];
+        my_q = pair_id[si.beg + lane];
+    }
+    ent_q[wave][lane] = my_q;                                       // written and read by this wave only
+    const int nsteps = (si.end - si.beg + U - 1) / U;               // entries past the end repeat a valid row, nothing is stored for them
+    for (int step = 0; step < nsteps; ++step) {
+        float4 zv[U][NJ], hv[U][NJ];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const size_t v = (size_t)(unsigned)__builtin_amdgcn_readlane(my_col, (step * U + e) & 63);
+            const auto* zr = uniform_row<dl_vf4>(Z, v * ROW * sizeof(float));     // row base in SGPRs (dl_fast.h)
+            const auto* hr = uniform_row<dl_vf4>(H, v * ROW * sizeof(float));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                zv[e][j] = as_float4(zr[(unsigned)(lane + j * 64)]);
+                hv[e][j] = as_float4(hr[(unsigned)(lane + j * 64)]);
+            }
+        }
+        float val[16];                                              // index = table * 8 + chunk * 4 + entry
+#pragma unroll
+        for (int x = 0; x < 16; ++x) val[x] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4 a4 = mine[j * 64 + lane], b4 = mine[ROW / 4 + j * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                val[j * 4 + e] = dot4_packed(a4, zv[e][j]);
+                val[8 + j * 4 + e] = dot4_packed(b4, hv[e][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TransposedReduce<16, 8>::run(val, i);                       // lane i: sum number i — below 8: z_u . z_v of (chunk i / 4, entry i % 4), above: h_u . h_v
+        const float mine_v = val[0];
+        const float ex = expf(T1 ? mine_v : mine_v / t);
+        const float ttv = mine_v * xor_lane<8>(ex);                 // lanes 8..15: (h.h) e^(z.z / t) of (chunk, entry)
+        float term = ttv;
+        if constexpr (NJ == 2) term += xor_lane<4>(ttv);
+        const float logit = add_xor<32>(add_xor<16>(term));         // over the 4 DPP rows: all factors
+        const float p = sigmoid_ref(logit);
+        const int idx = step * U + (i & 3);
+        const bool live = si.beg + idx < si.end;
+        const int qq = ent_q[wave][idx & 63];
+        if (lane >= 8 && lane < 12 && live) prob[qq] = p;
+        if constexpr (COEF) {                                       // per-factor terms for the separate backward: e_k, q_k e_k
+            const int k = 4 * ((i & 7) >> 2) + r;                   // the factor this lane's sum belongs to (chunk j holds the factors 4 j + r)
+            if (live && (NJ == 2 || (i & 7) < 4)) {
+                if (i < 8) coef_e[(size_t)qq * K + k] = ex;
+                else coef_q[(size_t)qq * K + k] = ttv;
+            }
+        }
+    }
+}
+
 // Dense [N][N] scorer (the reference's link_pred, model.py:109-113): no pair list at all.  One wave = one
 // row u x one chunk of <= VCH consecutive columns; the column space is cut into n_slices XCD slices exactly
 // like the pair plans (workgroup b serves slice b % n_slices), so an XCD's L2 holds the v rows it gathers.
@@ -206,6 +306,17 @@ struct ScoreOps {
                          float* coef, hipStream_t st) {
         const dl_csr_plan* g = &by_u->csr;
         float* coef_q = coef ? coef + (size_t)by_u->n_pairs * K : nullptr;
+        if constexpr (std::is_same<T, float>::value && FwdWave<K, D>::ok) {
+            if (g->seg_len <= 64 && g->seg_len % FwdWave<K, D>::U == 0 && !config().fwd_group_kernel) {
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g, by_u->inc_pair, (const float*)Z,
+                                       (const float*)H, t, prob, coef, coef_q);
+                };
+                if (coef) { if (t == 1.0f) launch(score_fwd_wave_kernel<K, D, true, true>); else launch(score_fwd_wave_kernel<K, D, false, true>); }
+                else { if (t == 1.0f) launch(score_fwd_wave_kernel<K, D, true, false>); else launch(score_fwd_wave_kernel<K, D, false, false>); }
+                return check_launch("score_pairs_fwd(fast, wave per entry)");
+            }
+        }
         if (coef)
             hipLaunchKernelGGL((score_fwd_seg_kernel<K, D, T, true>), dim3(seg_blocks(g)), dim3(BLOCK), 0, st, *g,
                                by_u->inc_pair, (const T*)Z, (const T*)H, t, prob, coef, coef_q);

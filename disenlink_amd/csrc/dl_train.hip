@@ -48,15 +48,7 @@ __device__ __forceinline__ float row_allreduce_sum(float v) {
     return add_dpp<0x121>(v);   // row_ror:1
 }
 
-// 4-element dot product as two packed operations and one add (v_pk_mul_f32, v_pk_fma_f32: two lanes of fp32 per
-// instruction on gfx950) instead of a chain of four; symmetric in its arguments, so both endpoints of a pair still
-// compute the same bits.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float dot4_packed(const float4& a, const float4& b) {
-    const v2f a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
-    const v2f p = __builtin_elementwise_fma(a1, b1, a0 * b0);
-    return p.x + p.y;
-}
+// (dot4_packed: dl_fast.h — shared with the wave-per-entry forward scorer of dl_score.hip)
 
 #ifndef DL_TRAIN_WAVE_KERNEL
 #define DL_TRAIN_WAVE_KERNEL 1        // -DDL_TRAIN_WAVE_KERNEL=0: the group-per-entry kernel above, for A/B runs
@@ -131,15 +123,12 @@ __global__ __launch_bounds__(BLOCK, (UREG ? 3 : 4)) void score_train_wave_kernel
                 const size_t v = (size_t)(unsigned)__builtin_amdgcn_readlane(my_col, (step * U + e) & 63);
                 // the row base stays a SCALAR (the empty asm keeps the compiler from folding the loop-invariant lane offset
                 // into a hoisted 64-bit vector base per table): global_load ... v_lane_offset, s[base] — 3 registers fewer
-                const float* zs = Z + v * ROW;
-                const float* hs = H + v * ROW;
-                asm volatile("" : "+s"(zs), "+s"(hs));
-                const float* zr = zs + lane * 4;
-                const float* hr = hs + lane * 4;
+                const auto* zr = uniform_row<dl_vf4>(Z, v * ROW * sizeof(float));
+                const auto* hr = uniform_row<dl_vf4>(H, v * ROW * sizeof(float));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    zv[e][j] = *reinterpret_cast<const float4*>(zr + j * 256);
-                    hv[e][j] = *reinterpret_cast<const float4*>(hr + j * 256);
+                    zv[e][j] = as_float4(zr[(unsigned)(lane + j * 64)]);
+                    hv[e][j] = as_float4(hr[(unsigned)(lane + j * 64)]);
                 }
             }
         };
@@ -410,6 +399,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void score_train_wide_kernel(
             for (int u = 0; u < U; ++u) {
                 // the entry is wave-uniform: its row address is a scalar base, the lane offset a constant
                 const size_t v = (size_t)(unsigned)__builtin_amdgcn_readlane(my_col, (step * U + u) & 63);
+                // (the scalar-base global_load form of the d = 64 kernels — uniform_row, dl_fast.h — measured 0.8 % SLOWER here:
+                // Penn94-shaped bf16 14.50 vs 14.38 ms, profiles/r7n_*; this spelling gives flat loads with 64-bit vector addresses)
                 const T* zs = Z + v * ROW;
                 const T* hs = H + v * ROW;
                 asm volatile("" : "+s"(zs), "+s"(hs));
