@@ -57,7 +57,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: dense bf16 MFMA
 # kernels launched by each phase of the step (names as rocprofv3 reports them, template arguments stripped)
 PHASE_KERNELS = {"route": ("route_seg_kernel", "s_rowsum_thread_kernel"),
                  "aggregate": ("aggregate_cls_kernel", "row_combine_kernel"),
-                 "score": ("score_fwd_seg_kernel",)}
+                 "score": ("score_fwd_seg_kernel", "score_fwd_wave_kernel")}
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 NAMES = ("route", "aggregate", "score")
 
