@@ -2547,3 +2547,40 @@ def test_the_unchanged_reference_loop_teaches_the_dense_backward_its_masks_in_on
     for a, b, c in zip(w_idx, w_dec, w_grd):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7) and torch.allclose(a, c, rtol=1e-5, atol=1e-7)
     assert b_grd[-1] >= b_idx[-1]                                     # what the indexing saves (saturated pairs wake up epoch by epoch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [8, 4])
+@pytest.mark.parametrize("t", [1.0, 2.0])
+def test_wave_per_entry_forward_scorer_gives_the_training_scorers_bits(K, t, lib_env):
+    """Round 6: score_fwd_wave_kernel (d = 64, fp32) — the forward scorer in the geometry of the one-pass training scorer.
+    Its probabilities are the training scorer's bit for bit (the same operations up to the sigmoid), the pass that stores the
+    per-factor terms for the separate backward gives the same probabilities as the plain pass, and the group-per-entry
+    kernel it replaces at this shape (DL_FWD_GROUP_KERNEL=1; still the kernel of every other shape) agrees to rounding in
+    probabilities and stored terms — on a problem with saturated scores, self pairs, rows of many segments."""
+    from disenlink_amd import ops
+    G, pairs, Z, label, weight, pu, pv = _one_pass_case(K, 64, torch.float32, seed=77 + K)
+    H = ops.aggregate_fwd(G, Z, 0.6, *ops.route_fwd(G, Z, t))
+    lib_env("DL_FWD_GROUP_KERNEL")
+    prob_w = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs)
+    prob_wc, coef_w = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+    prob_t = ops.score_pairs_train(Z, H, pairs, t, label, weight)[0]
+    assert torch.equal(prob_w, prob_t) and torch.equal(prob_wc, prob_w)
+    lib_env("DL_FWD_GROUP_KERNEL", 1)
+    prob_g, coef_g = ops.score_pairs_fwd(Z, H, pairs.pu, pairs.pv, t, pairs, want_coef=True)
+    lib_env("DL_FWD_GROUP_KERNEL")
+    assert float((prob_g - prob_w).abs().max()) <= 3e-7
+    assert int((prob_w == 1.0).sum()) >= 20                            # the saturated pairs are there
+    fin = torch.isfinite(coef_g)
+    assert torch.equal(fin, torch.isfinite(coef_w))
+    for plane in range(2):                                              # e_k and q_k e_k, each against its own largest finite value
+        m = fin[plane]
+        err = (coef_w[plane][m] - coef_g[plane][m]).abs().max()
+        assert float(err) <= 1e-5 * float(coef_g[plane][m].abs().max()), (plane, float(err))
+    # both backward forms from the wave kernel's stored terms agree with the one-pass gradients (through the loss gradient)
+    pr = prob_w.detach().clone().requires_grad_(True)
+    (g_prob,) = torch.autograd.grad(ops.PairBCE.apply(pr, label, weight), pr)
+    dZ0, dH0 = ops.score_pairs_bwd(Z, H, pairs, t, prob_w, g_prob, coef=coef_w)
+    _p, dZ1, dH1 = ops.score_pairs_train(Z, H, pairs, t, label, weight)
+    for a, b in ((dZ0, dZ1), (dH0, dH1)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
