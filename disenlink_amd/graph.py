@@ -67,9 +67,14 @@ def auto_slices(n_nodes: int, row_bytes: int, entries_per_row: float = 1e9, n_ta
     forced = os.environ.get("DL_FORCE_SLICES")               # experiments only
     if forced:
         return int(forced)
+    table = float(n_nodes) * row_bytes * n_tables
+    # small tables: the FEWEST slices that put a slice inside an L2 (round 6, wave-per-entry scorer: chameleon — 9.3 MB —
+    # 34.0 / 32.4 / 34.3 / 40.9 us at 2 / 4 / 8 / 16 slices, profiles/r7q_fwd_slices.txt; squirrel — 21.3 MB — needs the 8)
+    for few in (1, 2, 4):
+        if table / few <= 0.7 * L2_BYTES_PER_XCD:
+            return few if entries_per_row >= 4 * few else 1
     if entries_per_row < 2 * DEFAULT_SLICES:                     # rows too short to be cut 8 ways
         return 1
-    table = float(n_nodes) * row_bytes * n_tables
     t_cap = 1
     while 2 * t_cap * DEFAULT_SLICES * 4 <= entries_per_row:       # keep >= 4 entries per (row, slice)
         t_cap *= 2
