@@ -137,6 +137,46 @@ def load_twitch(lang_dir: str, lang: str, standardise: bool = True) -> LinkDatas
     return LinkDataset(f"twitch-{lang}", standardise_rows(x) if standardise else x, src, dst)
 
 
+def load_webkb(raw_dir: str, name: str, standardise: bool = True) -> LinkDataset:
+    """texas / cornell / wisconsin (``WebKB(root, name)`` of main_disentangled.py:69-71, 91-96): the geom-gcn text
+    pair ``out1_node_feature_label.txt`` / ``out1_graph_edges.txt``; edge rows coalesced (sorted by (src, dst),
+    duplicates dropped), directed and self-loops kept — what ``<name>/processed/data.pt`` of the reference holds."""
+    ds = load_geom_gcn(os.path.join(raw_dir, "out1_graph_edges.txt"), os.path.join(raw_dir, "out1_node_feature_label.txt"),
+                       name=name, standardise=standardise)
+    n = ds.n_nodes
+    key = np.unique(ds.src * n + ds.dst)
+    return LinkDataset(name, ds.x, key // n, key % n)
+
+
+def load_amazon_npz(path: str, name: str = "photo", standardise: bool = True) -> LinkDataset:
+    """Amazon photo ``amazon_electronics_photo.npz`` (``Amazon(root, name)`` of main_disentangled.py:66-68, 85-90):
+    attributes and adjacency as CSR triplets; attributes binarised (> 0 -> 1), self-loops removed, edge rows made
+    undirected and coalesced.  The raw blob is absent from the reference tree: format pinned by a synthetic file only."""
+    import scipy.sparse as sp
+    with np.load(path, allow_pickle=True) as f:
+        x = sp.csr_matrix((f["attr_data"], f["attr_indices"], f["attr_indptr"]), shape=tuple(f["attr_shape"])).toarray()
+        adj = sp.csr_matrix((f["adj_data"], f["adj_indices"], f["adj_indptr"]), shape=tuple(f["adj_shape"])).tocoo()
+    x = (np.asarray(x) > 0).astype(np.float32)
+    n = x.shape[0]
+    src, dst = adj.row.astype(np.int64), adj.col.astype(np.int64)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = np.unique(np.concatenate([src * n + dst, dst * n + src]))
+    return LinkDataset(name, standardise_rows(x) if standardise else x, key // n, key % n)
+
+
+def load_deezer(mat_path: str, standardise: bool = True) -> LinkDataset:
+    """deezer-europe ``.mat`` (other_hetero_datasets.py:156-173): ``A.nonzero()`` as the edge rows, ``features`` dense.
+    The blob is absent from the reference tree: format pinned by a synthetic file only."""
+    import scipy.io
+    mat = scipy.io.loadmat(mat_path)
+    row, col = mat["A"].nonzero()
+    feats = mat["features"]
+    x = np.asarray(feats.todense() if hasattr(feats, "todense") else feats, dtype=np.float32)
+    return LinkDataset("deezer-europe", standardise_rows(x) if standardise else x, row.astype(np.int64),
+                       col.astype(np.int64))
+
+
 def save_binary(ds: LinkDataset, path: str) -> None:
     np.savez_compressed(path, x=ds.x, src=ds.src.astype(np.int64), dst=ds.dst.astype(np.int64), name=np.array(ds.name))
 

@@ -80,7 +80,14 @@ def load_dataset(args):
             return datasets.load_fb100(os.path.join(root, "facebook100", args.sub_dataset + ".mat"), args.sub_dataset)
         if name == "twitch-e":                                      # :62-64, 109-116
             return datasets.load_twitch(os.path.join(root, "twitch", args.sub_dataset), args.sub_dataset)
-        raise SystemExit(f"no loader for --dataset {name}")
+        if name in ("texas", "wisconsin", "cornell"):               # :69-71, 91-96
+            return datasets.load_webkb(os.path.join(root, name, "raw"), name)
+        if name == "photo":                                         # :66-68, 85-90
+            return datasets.load_amazon_npz(os.path.join(root, "Photo", "raw", "amazon_electronics_photo.npz"))
+        if name == "deezer-europe":                                 # :58-59, 109-113
+            return datasets.load_deezer(os.path.join(root, "deezer-europe.mat"))
+        raise SystemExit(f"no loader for --dataset {name} (ogbn-proteins / arxiv-year / yelp-chi need the ogb download "
+                         f"layout: convert with datasets.save_binary and pass --data-file)")
     key = {"fb100": "penn94", "snap-patents": "snap_patents"}.get(args.dataset, args.dataset)
     if key not in SPECS:
         raise SystemExit(f"no data for --dataset {args.dataset}: give --data-root / --data-file")

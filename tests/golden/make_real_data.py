@@ -7,7 +7,8 @@ Run (this container only; needs /root/reference):  python tests/golden/make_real
 Writes tests/golden/real_chameleon.npz: the dataset arrays of the reference's
 data_pre_false/chameleon/raw/chameleon.npz that the run uses (features fp32 [2277,128], edge rows as uint16
 [72202,2] — data, not code) — and tests/golden/real_cora.npz from the Planetoid files of data/cora/raw (binary
-features as index pairs, 10,556 edge rows; BASELINE.json's "Cora, K=4, d=32" config) — and what the reference model produced: per-epoch loss and validation AUC
+features as index pairs, 10,556 edge rows; BASELINE.json's "Cora, K=4, d=32" config), tests/golden/real_texas.npz from
+data/texas/raw (WebKB; hyperparameters_setting:5) — and what the reference model produced: per-epoch loss and validation AUC
 (sklearn.roc_auc_score), test AUC with the best weights.  The model is initialised from torch.manual_seed(SEED)
 (same creation order in the drop-in module, so the same weights); the split comes from make_link_split(seed=0).
 """
@@ -29,7 +30,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 RUNS = {"chameleon": (7, 8, 64, 512, 0.5, 1, 5, 1e-4, 30), "cora": (11, 4, 32, 512, 0.6, 1, 5, 1e-3, 30),
         # squirrel: the real edge list (geom-gcn) with seeded N(0,1) features, F=128 — the feature blob is missing from
         # the reference tree; BASELINE.json configs[2]
-        "squirrel": (13, 8, 64, 512, 0.5, 1, 5, 1e-4, 20)}
+        "squirrel": (13, 8, 64, 512, 0.5, 1, 5, 1e-4, 20),
+        # texas (WebKB): hyperparameters_setting:5 — 183 nodes, 1,703 binary features standardised per row (:91-96)
+        "texas": (17, 5, 32, 512, 0.6, 1, 5, 1e-4, 30)}
 
 
 def dense(u, v, n):
@@ -64,6 +67,15 @@ def run(name, ref_model):
         feats = np.random.default_rng(SEED).standard_normal((ds.n_nodes, 128), dtype=np.float32)
         x = standardise_rows(feats)
         stored = dict(feat_seed=np.int64(SEED), feat_shape=np.array(feats.shape))
+    elif name == "texas":                                        # WebKB text files, rows standardised (:91-96)
+        from disenlink_amd.datasets import load_webkb
+        ds = load_webkb(os.path.join(REF, "data/texas/raw"), "texas", standardise=False)
+        feats, edges = ds.x, np.stack([ds.src, ds.dst], axis=1)
+        x = standardise_rows(feats)
+        r, c = np.nonzero(feats)
+        assert np.all(feats[r, c] == 1.0)
+        stored = dict(feat_row=r.astype(np.uint16), feat_col=c.astype(np.uint16), feat_shape=np.array(feats.shape),
+                      standardise=np.int64(1))
     else:                                                        # Planetoid files, binary features, not standardised (:117-123)
         ds = load_planetoid(os.path.join(REF, "data/cora/raw"), "cora")
         feats, edges = ds.x, np.stack([ds.src, ds.dst], axis=1)

@@ -145,3 +145,92 @@ def test_twitch_de_equals_the_references_arrays():
     assert ds.n_nodes == n and np.array_equal(ds.x, features.astype(np.float32))
     key = lambda a, b: np.sort(a * n + b)
     assert np.array_equal(key(ds.src, ds.dst), key(want_src, want_dst))
+
+
+def _processed_tensors(path):
+    """The tensors of a torch_geometric ``processed/data.pt`` without torch_geometric: its classes unpickle as
+    attribute bags (the file is data; nothing of the reference is executed)."""
+    import pickle
+    import types
+    import torch
+
+    class Bag:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            self.__dict__["state"] = state
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, mod, name):
+            return type(name, (Bag,), {}) if mod.startswith("torch_geometric") else super().find_class(mod, name)
+
+    pm = types.ModuleType("pickle")
+    pm.Unpickler, pm.load = Unpickler, (lambda f, **k: Unpickler(f, **k).load())
+    data = torch.load(path, pickle_module=pm, weights_only=False)[0]
+    store = data.state["_store"].state
+    return store.get("_mapping", store)
+
+
+@pytest.mark.parametrize("name,n,rows,loops", [("texas", 183, 325, 16), ("cornell", 183, 298, 3), ("wisconsin", 251, 515, 16)])
+def test_webkb_equals_the_reference_processed_file(name, n, rows, loops):
+    """main_disentangled.py:69-71: WebKB(root, name)[0] — x and edge_index of the reference's own processed file."""
+    import torch
+    from disenlink_amd.datasets import load_webkb
+    raw = _need(f"{REF}/data/{name}/raw")
+    ds = load_webkb(raw, name, standardise=False)
+    assert ds.n_nodes == n and ds.x.shape == (n, 1703) and ds.src.size == rows and int((ds.src == ds.dst).sum()) == loops
+    m = _processed_tensors(_need(f"{REF}/data/{name}/processed/data.pt"))
+    assert np.array_equal(np.stack([ds.src, ds.dst]), m["edge_index"].numpy())
+    assert np.array_equal(ds.x, m["x"].numpy())
+    t = m["x"]
+    want = (t - t.mean(dim=1, keepdim=True)) / t.std(dim=1).unsqueeze(1)               # :95
+    np.testing.assert_allclose(load_webkb(raw, name).x, want.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_amazon_npz_format(tmp_path):
+    """Amazon(root, 'photo') parses CSR triplets; binarised attributes, no self-loops, undirected, coalesced."""
+    import scipy.sparse as sp
+    from disenlink_amd.datasets import load_amazon_npz
+    rng = np.random.default_rng(3)
+    n = 12
+    a = sp.csr_matrix((rng.random((n, n)) < 0.2).astype(np.float32))
+    x = sp.csr_matrix(rng.integers(0, 3, (n, 7)).astype(np.float32))
+    p = tmp_path / "amazon_electronics_photo.npz"
+    np.savez(p, adj_data=a.data, adj_indices=a.indices, adj_indptr=a.indptr, adj_shape=np.array(a.shape),
+             attr_data=x.data, attr_indices=x.indices, attr_indptr=x.indptr, attr_shape=np.array(x.shape),
+             labels=np.zeros(n, np.int64))
+    ds = load_amazon_npz(str(p), standardise=False)
+    d = a.toarray()
+    np.fill_diagonal(d, 0)
+    want = np.stack(np.nonzero((d + d.T) != 0))
+    assert np.array_equal(np.stack([ds.src, ds.dst]), want)
+    assert np.array_equal(ds.x, (x.toarray() > 0).astype(np.float32))
+
+
+def test_deezer_mat_format(tmp_path):
+    """other_hetero_datasets.py:160-164: A.nonzero() rows in the matrix's own order, features densified."""
+    import scipy.io
+    import scipy.sparse as sp
+    from disenlink_amd.datasets import load_deezer
+    rng = np.random.default_rng(4)
+    n = 9
+    a = sp.csr_matrix((rng.random((n, n)) < 0.3).astype(np.float64))
+    feats = sp.csr_matrix(rng.integers(0, 2, (n, 5)).astype(np.float64))
+    p = tmp_path / "deezer-europe.mat"
+    scipy.io.savemat(p, {"A": a, "label": rng.integers(0, 2, (1, n)), "features": feats})
+    ds = load_deezer(str(p), standardise=False)
+    row, col = scipy.io.loadmat(p)["A"].nonzero()
+    assert np.array_equal(ds.src, row) and np.array_equal(ds.dst, col) and ds.src.size == a.nnz
+    assert np.array_equal(ds.x, feats.toarray().astype(np.float32))
+
+
+def test_cli_reads_webkb(tmp_path):
+    """--dataset texas goes through load_dataset (main_disentangled.py:69-71)."""
+    import argparse
+    from disenlink_amd.main import load_dataset
+    _need(f"{REF}/data/texas/raw")
+    args = argparse.Namespace(data_file=None, data_root=f"{REF}/data", synthetic=False, dataset="texas", sub_dataset="")
+    ds = load_dataset(args)
+    assert ds.n_nodes == 183 and ds.src.size == 325
+    np.testing.assert_allclose(ds.x.mean(axis=1), 0, atol=1e-5)

@@ -733,7 +733,7 @@ def test_dropin_module_follows_the_reference_training_trajectory(name):
     assert abs(test_auc - float(g["test_auc"])) <= 5e-3
 
 
-@pytest.mark.parametrize("name", ["chameleon", "cora", "squirrel"])
+@pytest.mark.parametrize("name", ["chameleon", "cora", "squirrel", "texas"])
 def test_real_data_auc_parity_with_the_reference_model(name):
     """BASELINE.json: "chameleon, K=8, d=64, fp32" and "Cora, K=4, d=32" ... "AUC parity vs the CPU reference within
     1e-4 on the same edge splits".  tests/golden/real_<name>.npz holds the real dataset arrays and what the reference
@@ -741,7 +741,8 @@ def test_real_data_auc_parity_with_the_reference_model(name):
     seeded initial weights through (a) the drop-in module inside the reference's dense-mask loop and (b) the scalable
     pair-list loop — per-epoch loss, validation AUC and the final test AUC.  (All three run the projection kernels:
     Cora's 1,433 features exercise the padded feature tails of the plane arrays; squirrel = the real 217k-row edge
-    list with seeded features, the configuration the benchmark is quoted on.)"""
+    list with seeded features, the configuration the benchmark is quoted on; texas = WebKB at hyperparameters_setting:5,
+    183 nodes and 1,703 features: a graph far smaller than one launch's grid, K = 5.)"""
     import json
     import os
     import torch.nn.functional as F
@@ -759,10 +760,10 @@ def test_real_data_auc_parity_with_the_reference_model(name):
     elif "feat_seed" in g:                                          # squirrel: real edge list, seeded N(0,1) features (blob missing)
         feats = np.random.default_rng(int(g["feat_seed"])).standard_normal(tuple(g["feat_shape"]), dtype=np.float32)
         x = torch.from_numpy(standardise_rows(feats)).to(DEV)
-    else:                                                           # Cora: binary features as they are (:117-123)
-        feats = np.zeros(tuple(g["feat_shape"]), dtype=np.float32)
+    else:                                                           # Cora: binary features as they are (:117-123);
+        feats = np.zeros(tuple(g["feat_shape"]), dtype=np.float32)  # texas (WebKB): binary, then standardised (:91-96)
         feats[g["feat_row"].astype(np.int64), g["feat_col"].astype(np.int64)] = 1.0
-        x = torch.from_numpy(feats).to(DEV)
+        x = torch.from_numpy(standardise_rows(feats) if "standardise" in g else feats).to(DEV)
     n = feats.shape[0]
     split = make_link_split(edges[:, 0], edges[:, 1], n, m=m["m"], seed=m["split_seed"])
     assert (split.pos_train.u.size, split.neg_train.u.size, split.val.u.size, split.test.u.size) == \
