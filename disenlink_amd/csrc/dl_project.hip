@@ -291,6 +291,7 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
         }
     }
     DL_STAMP(2);
+    if constexpr (DMA) wait_vmem();
     __syncthreads();
     DL_STAMP(3);
     for (int s = 0; s < steps; ++s) {
@@ -528,6 +529,10 @@ __global__ __launch_bounds__(NTHR) void project2_fwd_kernel(const float* __restr
             for (int ht = 0; ht < 2; ++ht) zero_acc(hacc[ht]);
         }
         DL_STAMP(16);
+        // LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier the reader has passed;
+        // the workgroup fence of __syncthreads() waits for LDS operations only.  (hipcc already emitted this wait here, for
+        // the pending bias load: written out so that the tile of step s + 1 does not depend on that.)
+        if constexpr (DMA) wait_vmem();
         __syncthreads();
         DL_STAMP(17);
     }

@@ -8,7 +8,8 @@ reference's 2000 / 200 would be hours of dense CPU epochs per seed).
 
 Run (this container only; needs /root/reference):  python tests/golden/make_convergence.py [seed ...]
 
-The dataset arrays are those of tests/golden/real_chameleon.npz (make_real_data.py).  Writes
+The dataset arrays are those of tests/golden/real_chameleon.npz (make_real_data.py); DL_CONV_TAG=fast: the same at lr 1e-3;
+DL_CONV_TAG=cora: Cora (real_cora.npz) at hyperparameters_setting:11 -> conv_cora.npz.  Writes
 tests/golden/conv_chameleon.npz: per seed the per-epoch loss and validation AUC, the epoch the loop stopped at, the
 epoch of the best validation AUC, the test AUC — outputs of the reference's model.py on CPU, nothing else.
 """
@@ -32,9 +33,16 @@ SEEDS = (21, 22, 23)
 # At that recipe the validation AUC of the reference still improves at (nearly) every one of 400 epochs — the early stop
 # never fires (it would take the reference's 2000 epochs).  A second set, tag "fast": the same recipe at the learning rate
 # of hyperparameters_setting:10-13 (1e-3), where the validation AUC peaks and decays inside the cap: the patience FIRES.
+# A third set, tag "cora": the Planetoid graph of BASELINE.json's configs[0] at the recipe of hyperparameters_setting:11
+# (beta 0.6, K 10, nhid 256, d 64, lr 1e-3, m 5; binary features, NOT standardised — main_disentangled.py:117-123).
 TAG = os.environ.get("DL_CONV_TAG", "")
+DATASET = "chameleon"
 if TAG == "fast":
     RECIPE = dict(RECIPE, lr=1e-3)
+    EPOCHS, PATIENCE = 400, 20
+elif TAG == "cora":
+    DATASET = "cora"
+    RECIPE = dict(K=10, d=64, nhid=256, beta=0.6, t=1, m=5, lr=1e-3, weight_decay=5e-4)
     EPOCHS, PATIENCE = 400, 20
 
 
@@ -58,7 +66,7 @@ def one_run(seed, ref_model, feats, edges, log):
     from disenlink_amd.splits import make_link_split
     r = RECIPE
     n = feats.shape[0]
-    x = standardise_rows(feats)
+    x = standardise_rows(feats) if DATASET == "chameleon" else feats     # main_disentangled.py:97-101 / :117-123
     split = make_link_split(edges[:, 0], edges[:, 1], n, m=r["m"], seed=seed, keep_raw=True)
     ori = dense(edges[:, 0], edges[:, 1], n)
     adj = dense(split.train_src, split.train_dst, n)
@@ -103,8 +111,13 @@ def one_run(seed, ref_model, feats, edges, log):
 def main():
     sys.path.insert(0, REF)
     import model as ref_model                                    # the reference's model.py
-    raw = np.load(os.path.join(REF, "data_pre_false/chameleon/raw/chameleon.npz"), allow_pickle=True)
-    feats, edges = np.asarray(raw["features"], np.float32), np.asarray(raw["edges"], np.int64)
+    if DATASET == "cora":
+        from disenlink_amd.datasets import load_planetoid
+        ds = load_planetoid(os.path.join(REF, "data/cora/raw"), "cora")
+        feats, edges = ds.x, np.stack([ds.src, ds.dst], axis=1)
+    else:
+        raw = np.load(os.path.join(REF, "data_pre_false/chameleon/raw/chameleon.npz"), allow_pickle=True)
+        feats, edges = np.asarray(raw["features"], np.float32), np.asarray(raw["edges"], np.int64)
     seeds = [int(s) for s in sys.argv[1:]] or list(SEEDS)
     out = {}
     log = lambda s: print(s, flush=True)
@@ -123,11 +136,12 @@ def main():
             with np.load(os.path.join(HERE, f"{prefix}{s}.npz")) as g:
                 for k in g.files:
                     out[f"s{s}_{k}"] = g[k]
-        meta = dict(RECIPE, epochs=EPOCHS, patience=PATIENCE, seeds=list(SEEDS), dataset="chameleon",
-                    recipe="hyperparameters_setting:2" + (" at lr 1e-3 (the learning rate of :10-13)" if TAG == "fast" else ""))
+        meta = dict(RECIPE, epochs=EPOCHS, patience=PATIENCE, seeds=list(SEEDS), dataset=DATASET,
+                    recipe="hyperparameters_setting:11" if TAG == "cora" else
+                    "hyperparameters_setting:2" + (" at lr 1e-3 (the learning rate of :10-13)" if TAG == "fast" else ""))
         tests = np.array([float(out[f"s{s}_test_auc"]) for s in SEEDS])
         meta["test_auc_mean"], meta["test_auc_std"] = float(tests.mean()), float(tests.std())   # np.std, as :222-223
-        path = os.path.join(HERE, f"conv_chameleon{'_' + TAG if TAG else ''}.npz")
+        path = os.path.join(HERE, "conv_cora.npz" if TAG == "cora" else f"conv_chameleon{'_' + TAG if TAG else ''}.npz")
         np.savez_compressed(path, meta=np.array(json.dumps(meta)), **out)
         for p in parts:
             os.remove(os.path.join(HERE, p))
