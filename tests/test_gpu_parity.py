@@ -2412,7 +2412,7 @@ def _early_stop_trace(aucs, patience):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["eager-device", "eager-host", "replayed-device"])
-@pytest.mark.parametrize("tag", ["", "_fast"])
+@pytest.mark.parametrize("tag", ["chameleon", "chameleon_fast", "cora"])
 def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkeypatch):
     """Round 6: the reference's whole per-run protocol (main_disentangled.py:131-224 — fresh split and
     model per run, validation AUC every epoch from the pre-step forward, best weights after the step, patience, test AUC with
@@ -2420,7 +2420,9 @@ def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkey
     reference's model.py did on CPU (make_convergence.py) for 3 seeds on the real chameleon graph at the recipe of
     hyperparameters_setting:2 (K = 5, d = 32, nhid 512, beta 0.7): 400 epochs at its learning rate 1e-4, where the validation
     AUC still improves at nearly every epoch and the patience of 20 never fires, and ("_fast") at learning rate 1e-3, where it
-    peaks and decays and the early stop FIRES.  Here: the pair-list loop on the MI355X with the bookkeeping on the device
+    peaks and decays and the early stop FIRES; conv_cora.npz: Cora (BASELINE.json configs[0]; binary features, not
+    standardised) at ITS recipe, hyperparameters_setting:11 (K = 10, d = 64, nhid 256, beta 0.6, lr 1e-3), where the early stop
+    fires after 100-200 epochs.  Here: the pair-list loop on the MI355X with the bookkeeping on the device
     (dl_epoch_finish, history read one epoch behind), on the host (the reference's form), and replayed from a HIP graph.
       * the loop's own decisions are exactly the reference's rule applied to ITS validation AUCs (stop epoch, best epoch);
       * every epoch's validation AUC is within 1e-3 of the reference's (fp32 trajectories separate at
@@ -2436,14 +2438,20 @@ def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkey
     from disenlink_amd.model import Disentangle
     from disenlink_amd.splits import make_link_split
     from disenlink_amd.train import prepare_run, run_link_prediction
-    path = os.path.join(GOLDEN_DIR, f"conv_chameleon{tag}.npz")
+    path = os.path.join(GOLDEN_DIR, f"conv_{tag}.npz")
     if not os.path.exists(path):
         pytest.skip(f"{path} not generated")
     g = np.load(path)
     m = json.loads(str(g["meta"]))
-    data = np.load(os.path.join(GOLDEN_DIR, "real_chameleon.npz"))
-    feats, edges = data["features"], data["edges"].astype(np.int64)
-    x = torch.from_numpy(standardise_rows(feats)).to(DEV)
+    data = np.load(os.path.join(GOLDEN_DIR, f"real_{m['dataset']}.npz"))
+    edges = data["edges"].astype(np.int64)
+    if m["dataset"] == "cora":                                       # binary features as they are (main_disentangled.py:117-123)
+        feats = np.zeros(tuple(data["feat_shape"]), dtype=np.float32)
+        feats[data["feat_row"].astype(np.int64), data["feat_col"].astype(np.int64)] = 1.0
+        x = torch.from_numpy(feats).to(DEV)
+    else:
+        feats = data["features"]
+        x = torch.from_numpy(standardise_rows(feats)).to(DEV)
     n = feats.shape[0]
     monkeypatch.setenv("DL_DEVICE_EARLY_STOP", "0" if mode == "eager-host" else "1")
     tests_ref, tests_got = [], []
@@ -2471,7 +2479,7 @@ def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkey
         if (run_o, best_o) != (run_r, best_r):
             first = next(e for e in range(k) if flags_o[e] != flags_r[e])
             margin = abs(ref_auc[first] - ref_auc[:first].max())
-            print(f"conv{tag} seed {seed} {mode}: stop/best ({run_o}, {best_o}) vs reference ({run_r}, {best_r}); decisions first differ at "
+            print(f"conv_{tag} seed {seed} {mode}: stop/best ({run_o}, {best_o}) vs reference ({run_r}, {best_r}); decisions first differ at "
                   f"epoch {first}, where the reference's AUC is {margin:.2e} from its running best and ours differs by "
                   f"{abs(aucs[first] - ref_auc[first]):.2e}")
             assert margin <= 2e-3, (seed, first, margin)
@@ -2480,7 +2488,7 @@ def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkey
         tests_ref.append(float(g[f"s{seed}_test_auc"]))
         tests_got.append(res.test_auc)
     assert abs(np.mean(tests_got) - m["test_auc_mean"]) <= 1e-3
-    print(f"conv{tag} {mode}: test AUC {np.mean(tests_got):.6f} +- {np.std(tests_got):.6f} (reference {m['test_auc_mean']:.6f} +- {m['test_auc_std']:.6f})")
+    print(f"conv_{tag} {mode}: test AUC {np.mean(tests_got):.6f} +- {np.std(tests_got):.6f} (reference {m['test_auc_mean']:.6f} +- {m['test_auc_std']:.6f})")
 
 
 
