@@ -8,10 +8,19 @@
 # Workloads: the default headline (squirrel_real), the hbm_bound block (snap_patents x0.25), and the other BASELINE.json
 # configurations on one GPU: chameleon K=8 d=64 fp32 (configs[1]) and Penn94-shaped K=16 d=128 bf16 (configs[4]).
 # Copy the files into profiles/ afterwards (tools/stats_md.py turns a csv into the markdown table).
+# A gpurun call is capped at 20 minutes: PARTS="1 2 3 4" (default: all) selects what runs; the PMC summaries of earlier parts
+# are picked up from profiles/_partial/ (copy gpurun_out/<tag>_pmc_*.json there between calls — gpurun_out/ does not travel).
 set -u
 tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$root"
+PARTS=${PARTS:-"1 2 3 4"}
+mkdir -p gpurun_out
+for f in pmc_traffic pmc_l2; do
+  [ -f profiles/_partial/${tag}_$f.json ] && [ ! -f gpurun_out/${tag}_$f.json ] && cp profiles/_partial/${tag}_$f.json gpurun_out/${tag}_$f.json
+done
+part() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+if part 1; then
 bash tools/prof_stats.sh ${tag}_headline bench.py --sections headline --steps 20 --warmup 5 --no-cpu-baseline || exit 1
 bash tools/prof_stats.sh ${tag}_hbm_bound bench.py --sections hbm_bound --no-cpu-baseline || exit 1
 bash tools/prof_stats.sh ${tag}_chameleon bench.py --workload chameleon --sections headline --steps 20 --warmup 5 --no-cpu-baseline || exit 1
@@ -21,6 +30,8 @@ bash tools/prof_stats.sh ${tag}_penn94_training bench.py --workload penn94 --K 1
 # the path the one-line swap gives: the reference's dense-mask loop around the drop-in module (tools/dropin_epoch.py)
 bash tools/prof_stats.sh ${tag}_dropin_static tools/dropin_epoch.py squirrel_real 30 static || exit 1
 bash tools/prof_stats.sh ${tag}_dropin_default tools/dropin_epoch.py squirrel_real 30 default || exit 1
+fi
+if part 2; then
 bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32 --sections headline --steps 5 --warmup 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag squirrel_realx1_K8_d64_f32_train --sections fwd_bwd --steps 5 --warmup 2 || exit 1
 # L2-side request counters (what `moved_bytes` is checked against): headline, training step, hbm_bound
@@ -28,12 +39,16 @@ bash tools/pmc_l2_run.sh $tag squirrel_realx1_K8_d64_f32 --sections headline --s
 bash tools/pmc_l2_run.sh $tag squirrel_realx1_K8_d64_f32_train --sections fwd_bwd --steps 5 --warmup 2 || exit 1
 bash tools/pmc_l2_run.sh $tag snap_patentsx0.25_K8_d64_f32 --sections hbm_bound --hbm-steps 2 --repeats 2 || exit 1
 bash tools/pmc_l2_run.sh $tag chameleonx1_K8_d64_f32 --workload chameleon --sections headline --steps 5 --warmup 2 || exit 1
+fi
+if part 3; then
 bash tools/pmc_l2_run.sh $tag penn94x1_K16_d128_bf16 --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 3 --warmup 1 --repeats 2 || exit 1
 bash tools/pmc_l2_run.sh $tag penn94x1_K16_d128_bf16_train --workload penn94 --K 16 --d 128 --dtype bf16 --sections fwd_bwd --steps 3 --warmup 1 || exit 1
 bash tools/pmc_traffic_run.sh $tag penn94x1_K16_d128_bf16_train --workload penn94 --K 16 --d 128 --dtype bf16 --sections fwd_bwd --steps 3 --warmup 1 || exit 1
 bash tools/pmc_traffic_run.sh $tag snap_patentsx0.25_K8_d64_f32 --sections hbm_bound --hbm-steps 2 --repeats 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag chameleonx1_K8_d64_f32 --workload chameleon --sections headline --steps 5 --warmup 2 || exit 1
 bash tools/pmc_traffic_run.sh $tag penn94x1_K16_d128_bf16 --workload penn94 --K 16 --d 128 --dtype bf16 --sections headline --steps 3 --warmup 1 --repeats 2 || exit 1
+fi
+if part 4; then
 # the bench lines last, with the fresh PMC summary in place so that their `traffic` fields are this build's
 cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic_latest.json
 cp gpurun_out/${tag}_pmc_l2.json profiles/pmc_l2_latest.json
@@ -44,4 +59,5 @@ python3 bench.py --workload penn94 --K 16 --d 128 --dtype bf16 --sections headli
 python3 bench.py --workload snap_patents --sections headline,cpu --steps 5 --warmup 2 --repeats 3 > gpurun_out/${tag}_snap_patents_bench_line.json 2>> gpurun_out/${tag}_bench.err || exit 1
 cp profiles/pmc_traffic_latest.json gpurun_out/${tag}_pmc_traffic_latest.json
 cp profiles/pmc_l2_latest.json gpurun_out/${tag}_pmc_l2_latest.json
-echo "profile_round $tag done"
+fi
+echo "profile_round $tag parts $PARTS done"
