@@ -177,6 +177,42 @@ def load_deezer(mat_path: str, standardise: bool = True) -> LinkDataset:
                        col.astype(np.int64))
 
 
+def read_pyg_data(path: str) -> dict:
+    """The tensors of a pickled ``torch_geometric.data.Data`` (``torch.save(data, path)``; a dataset's
+    ``processed/data.pt`` holds a tuple whose first item is one) without torch_geometric: its classes are unpickled as
+    attribute bags — the file is data, nothing of the library is needed or run."""
+    import types
+    import torch
+
+    class Bag:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            self.__dict__["state"] = state
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, mod, name):
+            return type(name, (Bag,), {}) if mod.startswith("torch_geometric") else super().find_class(mod, name)
+
+    pm = types.ModuleType("pickle")
+    pm.Unpickler, pm.load = Unpickler, (lambda f, **k: Unpickler(f, **k).load())
+    obj = torch.load(path, pickle_module=pm, weights_only=False, map_location="cpu")
+    data = obj[0] if isinstance(obj, (tuple, list)) else obj
+    store = data.state
+    store = store["_store"].state if "_store" in store else store
+    return dict(store.get("_mapping", store))
+
+
+def load_arxiv_year_mini(path: str, name: str | None = None, standardise: bool = True) -> LinkDataset:
+    """``mini/year<id>.pt`` (main_disentangled.py:124-129): a pickled PyG ``Data`` with ``x`` and ``edge_index``; rows
+    standardised, edge rows as stored."""
+    m = read_pyg_data(path)
+    x = m["x"].numpy().astype(np.float32)
+    e = m["edge_index"].numpy().astype(np.int64)
+    return LinkDataset(name or os.path.basename(path), standardise_rows(x) if standardise else x, e[0].copy(), e[1].copy())
+
+
 def save_binary(ds: LinkDataset, path: str) -> None:
     np.savez_compressed(path, x=ds.x, src=ds.src.astype(np.int64), dst=ds.dst.astype(np.int64), name=np.array(ds.name))
 

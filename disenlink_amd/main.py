@@ -86,8 +86,11 @@ def load_dataset(args):
             return datasets.load_amazon_npz(os.path.join(root, "Photo", "raw", "amazon_electronics_photo.npz"))
         if name == "deezer-europe":                                 # :58-59, 109-113
             return datasets.load_deezer(os.path.join(root, "deezer-europe.mat"))
-        raise SystemExit(f"no loader for --dataset {name} (ogbn-proteins / arxiv-year / yelp-chi need the ogb download "
-                         f"layout: convert with datasets.save_binary and pass --data-file)")
+        if name == "year":                                          # :124-129 (the arxiv-year minis, --miniid 0..9)
+            return datasets.load_arxiv_year_mini(os.path.join(os.path.dirname(root.rstrip("/")), "mini", f"year{args.miniid}.pt"),
+                                                 f"year{args.miniid}")
+        raise SystemExit(f"no loader for --dataset {name} (ogbn-proteins / the full arxiv-year / yelp-chi need the ogb "
+                         f"download layout: convert with datasets.save_binary and pass --data-file)")
     key = {"fb100": "penn94", "snap-patents": "snap_patents"}.get(args.dataset, args.dataset)
     if key not in SPECS:
         raise SystemExit(f"no data for --dataset {args.dataset}: give --data-root / --data-file")

@@ -148,28 +148,9 @@ def test_twitch_de_equals_the_references_arrays():
 
 
 def _processed_tensors(path):
-    """The tensors of a torch_geometric ``processed/data.pt`` without torch_geometric: its classes unpickle as
-    attribute bags (the file is data; nothing of the reference is executed)."""
-    import pickle
-    import types
-    import torch
-
-    class Bag:
-        def __init__(self, *a, **k):
-            pass
-
-        def __setstate__(self, state):
-            self.__dict__["state"] = state
-
-    class Unpickler(pickle.Unpickler):
-        def find_class(self, mod, name):
-            return type(name, (Bag,), {}) if mod.startswith("torch_geometric") else super().find_class(mod, name)
-
-    pm = types.ModuleType("pickle")
-    pm.Unpickler, pm.load = Unpickler, (lambda f, **k: Unpickler(f, **k).load())
-    data = torch.load(path, pickle_module=pm, weights_only=False)[0]
-    store = data.state["_store"].state
-    return store.get("_mapping", store)
+    """The tensors of a torch_geometric ``processed/data.pt`` (datasets.read_pyg_data: no torch_geometric needed)."""
+    from disenlink_amd.datasets import read_pyg_data
+    return read_pyg_data(path)
 
 
 @pytest.mark.parametrize("name,n,rows,loops", [("texas", 183, 325, 16), ("cornell", 183, 298, 3), ("wisconsin", 251, 515, 16)])
@@ -234,3 +215,21 @@ def test_cli_reads_webkb(tmp_path):
     ds = load_dataset(args)
     assert ds.n_nodes == 183 and ds.src.size == 325
     np.testing.assert_allclose(ds.x.mean(axis=1), 0, atol=1e-5)
+
+
+def test_arxiv_year_mini_and_cli():
+    """main_disentangled.py:124-129: --dataset year --miniid i reads mini/year<i>.pt (a pickled PyG Data)."""
+    import argparse
+    from disenlink_amd.datasets import load_arxiv_year_mini, read_pyg_data
+    from disenlink_amd.main import load_dataset
+    path = _need(f"{REF}/mini/year0.pt")
+    m = read_pyg_data(path)
+    ds = load_arxiv_year_mini(path, standardise=False)
+    assert ds.x.shape == (5443, 128) and ds.src.size == 15497 and int(max(ds.src.max(), ds.dst.max())) == 5442
+    assert np.array_equal(ds.x, m["x"].numpy()) and np.array_equal(np.stack([ds.src, ds.dst]), m["edge_index"].numpy())
+    args = argparse.Namespace(data_file=None, data_root=f"{REF}/data", synthetic=False, dataset="year", sub_dataset="", miniid=0)
+    got = load_dataset(args)
+    t = m["x"]
+    want = (t - t.mean(dim=1, keepdim=True)) / t.std(dim=1).unsqueeze(1)                  # :127
+    np.testing.assert_allclose(got.x, want.numpy(), rtol=1e-6, atol=1e-6)
+    assert got.src.size == 15497
