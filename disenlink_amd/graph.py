@@ -431,7 +431,8 @@ class Graph:
         lc, lr = c[e0:e1], r[e0:e1] - lo
         # XCD slicing of the routing plan was measured and rejected: hub rows already give the Z gathers a high
         # L2 hit rate, and the extra segments cost more than they save (squirrel 50 -> 72 us; 41.6k-node shard
-        # 115 -> 107 us).  `row_bytes` is kept for callers that pass the model shape.
+        # 115 -> 107 us; re-measured in round 6 on the mirrored 22 us kernel: 31.5 / 31.1 / 32.5 / 35.0 us by events at
+        # 1 / 2 / 4 / 8 slices).  `row_bytes` is kept for callers that pass the model shape.
         route = CsrPlan.build(full_ptr[lo:hi + 1] - e0, lc, n_nodes, row_offset=lo,
                               seg_len=min(seg_len, route_seg_len((e1 - e0 + 1) // 2 if mirror else e1 - e0)), n_slices=1,
                               keep=(lc >= lr + lo) if mirror else None, unit_segs=1, by_length=by_len)
