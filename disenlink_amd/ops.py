@@ -996,6 +996,14 @@ class LinkPred(torch.Tensor):
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 
+    # Copies and serialised forms are DATA: plain tensors, without the owning module's cache (torch's default __deepcopy__
+    # refuses a subclass without new_empty(); pickling the subclass would drag the cache along and break weights_only loads).
+    def __deepcopy__(self, memo):
+        return self.as_subclass(torch.Tensor).__deepcopy__(memo)
+
+    def __reduce_ex__(self, proto):
+        return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
+
 
 def as_link_pred(prob: torch.Tensor, cache: "DensePairPlanCache") -> torch.Tensor:
     if os.environ.get("DL_LINK_PRED_SUBCLASS", "1") == "0":        # plain tensor: the plan is learnt from the gradients alone

@@ -608,3 +608,42 @@ def test_compiled_torch_binding_builds_loads_and_registers_its_operator():
     assert int(torch.ops.disenlink_native.binding_abi()) == native.BINDING_ABI
     with pytest.raises(RuntimeError, match="CUDA fp32"):
         op(torch.zeros(3, 2, 8), 0, 0, 0, 0.5, 1.0, torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1), 0)
+
+
+def test_link_pred_behaves_like_a_tensor_for_copies_and_files():
+    """ops.LinkPred (the dense link_pred of the drop-in forward) only adds a hook to indexing: every result is a plain
+    tensor, deepcopy / pickle / torch.save of it are plain tensors too (no module cache inside, weights_only loads work),
+    and autograd runs through a mask gather exactly as through a plain tensor."""
+    import copy
+    import io
+    import pickle
+    from disenlink_amd import ops
+
+    class Cache:
+        notes = 0
+
+        def note_index(self, n, idx):
+            Cache.notes += 1
+
+    base = torch.rand(6, 6, requires_grad=True)
+    t = ops.as_link_pred(base * 1.0, Cache())
+    assert isinstance(t, ops.LinkPred) and t.requires_grad
+    m = torch.rand(6, 6, generator=torch.Generator().manual_seed(1)) > 0.5
+    for r in (t[m], t[2, 3], t[1:3], t + 1, torch.sigmoid(t), t.detach(), t.clone(), t.view(-1), t.t(), torch.masked_select(t, m),
+              t[torch.tensor([0, 1]), torch.tensor([2, 3])]):
+        assert type(r) is torch.Tensor
+    assert Cache.notes >= 4                                          # every a_pred[...] was reported
+    d = ops.as_link_pred(torch.rand(3, 3), Cache())
+    c = copy.deepcopy(d)
+    assert type(c) is torch.Tensor and torch.equal(c, d) and c.data_ptr() != d.data_ptr()
+    assert type(pickle.loads(pickle.dumps(d))) is torch.Tensor
+    buf = io.BytesIO()
+    torch.save(d, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=True)
+    assert type(back) is torch.Tensor and torch.equal(back, d)
+    torch.nn.functional.binary_cross_entropy(t[m], torch.ones(int(m.sum()))).backward()
+    ref = torch.rand(0)                                              # the same through a plain tensor
+    b2 = base.detach().clone().requires_grad_(True)
+    torch.nn.functional.binary_cross_entropy((b2 * 1.0)[m], torch.ones(int(m.sum()))).backward()
+    assert torch.equal(base.grad, b2.grad)
