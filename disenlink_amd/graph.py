@@ -444,7 +444,19 @@ class Graph:
         """Dense ``adj_sym`` as the reference passes it to ``model(x, adj_sym)`` (main_disentangled.py:194)."""
         if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
             raise ValueError("adj must be square")
+        # The reference multiplies by adj (model.py:62: p * adj, compared with the factor numbers): its layer is only
+        # meaningful for entries that are 0 or 1.  Anything else would be an edge here and garbage there: refuse it.
+        if adj.layout != torch.strided:                            # sparse COO / CSR: the stored entries (an extension)
+            coo = adj.to_sparse_coo().coalesce()
+            val, idx = coo.values(), coo.indices()
+            if bool(((val != 0) & (val != 1)).any()):
+                raise ValueError("adj must hold 0 / 1 entries (the reference's layer multiplies by it, model.py:62)")
+            keep = val != 0
+            return Graph.from_edge_rows(idx[0][keep], idx[1][keep], adj.shape[0], symmetrise=False, seg_len=seg_len,
+                                        row_bytes=row_bytes)
         nz = torch.nonzero(adj)
+        if nz.shape[0] and bool((adj[nz[:, 0], nz[:, 1]] != 1).any()):
+            raise ValueError("adj must hold 0 / 1 entries (the reference's layer multiplies by it, model.py:62)")
         return Graph.from_edge_rows(nz[:, 0], nz[:, 1], adj.shape[0], symmetrise=False, seg_len=seg_len,
                                     row_bytes=row_bytes)
 

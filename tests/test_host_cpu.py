@@ -647,3 +647,27 @@ def test_link_pred_behaves_like_a_tensor_for_copies_and_files():
     b2 = base.detach().clone().requires_grad_(True)
     torch.nn.functional.binary_cross_entropy((b2 * 1.0)[m], torch.ones(int(m.sum()))).backward()
     assert torch.equal(base.grad, b2.grad)
+
+
+def test_graph_from_dense_takes_sparse_layouts_and_refuses_weights():
+    """Graph.from_dense: adj is the 0 / 1 matrix the reference's layer multiplies by (model.py:62) — dense of any dtype,
+    sparse COO or CSR give the same plan; an entry that is neither 0 nor 1 raises instead of becoming an edge."""
+    from disenlink_amd.graph import Graph
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand(40, 40, generator=g) < 0.1).float()
+    a = ((a + a.t()) != 0).float()
+    ref = Graph.from_dense(a)
+    for other in (a.bool(), a.long(), a.double(), a.to_sparse(), a.to_sparse_csr()):
+        got = Graph.from_dense(other)
+        assert torch.equal(got.rowptr, ref.rowptr) and torch.equal(got.col, ref.col)
+    sp = a.to_sparse()
+    explicit_zero = torch.sparse_coo_tensor(torch.cat([sp.indices(), torch.tensor([[0], [0]])], 1),
+                                            torch.cat([sp.values(), torch.zeros(1)]), a.shape)
+    if a[0, 0] == 0:
+        assert torch.equal(Graph.from_dense(explicit_zero).col, ref.col)          # a stored 0 is no edge
+    w = a.clone()
+    r, c = torch.nonzero(a)[0].tolist()
+    w[r, c] = w[c, r] = 0.5
+    for bad in (w, w.to_sparse()):
+        with pytest.raises(ValueError, match="0 / 1"):
+            Graph.from_dense(bad)
