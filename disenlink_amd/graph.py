@@ -506,14 +506,20 @@ class PairList:
         coalesced stream instead of two random reads per entry; the weight's sign picks the one entry of a pair that
         writes prob) — for the label and weight tensors the loop passes EVERY epoch (main_disentangled.py:195: the masks
         are fixed for a run).  Keyed on the tensors' identity and version counter; built the second time the same pair
-        of tensors is seen, so a caller that draws new labels for every step never pays for it.  Writes that bypass the
+        of tensor OBJECTS is seen, so a caller that draws new labels for every step never pays for it — and never gets the
+        stream of an earlier tensor that lived at the same address.  Writes that bypass the
         version counter (``.data``, raw kernels) are not seen: call ``unbind_labels()`` after such a write."""
         if os.environ.get("DL_ENTRY_LABELS", "1") == "0" or label.is_inference() or weight.is_inference():   # (A/B runs; no version counter)
             self.unbind_labels()
             return
-        key = (label.data_ptr(), label._version, weight.data_ptr(), weight._version, int(label.numel()), label.device)
-        if self._yw_key != key:
-            if self._yw_seen != key:                                # first sight: keep the gathers, remember the pair
+        # identity = the tensor OBJECTS (weak references) and their version counters: an address can be handed to a new
+        # tensor with other contents — a caller that makes its labels afresh every step gets the same data_ptr and version 0
+        # again and again — an object cannot
+        def same(key):
+            return key is not None and key[0]() is label and key[1]() is weight and key[2:] == (label._version, weight._version)
+        if not same(self._yw_key):
+            key = (weakref.ref(label), weakref.ref(weight), label._version, weight._version)
+            if not same(self._yw_seen):                             # first sight: keep the gathers, remember the pair
                 self._yw_seen = key
                 self.unbind_labels()
                 return

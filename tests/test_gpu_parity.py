@@ -2355,6 +2355,24 @@ def test_per_entry_labels_give_the_same_bits_and_every_probability(K, d, dtype, 
             label.add_(0.0)                                                       # an in-place write bumps the version: the old binding must go
             got3 = ops.score_pairs_train(Zt, H, pl, t, label, weight)
             assert all(torch.equal(a[lo:hi], b[lo:hi]) for a, b in zip(ref[1:], got3[1:]))
+    # Labels made AFRESH for every step (a new tensor object each time, which the allocator places at the address of the one
+    # just freed, version 0 again): identity is the object, not the address — no step may see an earlier step's stream.
+    pl = PairList.build(tpu, tpv, N, build_by_u=False, row_bytes=K * d * wb)
+    pl_ref = PairList.build(tpu, tpv, N, build_by_u=False, row_bytes=K * d * wb)      # sees every label tensor once: always the gathers
+    monkeypatch.setenv("DL_ENTRY_LABELS", "1")
+    addresses, bound = set(), 0
+    for stepno in range(6):
+        content = label.clone()
+        content[stepno * 40:(stepno + 1) * 40] = 1.0 - content[stepno * 40:(stepno + 1) * 40]
+        want = ops.score_pairs_train(Zt, H, pl_ref, 1.0, content, weight)
+        assert pl_ref._yw is None
+        fresh = content.clone()
+        addresses.add(fresh.data_ptr())
+        got = ops.score_pairs_train(Zt, H, pl, 1.0, fresh, weight)
+        bound += pl._yw is not None
+        assert all(torch.equal(a, b) for a, b in zip(want[1:], got[1:])), stepno
+        del fresh, got, want, content
+    assert len(addresses) < 6 and bound == 0                          # addresses WERE reused, and no stream was ever bound to one
 
 
 @pytest.mark.gpu
