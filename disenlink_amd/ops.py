@@ -865,6 +865,7 @@ class DensePairPlanCache:
         self.from_masks = False  # the set is the caller's declared support (never extended behind their back)
         self.rebuilds = 0        # how often the plan was (re)built: a learnt plan is rebuilt whenever new entries carry gradient
         self._seen_index = set() # fingerprints of the index masks link_pred was indexed with (note_index)
+        self._seen_ij = []       # (rows, cols) index tensors seen: weak references + version counters
         self._pending = []       # flat positions learnt from indexing, not yet in the plan
         self._hash_vec = None
 
@@ -895,7 +896,7 @@ class DensePairPlanCache:
     def clear(self):
         self.pairs = self.flat = self.key = None
         self.from_masks = False
-        self._seen_index, self._pending = set(), []
+        self._seen_index, self._seen_ij, self._pending = set(), [], []
 
     # ---- learnt from the caller's indexing of link_pred (LinkPred.__torch_function__)
     def note_index(self, N: int, index) -> None:
@@ -923,11 +924,16 @@ class DensePairPlanCache:
                 self._pending.append(torch.nonzero(index.reshape(-1)).reshape(-1))
             elif isinstance(index, tuple) and len(index) == 2 and all(torch.is_tensor(v) and v.dtype == torch.int64 and v.dim() == 1
                                                                         for v in index) and index[0].is_cuda:
-                fp = ("ij", index[0].data_ptr(), index[0]._version, index[1].data_ptr(), index[1]._version, int(index[0].numel()))
-                if fp in self._seen_index:
-                    return
-                self._seen_index.add(fp)
-                self._pending.append((index[0] % N) * N + (index[1] % N))
+                # recognised by the tensor OBJECTS and their version counters (no device read: this form of indexing does not
+                # synchronise) — not by addresses: index tensors made afresh every epoch come back at the address of the ones
+                # just freed, with other contents
+                rows, cols = index
+                for r0, r1, v0, v1 in self._seen_ij:
+                    if r0() is rows and r1() is cols and (v0, v1) == (rows._version, cols._version):
+                        return
+                self._seen_ij.append((weakref.ref(rows), weakref.ref(cols), rows._version, cols._version))
+                del self._seen_ij[:-16]
+                self._pending.append((rows % N) * N + (cols % N))
         except RuntimeError:                                        # an index torch itself will reject: let torch say so
             return
 

@@ -2543,6 +2543,40 @@ def test_convergence_length_runs_follow_the_reference_protocol(tag, mode, monkey
 
 
 @pytest.mark.gpu
+def test_link_pred_indexed_with_fresh_index_tensors_every_step_is_learnt_by_object_not_by_address():
+    """``a_pred[rows, cols]`` with index tensors made AFRESH for every step (the allocator hands the new ones the address
+    of the ones just freed, version 0 again) and OTHER contents each time: ops.LinkPred recognises index tensors by object,
+    so every step's entries enter the pair plan of the dense backward — including saturated ones, which carry no gradient
+    and which the safety net (learning from the non-zero gradient) would therefore never add."""
+    import torch.nn.functional as F
+    from disenlink_amd.model import Disentangle
+    rng = np.random.default_rng(12)
+    N, Fd = 300, 24
+    src, dst = rng.integers(0, N, 2500), rng.integers(0, N, 2500)
+    adj = torch.zeros(N, N, device=DEV)
+    adj[torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV)] = 1
+    adj_sym = ((adj + adj.t()) != 0).float()
+    x = torch.from_numpy(rng.standard_normal((N, Fd)).astype(np.float32) * 1.5).to(DEV)       # large enough for saturated scores
+    torch.manual_seed(4)
+    model = Disentangle(Fd, 32, 32, nfactor=4, beta=0.6, t=1).to(DEV)
+    addresses, taken = set(), []
+    for stepno in range(5):
+        rows = torch.from_numpy(rng.integers(0, N, 6000)).to(DEV)
+        cols = torch.from_numpy(rng.integers(0, N, 6000)).to(DEV)
+        addresses.add((rows.data_ptr(), cols.data_ptr()))
+        _h, a_pred = model(x, adj_sym)
+        vals = a_pred[rows, cols]
+        assert int((vals == 1).sum()) > 0                             # saturated entries are really among them
+        F.binary_cross_entropy(vals, adj_sym[rows, cols]).backward()
+        model.zero_grad()
+        taken.append(rows * N + cols)
+        plan = model._dense_plan.flat
+        assert bool(torch.isin(torch.cat(taken), plan).all()), stepno
+        del rows, cols, vals, a_pred, _h
+    assert len(addresses) < 5                                         # addresses WERE reused
+
+
+@pytest.mark.gpu
 def test_the_unchanged_reference_loop_teaches_the_dense_backward_its_masks_in_one_epoch():
     """Round 6: the drop-in module inside the reference's loop as it is written
     (main_disentangled.py:192-214: dense masks, ``a_pred[pos_train_adj == 1]``, F.binary_cross_entropy, Adam, the validation
