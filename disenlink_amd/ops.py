@@ -934,6 +934,8 @@ class DensePairPlanCache:
                 self._seen_ij.append((weakref.ref(rows), weakref.ref(cols), rows._version, cols._version))
                 del self._seen_ij[:-16]
                 self._pending.append((rows % N) * N + (cols % N))
+            if len(self._pending) > 32:                             # many gathers between two backwards: keep one merged set
+                self._pending = [torch.unique(torch.cat(self._pending))]
         except RuntimeError:                                        # an index torch itself will reject: let torch say so
             return
 
@@ -1009,7 +1011,9 @@ class LinkPred(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], LinkPred):
             cache = args[0]._dl_cache
-            if cache is not None and args[0].dim() == 2:
+            # (only where a backward can follow: an evaluation loop under no_grad indexes without end and never consumes
+            # what it reported)
+            if cache is not None and args[0].dim() == 2 and args[0].requires_grad and torch.is_grad_enabled():
                 cache.note_index(int(args[0].shape[0]), args[1])
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))

@@ -2372,7 +2372,10 @@ def test_per_entry_labels_give_the_same_bits_and_every_probability(K, d, dtype, 
         bound += pl._yw is not None
         assert all(torch.equal(a, b) for a, b in zip(want[1:], got[1:])), stepno
         del fresh, got, want, content
-    assert len(addresses) < 6 and bound == 0                          # addresses WERE reused, and no stream was ever bound to one
+    assert bound == 0                                                 # no stream was ever bound to a tensor seen once
+    # (whether the allocator really handed out the same address twice depends on its state — it did, 3 to 5 times out of 6,
+    # in the runs this test was written against; the by-object rule itself is pinned without an allocator in
+    # tests/test_host_cpu.py::test_label_stream_is_keyed_on_tensor_objects)
 
 
 @pytest.mark.gpu
@@ -2573,7 +2576,7 @@ def test_link_pred_indexed_with_fresh_index_tensors_every_step_is_learnt_by_obje
         plan = model._dense_plan.flat
         assert bool(torch.isin(torch.cat(taken), plan).all()), stepno
         del rows, cols, vals, a_pred, _h
-    assert len(addresses) < 5                                         # addresses WERE reused
+    # (address reuse depends on the allocator's state: typically 2 to 3 of the 5 steps share a rows / cols address)
 
 
 @pytest.mark.gpu

@@ -671,3 +671,34 @@ def test_graph_from_dense_takes_sparse_layouts_and_refuses_weights():
     for bad in (w, w.to_sparse()):
         with pytest.raises(ValueError, match="0 / 1"):
             Graph.from_dense(bad)
+
+
+def test_label_stream_is_keyed_on_tensor_objects():
+    """PairList.bind_labels: the per-entry (label, weight) stream follows the tensor OBJECTS and their version counters.  Two
+    tensors over the same memory (torch.from_numpy twice: same address, version 0 both) whose contents changed in between
+    are two different label vectors — the second must not get the first one's stream."""
+    from disenlink_amd.graph import PairList
+    rng = np.random.default_rng(1)
+    N, P = 50, 400
+    pu, pv = torch.from_numpy(rng.integers(0, N, P)), torch.from_numpy(rng.integers(0, N, P))
+    pl = PairList.build(pu, pv, N, build_by_u=False)
+    mem = rng.random(P).astype(np.float32)
+    weight = torch.full((P,), 0.5)
+    a = torch.from_numpy(mem)
+    pl.bind_labels(a, weight, P)
+    assert pl._yw is None                                            # first sight
+    pl.bind_labels(a, weight, P)
+    assert pl._yw is not None                                        # second sight of the same objects: bound
+    first = pl._yw.clone()
+    mem[:] = 1.0 - mem                                               # other contents, no version bump (written through numpy)
+    b = torch.from_numpy(mem)
+    assert b.data_ptr() == a.data_ptr() and b._version == a._version and b is not a
+    pl.bind_labels(b, weight, P)
+    assert pl._yw is None                                            # a NEW object: first sight again, nothing stale is used
+    pl.bind_labels(b, weight, P)
+    assert pl._yw is not None and not torch.equal(pl._yw[:, 0], first[:, 0])
+    q = pl.inc_pair.long()
+    assert torch.equal(pl._yw[:, 0], b[q]) and torch.equal(pl._yw[:, 1].abs(), weight[q])
+    a.add_(0)                                                        # an in-place write bumps the version: rebinding `a` starts over
+    pl.bind_labels(a, weight, P)
+    assert pl._yw is None
