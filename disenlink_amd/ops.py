@@ -21,14 +21,6 @@ from .graph import Graph, PairList
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
-def _stream_of(device) -> int:
-    """Handle of torch's current stream on `device` (keys the per-stream scratch)."""
-    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
-    if _raw_stream is not None:
-        return _raw_stream(idx)
-    return torch.cuda.current_stream(idx).cuda_stream
-
-
 def _stream() -> int:
     """Handle of torch's current stream on the current device (the raw getter where torch has it: a fifth of the host
     time of building a Stream object, ~25 times per training epoch)."""
@@ -84,19 +76,20 @@ def _empty_like(x):
 
 
 class _Workspace:
-    """Grow-only scratch per device AND stream; the C ABI never allocates.  Launches on one stream use their scratch one
-    after the other; two streams of one process (an evaluation beside a training step, two models) each get their own —
-    one buffer per device would be shared by kernels that run at the same time."""
+    """Grow-only scratch per device; the C ABI never allocates.  ONE buffer per device, whatever the stream: launches on one
+    stream use it one after the other — two streams of one process computing side by side would share it (INTEGRATION.md:
+    one compute stream per device, or order the streams).  (Per-stream buffers were tried at the end of round 6 and taken
+    back: every graph-replayed run warms up on a fresh side stream and captures on another, so the buffers — and the
+    captured graphs' memory pools they were allocated from — accumulated run after run.)"""
 
     def __init__(self):
         self.buf: dict = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device, _stream_of(device))
-        cur = self.buf.get(key)
+        cur = self.buf.get(device)
         if cur is None or cur.numel() < nbytes:
             cur = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=device)
-            self.buf[key] = cur
+            self.buf[device] = cur
         if _POISON:
             cur.fill_(0xFF)
         return cur
@@ -109,10 +102,9 @@ _bce_ws: dict = {}
 def _ws_bce(device) -> torch.Tensor:
     """dl_pair_bce's 8 KiB of scratch: a buffer of its own (the shared grow-only workspace is handed to the plans' kernels
     in the same step; the compiled binding passes all three scratch tensors into one call)."""
-    key = (device, _stream_of(device))
-    t = _bce_ws.get(key)
+    t = _bce_ws.get(device)
     if t is None:
-        t = _bce_ws[key] = torch.empty(8192, dtype=torch.uint8, device=device)
+        t = _bce_ws[device] = torch.empty(8192, dtype=torch.uint8, device=device)
     return t
 
 

@@ -2416,38 +2416,6 @@ def test_rows_of_several_units_summed_inside_the_launch_equal_the_combine_launch
             assert int(G.plan.unit_count.abs().sum()) == 0
 
 
-@pytest.mark.gpu
-def test_scratch_is_per_stream_and_two_streams_compute_side_by_side():
-    """The Python operators' grow-only scratch is per (device, stream): launches on one stream use it one after the other,
-    two streams of one process get their own — one buffer per device would be shared by kernels running at the same time.
-    Two training-scorer steps with partial slots (sliced incidence plans) issued side by side on two streams give the bits
-    of the same steps issued alone."""
-    from disenlink_amd import ops
-    from disenlink_amd.graph import PairList
-    G, pairs, Z, label, weight, pu, pv = _one_pass_case(8, 64, torch.float32, seed=5)
-    N = Z.shape[0]
-    H = ops.aggregate_fwd(G, Z, 0.6, *ops.route_fwd(G, Z, 1.0))
-    tpu, tpv = torch.from_numpy(pu).to(DEV), torch.from_numpy(pv).to(DEV)
-    plans = [PairList.build(tpu, tpv, N, build_by_u=False, row_bytes=2048, inc_slices=s) for s in (8, 4)]
-    Z2, H2 = (Z * 0.5).contiguous(), (H * 0.5).contiguous()
-    alone = [ops.score_pairs_train(Z, H, plans[0], 1.0, label, weight), ops.score_pairs_train(Z2, H2, plans[1], 1.0, label, weight)]
-    torch.cuda.synchronize()
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    with torch.cuda.stream(s1):
-        w1 = ops._ws.get(4096, Z.device)
-    with torch.cuda.stream(s2):
-        w2 = ops._ws.get(4096, Z.device)
-    assert w1.data_ptr() != w2.data_ptr() and ops._ws.get(4096, Z.device).data_ptr() not in (w1.data_ptr(), w2.data_ptr())
-    for rep in range(6):
-        with torch.cuda.stream(s1):
-            a = ops.score_pairs_train(Z, H, plans[0], 1.0, label, weight)
-        with torch.cuda.stream(s2):
-            b = ops.score_pairs_train(Z2, H2, plans[1], 1.0, label, weight)
-        torch.cuda.synchronize()
-        assert all(torch.equal(x, y) for x, y in zip(a[1:], alone[0][1:])), rep
-        assert all(torch.equal(x, y) for x, y in zip(b[1:], alone[1][1:])), rep
-
-
 def _early_stop_trace(aucs, patience):
     """main_disentangled.py:206-213 applied to a validation-AUC sequence -> (epochs run, best epoch, improved flags)."""
     best, stale, best_ep, flags = 0.0, 0, -1, []
